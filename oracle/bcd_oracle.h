@@ -1,0 +1,114 @@
+/*
+ * bcd_oracle.h -- CPU ORACLE for the BCD hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the reference algorithm (superboubek/bcd v1.1) used as the
+ * checker for the HIP path.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product (bcd_amd/)
+ * never links, imports or calls it.
+ *
+ * PARITY PIN STATUS
+ *   - pyramid reducers, merge/interpolate, spike filter, samples accumulator:
+ *     PINNED bit-exactly against the compiled reference translation units
+ *     (oracle/_ref, built by oracle/Makefile from /root/reference sources).
+ *   - Denoiser / DenoisingUnit core (distances, selection, Bayesian steps,
+ *     aggregation): PARITY UNPINNED.  The reference core needs Eigen
+ *     (include/bcd/core/DenoisingUnit.h:21-22), an un-vendored, un-pinned
+ *     submodule (.gitmodules:10-12, libigl/eigen) absent from this image, so it
+ *     is unbuildable here and the reference ships no tests or golden vectors.
+ *     The restatement follows the reference line by line (citations on each
+ *     function); Eigen's SelfAdjointEigenSolver is restated as the published
+ *     algorithm it implements (Householder tridiagonalisation + implicit
+ *     symmetric QL/QR with shifts, eigenvalues ascending).
+ *
+ * All images are interleaved row-major "DeepImage" buffers:
+ *     index = (line * W + col) * D + d       (include/bcd/core/DeepImage.hpp:385-396)
+ * All arithmetic is IEEE fp32, no FMA contraction (compile with -ffp-contract=off).
+ */
+#ifndef BCD_ORACLE_H
+#define BCD_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct BcdoParams {
+    float hist_dist_threshold; /* m_histogramDistanceThreshold (IDenoiser.h:36)  default 1   */
+    int   patch_radius;        /* m_patchRadius               (IDenoiser.h:37)  default 1   */
+    int   search_radius;       /* m_searchWindowRadius        (IDenoiser.h:38)  default 6   */
+    float min_eigen_value;     /* m_minEigenValue             (IDenoiser.h:39)  default 1e-8 */
+    float skip_probability;    /* m_markedPixelsSkippingProbability (:41); only 0 and 1 are
+                                  deterministic in the reference (rand() otherwise)          */
+    int   nb_threads;          /* OpenMP threads for the m=0 path (order-free); m=1 is serial */
+} BcdoParams;
+
+/* per-pixel diagnostics (all optional, may be NULL); W*H entries each */
+typedef struct BcdoDiag {
+    uint8_t *processed;   /* 1 if the main pixel was not skipped                              */
+    uint8_t *fallback;    /* 1 if processed through denoiseOnlyMainPatch (|S| < 3P+1)         */
+    int32_t *nb_similar;  /* |S| for processed pixels, -1 otherwise                           */
+} BcdoDiag;
+
+/* ---- a6: pre-pass  (src/core/Denoiser.cpp:357-373) ---- */
+void bcdo_pixel_cov_from_sample_cov(const float *cov, const float *nsamp, int W, int H, float *out);
+
+/* ---- a10: distances (src/core/DenoisingUnit.cpp:336-386) ---- */
+float bcdo_patch_distance(const float *hist, const float *nsamp, int W, int H, int D, int w,
+                          int pl, int pc, int ql, int qc);
+/* distances of main pixel (pl,pc) to its clipped window, row-major, written to out[(2b+1)^2]
+ * at slot (dl+b)*(2b+1)+(dc+b); slots outside the clipped window are set to +inf. */
+void bcdo_window_distances(const float *hist, const float *nsamp, int W, int H, int D, int w, int b,
+                           int pl, int pc, float *out);
+/* similarity bitmask for every pixel: bit k=(dl+b)*(2b+1)+(dc+b) of mask[p*words+k/32];
+ * non-main (border) pixels get an all-zero mask.  Returns words per pixel. */
+int bcdo_similarity_masks(const float *hist, const float *nsamp, int W, int H, int D, int w, int b,
+                          float tau, uint32_t *mask, int32_t *count, int nb_threads);
+
+/* ---- Eigen::SelfAdjointEigenSolver restatement (lower triangle read, ascending) ---- */
+void bcdo_sym_eig(int n, const float *A, float *evals, float *evecs /* column j = vector j, row-major [r*n+j] */);
+
+/* ---- a9..a16: monoscale denoiser (src/core/Denoiser.cpp:84-212, DenoisingUnit.cpp:157-693)
+ * order: visiting order of main pixels as linear indices line*W+col (NULL = scanline,
+ * the reference's 1-thread -r 0 order, Denoiser.cpp:136-146).  Returns 0 on success. ---- */
+int bcdo_denoise_mono(const float *colors, const float *nsamp, const float *hist, const float *cov,
+                      int W, int H, int D, const BcdoParams *prm,
+                      const int32_t *order, int64_t n_order,
+                      float *out, const BcdoDiag *diag);
+
+/* reference-style racy OpenMP m=1 run (shared mark image, strip order, dynamic schedule;
+ * Denoiser.cpp:164-205,375-414) -- for cpu_baseline timing only, NOT reproducible. */
+int bcdo_denoise_mono_omp_racy(const float *colors, const float *nsamp, const float *hist, const float *cov,
+                               int W, int H, int D, const BcdoParams *prm, float *out);
+
+/* ---- a18/a19: pyramid + merge (src/core/MultiscaleDenoiser.cpp:243-334,453-548) ---- */
+void bcdo_downscale_sum(const float *in, int W, int H, int D, float *out);
+void bcdo_downscale_avg(const float *in, int W, int H, int D, float *out);
+void bcdo_downscale_cov(const float *cov, const float *nsamp, int W, int H, int D, float *out);
+void bcdo_interpolate(const float *lo, int w, int h, int D, float *hi, int W, int H);
+void bcdo_merge(float *hi, int W, int H, const float *lo, int D);
+
+/* ---- a17: multiscale (src/core/MultiscaleDenoiser.cpp:31-136).
+ * orders[s] / n_orders[s] per scale (NULL => scanline at every scale). ---- */
+int bcdo_denoise_multiscale(const float *colors, const float *nsamp, const float *hist, const float *cov,
+                            int W, int H, int D, int nb_scales, const BcdoParams *prm,
+                            const int32_t *const *orders, const int64_t *n_orders,
+                            float *out, int racy_omp);
+
+/* ---- a20: spike removal prefilter (src/core/SpikeRemovalFilter.cpp:18-116), in place,
+ * float-abs semantics (MSVC / -include math.h). ---- */
+void bcdo_spike_filter(float *colors, float *nsamp, float *hist, float *cov, int W, int H, int D, float factor);
+
+/* ---- SamplesAccumulator (src/core/SamplesAccumulator.cpp:44-141) ----
+ * samples: n x 6 floats (line, col, r, g, b, weight); outputs must be zero-initialised by the caller?
+ * no: the function zeroes them.  hist depth = 3*nbins. */
+void bcdo_accumulate(const float *samples, int64_t n, int W, int H, int nbins, float gamma, float maxval,
+                     float *nsamp, float *mean, float *cov, float *hist);
+
+/* ---- CLI clean-up (src/cli/main.cpp:389-420) ---- */
+void bcdo_zero_bad_values(float *img, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
