@@ -1,0 +1,99 @@
+"""Build recipe of the native parts (hipcc, gfx950 only).  In-tree outputs under bcd_amd/lib/:
+    libbcd_hip.so   HIP kernels + the C ABI of include/bcd_hip.h
+    libbcdcore.so   C++ host library mirroring the reference's include/bcd API (calls the C ABI)
+    bcd_cli         the reference's command-line front-end re-implemented on top of libbcdcore
+Incremental by mtime; `python -m bcd_amd.build` or `bcd_amd.build.build_all()`."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+LIB = os.path.join(HERE, "lib")
+OBJ = os.path.join(LIB, "obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# -ffp-contract=off: the reference CPU path is built without FMA contraction and the similarity test is a
+# hard threshold; kernels call fmaf() explicitly where fusing is wanted.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
+             "-Wno-unused-result", "-Wno-unused-value", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+CXX_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-fopenmp"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build_hip(verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "bcd_hip.h")]
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ, s[:-4] + ".o")
+        objs.append(o)
+        if _newer(o, [os.path.join(CSRC, s)] + hdrs):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-c", os.path.join(CSRC, s), "-o", o])
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for out in ex.map(_run, jobs):
+            if verbose and out.strip():
+                print(out)
+    so = os.path.join(LIB, "libbcd_hip.so")
+    if _newer(so, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
+    return so
+
+
+def build_host(verbose=False):
+    """C++ host library + CLI (g++; links libbcd_hip.so)."""
+    if not os.path.isdir(HOST):
+        return None
+    os.makedirs(OBJ, exist_ok=True)
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "bcd", "core"),
+           "-I" + os.path.join(ROOT, "include", "bcd", "io")]
+    hdrs = []
+    for d, _, fs in os.walk(os.path.join(ROOT, "include")):
+        hdrs += [os.path.join(d, f) for f in fs]
+    lib_srcs = sorted(f for f in os.listdir(HOST) if f.endswith(".cpp") and f != "bcd_cli.cpp")
+    if not lib_srcs:
+        return None
+    objs, jobs = [], []
+    for s in lib_srcs:
+        o = os.path.join(OBJ, "host_" + s[:-4] + ".o")
+        objs.append(o)
+        if _newer(o, [os.path.join(HOST, s)] + hdrs):
+            jobs.append(["g++"] + CXX_FLAGS + inc + ["-c", os.path.join(HOST, s), "-o", o])
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(_run, jobs))
+    so = os.path.join(LIB, "libbcdcore.so")
+    if _newer(so, objs + [os.path.join(LIB, "libbcd_hip.so")]):
+        _run(["g++", "-shared", "-fPIC", "-fopenmp", "-o", so] + objs + ["-L" + LIB, "-lbcd_hip", "-lz", "-Wl,-rpath,$ORIGIN"])
+    cli_src = os.path.join(HOST, "bcd_cli.cpp")
+    if os.path.exists(cli_src):
+        exe = os.path.join(LIB, "bcd_cli")
+        if _newer(exe, [cli_src, so] + hdrs):
+            _run(["g++"] + CXX_FLAGS + inc + [cli_src, "-o", exe, "-L" + LIB, "-lbcdcore", "-lbcd_hip", "-lz", "-Wl,-rpath,$ORIGIN"])
+    return so
+
+
+def build_all(verbose=False):
+    so = build_hip(verbose)
+    build_host(verbose)
+    return so
+
+
+if __name__ == "__main__":
+    print(build_all(verbose="-v" in sys.argv))

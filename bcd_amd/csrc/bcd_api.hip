@@ -1,0 +1,564 @@
+// bcd_api.hip -- implementation of the C ABI declared in include/bcd_hip.h: context, workspace,
+// the per-scale driver (Denoiser::denoise, src/core/Denoiser.cpp:84-212) and the multiscale driver
+// (MultiscaleDenoiser::denoise, src/core/MultiscaleDenoiser.cpp:31-136) on device-resident images.
+#include "../../include/bcd_hip.h"
+#include "bcd_common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+// launchers implemented in the k_*.hip files
+size_t bcd_pairdist_lds_bytes(int D, int b);
+hipError_t bcd_launch_pairdist(const float *, const float *, int, int, int, int, float *, uint8_t *, hipStream_t);
+hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, hipStream_t);
+hipError_t bcd_launch_window_distances(const float *, const uint8_t *, int, int, int, int, int, int, float *, hipStream_t);
+hipError_t bcd_launch_pixel_cov(const float *, const float *, int64_t, float *, hipStream_t);
+hipError_t bcd_launch_finalize(const float *, const int32_t *, int64_t, float *, hipStream_t);
+hipError_t bcd_launch_zero_bad(float *, int64_t, hipStream_t);
+hipError_t bcd_launch_downscale(int, const float *, int, int, int, float *, hipStream_t);
+hipError_t bcd_launch_downscale_cov(const float *, const float *, int, int, float *, hipStream_t);
+hipError_t bcd_launch_interpolate(int, const float *, int, int, int, float *, int, int, hipStream_t);
+hipError_t bcd_launch_spike(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *,
+                            float *, float *, hipStream_t);
+hipError_t bcd_launch_active_init(const int32_t *, int, int, int, int, int, float, uint32_t, uint8_t *, hipStream_t);
+hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int *, hipStream_t);
+hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
+size_t bcd_bayes_lds_bytes(int w, int b);
+hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, int, int, int, int, int, float,
+                                   float *, int32_t *, hipStream_t);
+hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, int, int, int, int, int, float *, int32_t *,
+                                 hipStream_t);
+
+namespace {
+
+constexpr int MAX_SCALES = 16;
+constexpr int ROUND_BATCH = 4;
+constexpr int MAX_EVENT_PAIRS = 4096;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct bcd_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    bool profiling = false;
+    std::string err;
+    bcd_hip_scale_stats stats[MAX_SCALES];
+    // grow-only workspace
+    DevBuf T, Cn, mask, nsim, state, strong, weak, counters, pixcov, sum, cnt, tmp_lo;
+    DevBuf pyr[MAX_SCALES][5]; // colours, nsamples, hist, cov, out
+    int32_t *h_counters = nullptr; // pinned
+    // pair-distance kernel timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    int ev_used = 0;
+    hipEvent_t ev_stage[4] = { nullptr, nullptr, nullptr, nullptr };
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                                             \
+    do {                                                                                                              \
+        hipError_t e__ = (expr);                                                                                      \
+        if (e__ != hipSuccess) {                                                                                      \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                          \
+            return BCD_HIP_EDEVICE;                                                                                   \
+        }                                                                                                             \
+    } while (0)
+
+#define RCCHK(expr)                                                                                                   \
+    do {                                                                                                              \
+        int rc__ = (expr);                                                                                            \
+        if (rc__ != BCD_HIP_OK) return rc__;                                                                          \
+    } while (0)
+
+int ensure(bcd_hip_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (b.bytes >= bytes && b.p) return BCD_HIP_OK;
+    if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    size_t want = bytes + bytes / 16 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { ctx->err = "hipMalloc failed: " + std::string(hipGetErrorString(e)); b.p = nullptr; return BCD_HIP_ENOMEM; }
+    b.bytes = want;
+    return BCD_HIP_OK;
+}
+
+int bad(bcd_hip_ctx *ctx, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return BCD_HIP_EINVAL;
+}
+
+int check_params(bcd_hip_ctx *ctx, int W, int H, int D, const bcd_hip_params *prm)
+{
+    if (!prm) return bad(ctx, "null parameters");
+    if (W <= 0 || H <= 0 || D <= 0) return bad(ctx, "empty input image");            // Denoiser.cpp:294-320
+    if (prm->patch_radius < 0 || prm->search_radius < 0) return bad(ctx, "negative radius");
+    if (W < 2 * prm->patch_radius + 1 || H < 2 * prm->patch_radius + 1) return bad(ctx, "image smaller than a patch");
+    if (D > 255) { ctx->err = "histogram depth > 255 is not supported"; return BCD_HIP_EUNSUPPORTED; }
+    int side = 2 * prm->search_radius + 1;
+    if ((side * side + 31) / 32 > 32) { ctx->err = "search radius > 15 is not supported"; return BCD_HIP_EUNSUPPORTED; }
+    if (bcd_bayes_lds_bytes(prm->patch_radius, prm->search_radius) > 160 * 1024) {
+        ctx->err = "patch/search radius combination exceeds the 160 KiB LDS working set";
+        return BCD_HIP_EUNSUPPORTED;
+    }
+    if ((int64_t)W * H >= (1ll << 31) / (D > 6 ? D : 6)) return bad(ctx, "image too large for 32-bit DeepImage indices");
+    return BCD_HIP_OK;
+}
+
+int similarity(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
+               uint32_t *d_mask, int32_t *d_count)
+{
+    const size_t npix = (size_t)W * H;
+    const int nd = bcd_delta_count(b);
+    RCCHK(ensure(ctx, ctx->T, npix * nd * sizeof(float)));
+    RCCHK(ensure(ctx, ctx->Cn, npix * nd));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->ev_used < MAX_EVENT_PAIRS) {
+        if (ctx->ev_used == (int)ctx->ev_pool.size()) {
+            hipEvent_t a, c;
+            HIPCHK(ctx, hipEventCreate(&a));
+            HIPCHK(ctx, hipEventCreate(&c));
+            ctx->ev_pool.emplace_back(a, c);
+        }
+        e0 = ctx->ev_pool[ctx->ev_used].first;
+        e1 = ctx->ev_pool[ctx->ev_used].second;
+        ++ctx->ev_used;
+        HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, ctx->stream));
+    if (e1) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    HIPCHK(ctx, bcd_launch_masks((const float *)ctx->T.p, (const uint8_t *)ctx->Cn.p, W, H, w, b, tau, d_mask, d_count, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
+               int row_end, float skip_prob, int random_order, uint32_t seed, uint8_t *d_state, int32_t *rounds_out)
+{
+    const int K = 3 * (2 * w + 1) * (2 * w + 1);
+    HIPCHK(ctx, bcd_launch_active_init(d_nsim, W, H, w, row_begin, row_end, skip_prob, seed, d_state, ctx->stream));
+    int rounds = 0;
+    if (skip_prob > 0.f) {
+        RCCHK(ensure(ctx, ctx->counters, 64 * sizeof(int32_t)));
+        int *d_cnt = (int *)ctx->counters.p;
+        const int max_rounds = 4 * (W + H) + 64;
+        bool done = false;
+        while (!done && rounds < max_rounds) {
+            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), ctx->stream));
+            for (int i = 0; i < ROUND_BATCH; ++i)
+                HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, d_cnt + i, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < ROUND_BATCH; ++i) {
+                ++rounds;
+                if (ctx->h_counters[i] == 0) { done = true; break; }
+            }
+        }
+        if (!done) { ctx->err = "marking fixed point did not converge"; return BCD_HIP_EDEVICE; }
+    }
+    if (rounds_out) *rounds_out = rounds;
+    return BCD_HIP_OK;
+}
+
+int bayes(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask, const int32_t *d_nsim,
+          const uint8_t *d_state, int W, int H, int w, int b, float min_eig, float *d_sum, int32_t *d_count,
+          int64_t *n_strong, int64_t *n_weak, int64_t *sim_total)
+{
+    const int64_t npix = (int64_t)W * H;
+    const int K = 3 * (2 * w + 1) * (2 * w + 1);
+    RCCHK(ensure(ctx, ctx->strong, npix * sizeof(int32_t)));
+    RCCHK(ensure(ctx, ctx->weak, npix * sizeof(int32_t)));
+    RCCHK(ensure(ctx, ctx->counters, 64 * sizeof(int32_t)));
+    int32_t *d_c = (int32_t *)ctx->counters.p + 16;
+    HIPCHK(ctx, hipMemsetAsync(d_c, 0, 4 * sizeof(int32_t), ctx->stream));
+    HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)ctx->strong.p, (int32_t *)ctx->weak.p, d_c, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int ns = ctx->h_counters[16], nw = ctx->h_counters[17];
+    int64_t tot;
+    memcpy(&tot, ctx->h_counters + 18, sizeof(tot));
+    if (n_strong) *n_strong = ns;
+    if (n_weak) *n_weak = nw;
+    if (sim_total) *sim_total = tot;
+    HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)ctx->strong.p, ns, W, H, w, b, min_eig, d_sum, d_count, ctx->stream));
+    HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)ctx->weak.p, nw, W, H, w, b, d_sum, d_count, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+float stage_ms(bcd_hip_ctx *ctx, int a, int b)
+{
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ctx->ev_stage[a], ctx->ev_stage[b]);
+    return ms;
+}
+
+// one scale: accumulators only (d_sum / d_count are zeroed here)
+int mono_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov,
+                    int W, int H, int D, int row_begin, int row_end, const bcd_hip_params *prm, uint32_t seed, int scale,
+                    float *d_sum, int32_t *d_count)
+{
+    const int w = prm->patch_radius, b = prm->search_radius;
+    const size_t npix = (size_t)W * H;
+    const int side = 2 * b + 1, words = (side * side + 31) / 32;
+    RCCHK(ensure(ctx, ctx->pixcov, npix * 6 * sizeof(float)));
+    RCCHK(ensure(ctx, ctx->mask, npix * words * sizeof(uint32_t)));
+    RCCHK(ensure(ctx, ctx->nsim, npix * sizeof(int32_t)));
+    RCCHK(ensure(ctx, ctx->state, npix));
+    bcd_hip_scale_stats &st = ctx->stats[scale < MAX_SCALES ? scale : MAX_SCALES - 1];
+    memset(&st, 0, sizeof(st));
+    st.width = W; st.height = H;
+    st.main_pixels = (int64_t)std::max(0, W - 2 * w) * std::max(0, std::min(row_end, H - w) - std::max(row_begin, w));
+    const bool prof = ctx->profiling;
+    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev_stage[0], ctx->stream));
+    HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)ctx->pixcov.p, ctx->stream));
+    RCCHK(similarity(ctx, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)ctx->mask.p, (int32_t *)ctx->nsim.p));
+    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev_stage[1], ctx->stream));
+    RCCHK(active_set(ctx, (const uint32_t *)ctx->mask.p, (const int32_t *)ctx->nsim.p, W, H, w, b, row_begin, row_end,
+                     prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)ctx->state.p, &st.active_rounds));
+    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev_stage[2], ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), ctx->stream));
+    int64_t ns = 0, nw = 0, tot = 0;
+    RCCHK(bayes(ctx, d_colors, (const float *)ctx->pixcov.p, (const uint32_t *)ctx->mask.p, (const int32_t *)ctx->nsim.p,
+                (const uint8_t *)ctx->state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count, &ns, &nw, &tot));
+    st.processed = ns + nw; st.fallback = nw; st.similar_total = tot;
+    if (prof) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_stage[3], ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        st.ms_similarity = stage_ms(ctx, 0, 1);
+        st.ms_active = stage_ms(ctx, 1, 2);
+        st.ms_bayes = stage_ms(ctx, 2, 3);
+        st.ms_total = stage_ms(ctx, 0, 3);
+    }
+    return BCD_HIP_OK;
+}
+
+int mono(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov, int W, int H, int D,
+         const bcd_hip_params *prm, uint32_t seed, int scale, float *d_out)
+{
+    const size_t npix = (size_t)W * H;
+    RCCHK(ensure(ctx, ctx->sum, npix * 3 * sizeof(float)));
+    RCCHK(ensure(ctx, ctx->cnt, npix * sizeof(int32_t)));
+    RCCHK(mono_accumulate(ctx, d_colors, d_ns, d_hist, d_cov, W, H, D, 0, H, prm, seed, scale, (float *)ctx->sum.p, (int32_t *)ctx->cnt.p));
+    HIPCHK(ctx, bcd_launch_finalize((const float *)ctx->sum.p, (const int32_t *)ctx->cnt.p, (int64_t)npix, d_out, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+} // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int bcd_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void bcd_hip_default_params(bcd_hip_params *p)
+{
+    if (!p) return;
+    p->hist_dist_threshold = 1.f;   // IDenoiser.h:23-31
+    p->patch_radius = 1;
+    p->search_radius = 6;
+    p->min_eigen_value = 1.e-8f;
+    p->use_random_pixel_order = 1;
+    p->marked_skip_probability = 1.f;
+    p->order_seed = 1234u;
+}
+
+int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
+{
+    if (!out) return BCD_HIP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0 || device < 0 || device >= n) return BCD_HIP_EDEVICE;
+    if (hipSetDevice(device) != hipSuccess) return BCD_HIP_EDEVICE;
+    bcd_hip_ctx *ctx = new (std::nothrow) bcd_hip_ctx();
+    if (!ctx) return BCD_HIP_ENOMEM;
+    ctx->device = device;
+    memset(ctx->stats, 0, sizeof(ctx->stats));
+    if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
+    else {
+        if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return BCD_HIP_EDEVICE; }
+        ctx->owns_stream = true;
+    }
+    if (hipHostMalloc((void **)&ctx->h_counters, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { delete ctx; return BCD_HIP_ENOMEM; }
+    for (int i = 0; i < 4; ++i)
+        if (hipEventCreate(&ctx->ev_stage[i]) != hipSuccess) { delete ctx; return BCD_HIP_EDEVICE; }
+    *out = ctx;
+    return BCD_HIP_OK;
+}
+
+void bcd_hip_ctx_destroy(bcd_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = { &ctx->T, &ctx->Cn, &ctx->mask, &ctx->nsim, &ctx->state, &ctx->strong, &ctx->weak, &ctx->counters,
+                       &ctx->pixcov, &ctx->sum, &ctx->cnt, &ctx->tmp_lo };
+    for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    for (int s = 0; s < MAX_SCALES; ++s)
+        for (int k = 0; k < 5; ++k) if (ctx->pyr[s][k].p) hipFree(ctx->pyr[s][k].p);
+    if (ctx->h_counters) hipHostFree(ctx->h_counters);
+    for (auto &pr : ctx->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (int i = 0; i < 4; ++i) if (ctx->ev_stage[i]) hipEventDestroy(ctx->ev_stage[i]);
+    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *bcd_hip_last_error(const bcd_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int bcd_hip_set_profiling(bcd_hip_ctx *ctx, int enabled)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    ctx->profiling = enabled != 0;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_get_stats(const bcd_hip_ctx *ctx, int scale, bcd_hip_scale_stats *out)
+{
+    if (!ctx || !out || scale < 0 || scale >= MAX_SCALES) return BCD_HIP_EINVAL;
+    *out = ctx->stats[scale];
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_kernel_time(const bcd_hip_ctx *cctx, float *ms_pairdist, int32_t *launches)
+{
+    bcd_hip_ctx *ctx = const_cast<bcd_hip_ctx *>(cctx);
+    if (!ctx) return BCD_HIP_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float tot = 0.f;
+    for (int i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        tot += ms;
+    }
+    if (ms_pairdist) *ms_pairdist = tot;
+    if (launches) *launches = ctx->ev_used;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_reset_kernel_time(bcd_hip_ctx *ctx)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ev_used = 0;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov,
+                    int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *d_out)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    if (!d_colors || !d_ns || !d_hist || !d_cov || !d_out) return bad(ctx, "null image pointer"); // Denoiser.cpp:266-293
+    RCCHK(check_params(ctx, W, H, D, prm));
+    if (nb_scales < 1 || nb_scales > MAX_SCALES) return bad(ctx, "bad number of scales");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (nb_scales == 1) return mono(ctx, d_colors, d_ns, d_hist, d_cov, W, H, D, prm, bcd_hip_scale_seed(prm->order_seed, 0), 0, d_out);
+
+    // ---- pyramids (MultiscaleDenoiser.cpp:41-53): level s has dims of level s-1 // 2
+    const float *col[MAX_SCALES], *ns[MAX_SCALES], *hs[MAX_SCALES], *cv[MAX_SCALES];
+    float *out[MAX_SCALES];
+    int ws[MAX_SCALES], hh[MAX_SCALES];
+    col[0] = d_colors; ns[0] = d_ns; hs[0] = d_hist; cv[0] = d_cov; out[0] = d_out; ws[0] = W; hh[0] = H;
+    for (int s = 1; s < nb_scales; ++s) {
+        ws[s] = ws[s - 1] / 2; hh[s] = hh[s - 1] / 2;
+        if (ws[s] < 2 * prm->patch_radius + 1 || hh[s] < 2 * prm->patch_radius + 1) return bad(ctx, "too many scales for this image size");
+        size_t np = (size_t)ws[s] * hh[s];
+        RCCHK(ensure(ctx, ctx->pyr[s][0], np * 3 * sizeof(float)));
+        RCCHK(ensure(ctx, ctx->pyr[s][1], np * sizeof(float)));
+        RCCHK(ensure(ctx, ctx->pyr[s][2], np * D * sizeof(float)));
+        RCCHK(ensure(ctx, ctx->pyr[s][3], np * 6 * sizeof(float)));
+        RCCHK(ensure(ctx, ctx->pyr[s][4], np * 3 * sizeof(float)));
+        HIPCHK(ctx, bcd_launch_downscale(1, col[s - 1], ws[s - 1], hh[s - 1], 3, (float *)ctx->pyr[s][0].p, ctx->stream));
+        HIPCHK(ctx, bcd_launch_downscale(0, ns[s - 1], ws[s - 1], hh[s - 1], 1, (float *)ctx->pyr[s][1].p, ctx->stream));
+        HIPCHK(ctx, bcd_launch_downscale(0, hs[s - 1], ws[s - 1], hh[s - 1], D, (float *)ctx->pyr[s][2].p, ctx->stream));
+        HIPCHK(ctx, bcd_launch_downscale_cov(cv[s - 1], ns[s - 1], ws[s - 1], hh[s - 1], (float *)ctx->pyr[s][3].p, ctx->stream));
+        col[s] = (float *)ctx->pyr[s][0].p; ns[s] = (float *)ctx->pyr[s][1].p; hs[s] = (float *)ctx->pyr[s][2].p;
+        cv[s] = (float *)ctx->pyr[s][3].p; out[s] = (float *)ctx->pyr[s][4].p;
+    }
+    // ---- coarse to fine (MultiscaleDenoiser.cpp:79-134)
+    for (int s = nb_scales - 1; s >= 0; --s) {
+        RCCHK(mono(ctx, col[s], ns[s], hs[s], cv[s], ws[s], hh[s], D, prm, bcd_hip_scale_seed(prm->order_seed, s), s, out[s]));
+        if (s < nb_scales - 1) RCCHK(bcd_hip_merge(ctx, out[s], ws[s], hh[s], out[s + 1], 3));
+    }
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_denoise_band(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov,
+                         int W, int H, int D, int main_row_begin, int main_row_end, const bcd_hip_params *prm, uint32_t order_seed,
+                         float *d_sum, int32_t *d_count)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    if (!d_colors || !d_ns || !d_hist || !d_cov || !d_sum || !d_count) return bad(ctx, "null image pointer");
+    RCCHK(check_params(ctx, W, H, D, prm));
+    if (main_row_begin < 0 || main_row_end > H || main_row_begin > main_row_end) return bad(ctx, "bad main row range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return mono_accumulate(ctx, d_colors, d_ns, d_hist, d_cov, W, H, D, main_row_begin, main_row_end, prm, order_seed, 0, d_sum, d_count);
+}
+
+int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_ns, const float *h_hist, const float *h_cov,
+                         int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    if (!h_colors || !h_ns || !h_hist || !h_cov || !h_out) return bad(ctx, "null image pointer");
+    RCCHK(check_params(ctx, W, H, D, prm));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t np = (size_t)W * H;
+    float *d[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    const size_t sz[5] = { np * 3, np, np * D, np * 6, np * 3 };
+    const float *src[4] = { h_colors, h_ns, h_hist, h_cov };
+    int rc = BCD_HIP_OK;
+    for (int i = 0; i < 5 && rc == BCD_HIP_OK; ++i)
+        if (hipMalloc((void **)&d[i], sz[i] * sizeof(float)) != hipSuccess) { ctx->err = "hipMalloc failed for host-path staging"; rc = BCD_HIP_ENOMEM; }
+    for (int i = 0; i < 4 && rc == BCD_HIP_OK; ++i)
+        if (hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D copy failed"; rc = BCD_HIP_EDEVICE; }
+    if (rc == BCD_HIP_OK) rc = bcd_hip_denoise(ctx, d[0], d[1], d[2], d[3], W, H, D, nb_scales, prm, d[4]);
+    if (rc == BCD_HIP_OK && hipMemcpyAsync(h_out, d[4], sz[4] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = BCD_HIP_EDEVICE; }
+    hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 5; ++i) if (d[i]) hipFree(d[i]);
+    return rc;
+}
+
+// ---- stages -------------------------------------------------------------------------------------------
+int bcd_hip_pixel_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_ns, int W, int H, float *d_out)
+{
+    if (!ctx || !d_cov || !d_ns || !d_out || W <= 0 || H <= 0) return bad(ctx, "bad argument");
+    HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)W * H, d_out, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_similarity_masks(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
+                             uint32_t *d_mask, int32_t *d_count)
+{
+    if (!ctx || !d_hist || !d_ns || !d_mask || !d_count) return bad(ctx, "bad argument");
+    bcd_hip_params p; bcd_hip_default_params(&p); p.patch_radius = w; p.search_radius = b;
+    RCCHK(check_params(ctx, W, H, D, &p));
+    return similarity(ctx, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count);
+}
+
+int bcd_hip_window_distances(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b,
+                             int line, int col, float *h_out)
+{
+    if (!ctx || !d_hist || !d_ns || !h_out) return bad(ctx, "bad argument");
+    bcd_hip_params p; bcd_hip_default_params(&p); p.patch_radius = w; p.search_radius = b;
+    RCCHK(check_params(ctx, W, H, D, &p));
+    if (line < w || line > H - 1 - w || col < w || col > W - 1 - w) return bad(ctx, "not a main pixel");
+    const size_t npix = (size_t)W * H;
+    const int nd = bcd_delta_count(b), n = (2 * b + 1) * (2 * b + 1);
+    RCCHK(ensure(ctx, ctx->T, npix * nd * sizeof(float)));
+    RCCHK(ensure(ctx, ctx->Cn, npix * nd));
+    RCCHK(ensure(ctx, ctx->tmp_lo, n * sizeof(float)));
+    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, ctx->stream));
+    HIPCHK(ctx, bcd_launch_window_distances((const float *)ctx->T.p, (const uint8_t *)ctx->Cn.p, W, H, w, b, line, col, (float *)ctx->tmp_lo.p, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->tmp_lo.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_count, int W, int H, int w, int b,
+                       int main_row_begin, int main_row_end, float skip_probability, int random_order, uint32_t seed,
+                       uint8_t *d_state, int32_t *rounds)
+{
+    if (!ctx || !d_mask || !d_count || !d_state) return bad(ctx, "bad argument");
+    return active_set(ctx, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, skip_probability, random_order, seed, d_state, rounds);
+}
+
+int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask,
+                             const int32_t *d_nsim, const uint8_t *d_state, int W, int H, int w, int b, float min_eig,
+                             float *d_sum, int32_t *d_count)
+{
+    if (!ctx || !d_colors || !d_pixcov || !d_mask || !d_nsim || !d_state || !d_sum || !d_count) return bad(ctx, "bad argument");
+    return bayes(ctx, d_colors, d_pixcov, d_mask, d_nsim, d_state, W, H, w, b, min_eig, d_sum, d_count, nullptr, nullptr, nullptr);
+}
+
+int bcd_hip_finalize(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int64_t npix, float *d_out)
+{
+    if (!ctx || !d_sum || !d_count || !d_out || npix <= 0) return bad(ctx, "bad argument");
+    HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, npix, d_out, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_downscale_sum(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int D, float *d_out)
+{
+    if (!ctx || !d_in || !d_out || W < 2 || H < 2 || D <= 0) return bad(ctx, "bad argument");
+    HIPCHK(ctx, bcd_launch_downscale(0, d_in, W, H, D, d_out, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_downscale_avg(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int D, float *d_out)
+{
+    if (!ctx || !d_in || !d_out || W < 2 || H < 2 || D <= 0) return bad(ctx, "bad argument");
+    HIPCHK(ctx, bcd_launch_downscale(1, d_in, W, H, D, d_out, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_downscale_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_ns, int W, int H, float *d_out)
+{
+    if (!ctx || !d_cov || !d_ns || !d_out || W < 2 || H < 2) return bad(ctx, "bad argument");
+    HIPCHK(ctx, bcd_launch_downscale_cov(d_cov, d_ns, W, H, d_out, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_interpolate(bcd_hip_ctx *ctx, const float *d_lo, int w, int h, int D, float *d_hi, int W, int H)
+{
+    if (!ctx || !d_lo || !d_hi || w != W / 2 || h != H / 2 || w <= 0 || h <= 0 || D <= 0) return bad(ctx, "bad argument");
+    HIPCHK(ctx, bcd_launch_interpolate(0, d_lo, w, h, D, d_hi, W, H, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_merge(bcd_hip_ctx *ctx, float *d_hi, int W, int H, const float *d_lo, int D)
+{
+    if (!ctx || !d_hi || !d_lo || W < 2 || H < 2 || D <= 0) return bad(ctx, "bad argument");
+    const int w2 = W / 2, h2 = H / 2;
+    RCCHK(ensure(ctx, ctx->tmp_lo, (size_t)w2 * h2 * D * sizeof(float)));
+    // mergeOutputs (MultiscaleDenoiser.cpp:453-466): hi -= up(down(hi)); hi += up(lo)
+    HIPCHK(ctx, bcd_launch_downscale(1, d_hi, W, H, D, (float *)ctx->tmp_lo.p, ctx->stream));
+    HIPCHK(ctx, bcd_launch_interpolate(1, (const float *)ctx->tmp_lo.p, w2, h2, D, d_hi, W, H, ctx->stream));
+    HIPCHK(ctx, bcd_launch_interpolate(2, d_lo, w2, h2, D, d_hi, W, H, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_spike_filter(bcd_hip_ctx *ctx, const float *d_col, const float *d_ns, const float *d_hist, const float *d_cov, int W, int H,
+                         int D, float factor, float *o_col, float *o_ns, float *o_hist, float *o_cov)
+{
+    if (!ctx || !d_col || !d_ns || !d_hist || !d_cov || !o_col || !o_ns || !o_hist || !o_cov) return bad(ctx, "bad argument");
+    if (W < 3 || H < 3 || D <= 0) return bad(ctx, "image smaller than 3x3");
+    HIPCHK(ctx, bcd_launch_spike(d_col, d_ns, d_hist, d_cov, W, H, D, factor, o_col, o_ns, o_hist, o_cov, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_zero_bad_values(bcd_hip_ctx *ctx, float *d_img, int64_t n)
+{
+    if (!ctx || !d_img || n <= 0) return bad(ctx, "bad argument");
+    HIPCHK(ctx, bcd_launch_zero_bad(d_img, n, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+// ---- host utilities -------------------------------------------------------------------------------------
+uint32_t bcd_hip_scale_seed(uint32_t seed0, int scale) { return seed0 + (uint32_t)scale; }
+
+int bcd_hip_visit_order(int W, int H, int w, int random_order, uint32_t seed, int32_t *h_order)
+{
+    if (!h_order || W < 2 * w + 1 || H < 2 * w + 1 || w < 0) return BCD_HIP_EINVAL;
+    std::vector<uint64_t> keys;
+    keys.reserve((size_t)(W - 2 * w) * (H - 2 * w));
+    for (int l = w; l <= H - 1 - w; ++l)
+        for (int c = w; c <= W - 1 - w; ++c) keys.push_back(bcd_order_key((uint32_t)(l * W + c), random_order, seed));
+    std::sort(keys.begin(), keys.end());
+    for (size_t i = 0; i < keys.size(); ++i) h_order[i] = (int32_t)(keys[i] & 0xffffffffu);
+    return BCD_HIP_OK;
+}
+
+} // extern "C"

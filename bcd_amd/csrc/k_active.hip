@@ -1,0 +1,120 @@
+// k_active.hip -- the "marking strategy" of the reference as a parallel fixed point.
+//
+// Reference (src/core/DenoisingUnit.cpp:164-173,182-191,690): main pixels are visited in a fixed order;
+// a pixel is skipped when it was marked by an earlier processed pixel q with |S(q)| >= 3P+1 and p in S(q);
+// pixels processed through the fallback path (|S| < 3P+1) mark nobody.  Because distances are bitwise
+// symmetric, p in S(q) <=> q in S(p), so with the visiting order expressed as a key:
+//     p is processed  <=>  no q in S(p) with key(q) < key(p), |S(q)| >= 3P+1, q processed.
+// This is the lexicographically-first independent-set construction on the similarity graph; it has a
+// unique solution, reached by iterating "decide p once all its earlier strong similar neighbours are
+// decided".  With a random order the dependency depth is O(log^2 n) (Blelloch, Fineman, Shun 2012).
+#include "bcd_common.h"
+
+namespace {
+
+__global__ void k_active_init(const int32_t *__restrict__ nsim, int W, int H, int w, int row_begin, int row_end,
+                              float skip_prob, uint32_t seed, uint8_t *__restrict__ state)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    size_t p = (size_t)r * W + c;
+    uint8_t s = BCD_ST_NONE;
+    if (r >= w && r <= H - 1 - w && c >= w && c <= W - 1 - w && r >= row_begin && r < row_end) {
+        if (skip_prob <= 0.f) s = BCD_ST_IN;
+        else if (skip_prob >= 1.f) s = BCD_ST_UNDECIDED;
+        else s = (bcd_unit_hash((uint32_t)p, seed) < skip_prob) ? BCD_ST_UNDECIDED : BCD_ST_IN; // never skipped when marked
+    }
+    state[p] = s;
+}
+
+__global__ __launch_bounds__(256) void k_active_round(const uint32_t *__restrict__ mask, const int32_t *__restrict__ nsim,
+                                                      uint8_t *state, int W, int H, int b, int words, int min_strong,
+                                                      int random_order, uint32_t seed, int *__restrict__ undecided)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    bool still = false;
+    if (c < W) {
+        size_t p = (size_t)r * W + c;
+        if (state[p] == BCD_ST_UNDECIDED) {
+            const uint64_t keyp = bcd_order_key((uint32_t)p, random_order, seed);
+            const int side = 2 * b + 1;
+            bool any_in = false, all_decided = true;
+            for (int j = 0; j < words && !any_in; ++j) {
+                uint32_t m = mask[p * words + j];
+                while (m) {
+                    int bit = __ffs(m) - 1;
+                    m &= m - 1;
+                    int k = j * 32 + bit;
+                    int dl = k / side - b, dc = k % side - b;
+                    size_t q = (size_t)(r + dl) * W + (c + dc);
+                    if (q == p) continue;
+                    if (nsim[q] < min_strong) continue;                 // fallback pixels mark nobody
+                    if (bcd_order_key((uint32_t)q, random_order, seed) > keyp) continue; // visited later
+                    uint8_t sq = state[q];
+                    if (sq == BCD_ST_IN) { any_in = true; break; }
+                    if (sq == BCD_ST_UNDECIDED) all_decided = false;
+                    // BCD_ST_OUT / BCD_ST_NONE (outside this band): never processed here -> marks nobody
+                }
+            }
+            if (any_in) state[p] = BCD_ST_OUT;
+            else if (all_decided) state[p] = BCD_ST_IN;
+            else still = true;
+        }
+    }
+    unsigned long long bal = __ballot(still);
+    if (bal && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)bal) - 1)) atomicAdd(undecided, __popcll(bal));
+}
+
+// compact lists of processed pixels: strong (full Bayesian path) and weak (fallback path)
+__global__ __launch_bounds__(256) void k_active_lists(const uint8_t *__restrict__ state, const int32_t *__restrict__ nsim,
+                                                      int64_t npix, int min_strong,
+                                                      int32_t *__restrict__ strong_list, int32_t *__restrict__ weak_list,
+                                                      int32_t *__restrict__ counters /* [0]=strong [1]=weak, [2..3] sum |S| (lo,hi) */)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool in = p < npix && state[p] == BCD_ST_IN;
+    int n = in ? nsim[p] : 0;
+    bool strong = in && n >= min_strong, weak = in && n < min_strong;
+    unsigned long long bs = __ballot(strong), bw = __ballot(weak);
+    int lane = threadIdx.x & 63;
+    unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int base_s = 0, base_w = 0;
+    if (lane == 0) {
+        if (bs) base_s = atomicAdd(&counters[0], __popcll(bs));
+        if (bw) base_w = atomicAdd(&counters[1], __popcll(bw));
+    }
+    base_s = __shfl(base_s, 0);
+    base_w = __shfl(base_w, 0);
+    if (strong) strong_list[base_s + __popcll(bs & lower)] = (int32_t)p;
+    if (weak) weak_list[base_w + __popcll(bw & lower)] = (int32_t)p;
+    // statistics: sum of |S| over processed pixels
+    int tot = n;
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+    if (lane == 0 && tot) atomicAdd(reinterpret_cast<unsigned long long *>(&counters[2]), (unsigned long long)tot);
+}
+
+} // namespace
+
+hipError_t bcd_launch_active_init(const int32_t *nsim, int W, int H, int w, int row_begin, int row_end, float skip_prob,
+                                  uint32_t seed, uint8_t *state, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_active_init, dim3((W + 255) / 256, H), dim3(256), 0, st, nsim, W, H, w, row_begin, row_end, skip_prob, seed, state);
+    return hipGetLastError();
+}
+
+hipError_t bcd_launch_active_round(const uint32_t *mask, const int32_t *nsim, uint8_t *state, int W, int H, int b,
+                                   int min_strong, int random_order, uint32_t seed, int *undecided, hipStream_t st)
+{
+    int side = 2 * b + 1, words = (side * side + 31) / 32;
+    hipLaunchKernelGGL(k_active_round, dim3((W + 255) / 256, H), dim3(256), 0, st, mask, nsim, state, W, H, b, words, min_strong,
+                       random_order, seed, undecided);
+    return hipGetLastError();
+}
+
+hipError_t bcd_launch_active_lists(const uint8_t *state, const int32_t *nsim, int64_t npix, int min_strong,
+                                   int32_t *strong_list, int32_t *weak_list, int32_t *counters, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_active_lists, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, state, nsim, npix, min_strong,
+                       strong_list, weak_list, counters);
+    return hipGetLastError();
+}

@@ -1,0 +1,345 @@
+// k_bayes.hip -- collaborative Bayesian denoising of the selected patches, one wavefront per processed pixel.
+//
+// Replaces DenoisingUnit::denoiseSelectedPatches (src/core/DenoisingUnit.cpp:388-453: computeNoiseCovPatchesMean,
+// Step1, Step2), denoiseOnlyMainPatch (:455-481) and aggregateOutputPatches (:672-693).
+// Everything lives in LDS: the n x K colour patches of the similar set (K = 3(2w+1)^2 = 27), the step-1
+// estimates, and the K x K matrices.  The three SelfAdjointEigenSolver calls (:589,617) are a parallel
+// (round-robin ordered) two-sided Jacobi iteration on the wavefront -- V f(Lambda) V^T is invariant to
+// the eigenbasis, so any accurate symmetric eigensolver reproduces the reference within fp32 round-off.
+// Sums that the reference accumulates sequentially (means, covariances, noise mean) are accumulated in
+// the same order here.  Compiled with -ffp-contract=off; fmaf() is used explicitly where contraction is wanted.
+#include "bcd_common.h"
+
+namespace {
+
+struct BayesGeom {
+    int W, H, w, b, side, words, P, K, KP, LD, maxS;
+};
+
+__device__ inline float wave_sum(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ---- parallel Jacobi on an LDS-resident symmetric matrix ------------------------------------------------
+// A (K x K, leading dimension LD) is overwritten by (nearly) diag(lambda); V receives the eigenvectors in columns.
+__device__ void jacobi_eig(float *A, float *V, float *rc, float *rs, int *rp, int *rq, int K, int KP, int LD, int lane)
+{
+    for (int e = lane; e < K * K; e += 64) {
+        int r = e / K, c = e - r * K;
+        V[r * LD + c] = (r == c) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const int N1 = KP - 1, npairs = KP / 2;
+    for (int sweep = 0; sweep < 14; ++sweep) {
+        float off = 0.f, dg = 0.f;
+        for (int e = lane; e < K * K; e += 64) {
+            int r = e / K, c = e - r * K;
+            float v = A[r * LD + c];
+            if (r == c) dg = fmaf(v, v, dg); else off = fmaf(v, v, off);
+        }
+        off = wave_sum(off);
+        dg = wave_sum(dg);
+        if (off <= 1e-13f * dg || off == 0.f) break;
+        for (int round = 0; round < N1; ++round) {
+            if (lane < npairs) {
+                int a = (lane == 0) ? N1 : (round + lane) % N1;
+                int bb = (lane == 0) ? round : (round - lane + N1) % N1;
+                int p = min(a, bb), q = max(a, bb);
+                float c = 1.f, s = 0.f;
+                if (q < K) {
+                    float apq = A[p * LD + q];
+                    if (apq != 0.f) {
+                        float app = A[p * LD + p], aqq = A[q * LD + q];
+                        float theta = (aqq - app) / (2.f * apq);
+                        float t = 1.f / (fabsf(theta) + sqrtf(fmaf(theta, theta, 1.f)));
+                        t = theta < 0.f ? -t : t;
+                        c = 1.f / sqrtf(fmaf(t, t, 1.f));
+                        s = t * c;
+                    }
+                } else { p = 0; q = 0; }
+                rc[lane] = c; rs[lane] = s; rp[lane] = p; rq[lane] = q;
+            }
+            __syncthreads();
+            // column rotations: A <- A J, V <- V J
+            for (int t = lane; t < npairs * K; t += 64) {
+                int k = t / K, row = t - k * K;
+                float c = rc[k], s = rs[k];
+                if (s != 0.f) {
+                    int p = rp[k], q = rq[k];
+                    float ap = A[row * LD + p], aq = A[row * LD + q];
+                    A[row * LD + p] = fmaf(c, ap, -s * aq);
+                    A[row * LD + q] = fmaf(s, ap, c * aq);
+                    float vp = V[row * LD + p], vq = V[row * LD + q];
+                    V[row * LD + p] = fmaf(c, vp, -s * vq);
+                    V[row * LD + q] = fmaf(s, vp, c * vq);
+                }
+            }
+            __syncthreads();
+            // row rotations: A <- J^T A
+            for (int t = lane; t < npairs * K; t += 64) {
+                int k = t / K, col = t - k * K;
+                float c = rc[k], s = rs[k];
+                if (s != 0.f) {
+                    int p = rp[k], q = rq[k];
+                    float ap = A[p * LD + col], aq = A[q * LD + col];
+                    A[p * LD + col] = fmaf(c, ap, -s * aq);
+                    A[q * LD + col] = fmaf(s, ap, c * aq);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// out = V f(lambda) V^T  (clampNegativeEigenValues :606-630 / inverseSymmetricMatrix :578-604)
+__device__ void spectral_rebuild(float *out, const float *A, const float *V, float *fl, int K, int LD, int lane,
+                                 bool inverse, float min_eig)
+{
+    for (int k = lane; k < K; k += 64) {
+        float lam = A[k * LD + k];
+        fl[k] = inverse ? 1.f / fmaxf(min_eig, lam) : fmaxf(0.f, lam);
+    }
+    __syncthreads();
+    for (int e = lane; e < K * K; e += 64) {
+        int r = e / K, c = e - r * K;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += V[r * LD + k] * (fl[k] * V[c * LD + k]);
+        out[r * LD + c] = s;
+    }
+    __syncthreads();
+}
+
+// +/- the block-diagonal noise covariance (add/substractCovMatPatch*Matrix :538-576)
+__device__ void add_noise_blocks(float *M, const float *noise, int P, int LD, int lane, float sign)
+{
+    for (int t = lane; t < P * 9; t += 64) {
+        int blk = t / 9, e = t - blk * 9, i = e / 3, j = e - i * 3;
+        // xx,yy,zz,yz,xz,xy
+        const int idx[3][3] = { { 0, 5, 4 }, { 5, 1, 3 }, { 4, 3, 2 } };
+        M[(3 * blk + i) * LD + 3 * blk + j] += sign * noise[blk * 6 + idx[i][j]];
+    }
+    __syncthreads();
+}
+
+// empiricalMean (:500-509) of an n x K cloud
+__device__ void cloud_mean(float *mean, const float *cloud, int n, int K, int lane)
+{
+    const float inv = 1.f / (float)n;
+    for (int k = lane; k < K; k += 64) {
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += cloud[i * K + k];
+        mean[k] = acc * inv;
+    }
+    __syncthreads();
+}
+
+// centerPointCloud + empiricalCovarianceMatrix (:511-536) -> full symmetric A
+__device__ void cloud_cov(float *A, const float *cloud, const float *mean, int n, int K, int LD, int lane)
+{
+    const float inv = 1.f / (float)(n - 1);
+    const int nE = K * (K + 1) / 2;
+    for (int e = lane; e < nE; e += 64) {
+        int r = 0, rem = e;
+        while (rem > r) { rem -= r + 1; ++r; }
+        int c = rem;
+        float mr = mean[r], mc = mean[c], acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += (cloud[i * K + r] - mr) * (cloud[i * K + c] - mc);
+        acc *= inv;
+        A[r * LD + c] = acc;
+        A[c * LD + r] = acc;
+    }
+    __syncthreads();
+}
+
+// finalDenoisingMatrixMultiplication (:656-670): est = x - N (Cinv (x - mean)), one (member, patch pixel) unit per lane
+template <bool SCATTER>
+__device__ void apply_estimate(const float *X, const float *Cinv, const float *mean, const float *noise, const int *mem,
+                               int n, const BayesGeom &g, int lane, float *Xd, float *sum, int32_t *cnt)
+{
+    const int K = g.K, P = g.P, LD = g.LD, pw = 2 * g.w + 1;
+    for (int u = lane; u < n * P; u += 64) {
+        int i = u / P, o = u - i * P;
+        const float *x = X + i * K;
+        float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+        const float *r0 = Cinv + (3 * o) * LD, *r1 = r0 + LD, *r2 = r1 + LD;
+        for (int c = 0; c < K; ++c) {
+            float xc = x[c] - mean[c];
+            y0 += r0[c] * xc; y1 += r1[c] * xc; y2 += r2[c] * xc;
+        }
+        y0 *= -1.f; y1 *= -1.f; y2 *= -1.f;
+        const float *n6 = noise + o * 6;
+        float e0 = n6[0] * y0 + n6[5] * y1 + n6[4] * y2;
+        float e1 = n6[5] * y0 + n6[1] * y1 + n6[3] * y2;
+        float e2 = n6[4] * y0 + n6[3] * y1 + n6[2] * y2;
+        e0 += x[3 * o]; e1 += x[3 * o + 1]; e2 += x[3 * o + 2];
+        if (SCATTER) {
+            int q = mem[i] + (o / pw - g.w) * g.W + (o % pw - g.w);
+            unsafeAtomicAdd(sum + (size_t)q * 3 + 0, e0);
+            unsafeAtomicAdd(sum + (size_t)q * 3 + 1, e1);
+            unsafeAtomicAdd(sum + (size_t)q * 3 + 2, e2);
+            atomicAdd(cnt + q, 1);
+        } else {
+            Xd[i * K + 3 * o] = e0; Xd[i * K + 3 * o + 1] = e1; Xd[i * K + 3 * o + 2] = e2;
+        }
+    }
+    __syncthreads();
+}
+
+// decode the similarity mask of pixel p into the ordered member list (window row-major order,
+// the order of m_similarPatchesCenters, DenoisingUnit.cpp:206-211); returns |S|
+__device__ int decode_members(const uint32_t *mask, int p, const BayesGeom &g, int *mem, int lane)
+{
+    int r = p / g.W, c = p - r * g.W;
+    uint32_t m = (lane < g.words) ? mask[(size_t)p * g.words + lane] : 0u;
+    int cntw = __popc(m), pre = cntw;
+    for (int off = 1; off < 32; off <<= 1) {
+        int v = __shfl_up(pre, off);
+        if ((lane & 63) >= off) pre += v;
+    }
+    int total = __shfl(pre, 31 < g.words - 1 ? 31 : g.words - 1);
+    int pos = pre - cntw;
+    while (m) {
+        int bit = __ffs(m) - 1;
+        m &= m - 1;
+        int k = lane * 32 + bit;
+        int dl = k / g.side - g.b, dc = k % g.side - g.b;
+        mem[pos++] = (r + dl) * g.W + (c + dc);
+    }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(64) void k_bayes_strong(const float *__restrict__ colors, const float *__restrict__ pixcov,
+                                                     const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
+                                                     BayesGeom g, float min_eig, float *sum, int32_t *cnt)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x;
+    const int K = g.K, P = g.P, KP = g.KP, LD = g.LD, pw = 2 * g.w + 1;
+    int *mem = reinterpret_cast<int *>(lds);
+    float *X = lds + g.maxS;
+    float *Xd = X + g.maxS * K;
+    float *A = Xd + g.maxS * K;
+    float *V = A + KP * LD;
+    float *Bm = V + KP * LD;
+    float *noise = Bm + KP * LD;
+    float *mean = noise + P * 6;
+    float *fl = mean + K;
+    float *rc = fl + K;
+    float *rs = rc + KP / 2;
+    int *rp = reinterpret_cast<int *>(rs + KP / 2);
+    int *rq = rp + KP / 2;
+
+    const int p = list[blockIdx.x];
+    const int n = decode_members(mask, p, g, mem, lane);
+    const float n_inv = 1.f / (float)n;
+
+    // computeNoiseCovPatchesMean (:400-419)
+    for (int v = lane; v < P * 6; v += 64) {
+        int o = v / 6, j = v - o * 6;
+        int offp = (o / pw - g.w) * g.W + (o % pw - g.w);
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += pixcov[(size_t)(mem[i] + offp) * 6 + j];
+        noise[v] = acc * n_inv;
+    }
+    // pickColorPatchesFromColorImage (:483-498)
+    for (int t = lane; t < n * K; t += 64) {
+        int i = t / K, k = t - i * K, o = k / 3, ch = k - o * 3;
+        int offp = (o / pw - g.w) * g.W + (o % pw - g.w);
+        X[t] = colors[(size_t)(mem[i] + offp) * 3 + ch];
+    }
+    __syncthreads();
+
+    // ---- Step 1 (:421-436)
+    cloud_mean(mean, X, n, K, lane);
+    cloud_cov(A, X, mean, n, K, LD, lane);
+    add_noise_blocks(A, noise, P, LD, lane, -1.f);
+    jacobi_eig(A, V, rc, rs, rp, rq, K, KP, LD, lane);
+    spectral_rebuild(Bm, A, V, fl, K, LD, lane, false, 0.f);      // clamp negative eigenvalues
+    add_noise_blocks(Bm, noise, P, LD, lane, +1.f);
+    for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; A[r * LD + c] = Bm[(r >= c ? r : c) * LD + (r >= c ? c : r)]; }
+    __syncthreads();
+    jacobi_eig(A, V, rc, rs, rp, rq, K, KP, LD, lane);
+    spectral_rebuild(Bm, A, V, fl, K, LD, lane, true, min_eig);   // inverse
+    apply_estimate<false>(X, Bm, mean, noise, mem, n, g, lane, Xd, nullptr, nullptr);
+
+    // ---- Step 2 (:438-453)
+    cloud_mean(mean, Xd, n, K, lane);
+    cloud_cov(A, Xd, mean, n, K, LD, lane);
+    add_noise_blocks(A, noise, P, LD, lane, +1.f);
+    jacobi_eig(A, V, rc, rs, rp, rq, K, KP, LD, lane);
+    spectral_rebuild(Bm, A, V, fl, K, LD, lane, true, min_eig);
+    // aggregateOutputPatches (:672-693)
+    apply_estimate<true>(X, Bm, mean, noise, mem, n, g, lane, nullptr, sum, cnt);
+}
+
+// denoiseOnlyMainPatch (:455-481): average of the similar colour patches added to the main patch only
+__global__ __launch_bounds__(64) void k_bayes_weak(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
+                                                   const int32_t *__restrict__ list, BayesGeom g, float *sum, int32_t *cnt)
+{
+    extern __shared__ float lds[];
+    int *mem = reinterpret_cast<int *>(lds);
+    const int lane = threadIdx.x, pw = 2 * g.w + 1;
+    const int p = list[blockIdx.x];
+    const int n = decode_members(mask, p, g, mem, lane);
+    const float n_inv = 1.f / (float)n; // inf when n == 0, like the reference (assert compiled out, :212-213)
+    for (int k = lane; k < g.K; k += 64) {
+        int o = k / 3, ch = k - o * 3;
+        int offp = (o / pw - g.w) * g.W + (o % pw - g.w);
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += colors[(size_t)(mem[i] + offp) * 3 + ch];
+        unsafeAtomicAdd(sum + (size_t)(p + offp) * 3 + ch, n_inv * acc);
+        if (ch == 0) atomicAdd(cnt + p + offp, 1);
+    }
+}
+
+BayesGeom make_geom(int W, int H, int w, int b)
+{
+    BayesGeom g;
+    g.W = W; g.H = H; g.w = w; g.b = b;
+    g.side = 2 * b + 1;
+    g.words = (g.side * g.side + 31) / 32;
+    g.P = (2 * w + 1) * (2 * w + 1);
+    g.K = 3 * g.P;
+    g.KP = g.K + (g.K & 1);
+    g.LD = g.KP + 1;
+    g.maxS = g.side * g.side;
+    return g;
+}
+
+} // namespace
+
+size_t bcd_bayes_lds_bytes(int w, int b)
+{
+    BayesGeom g = make_geom(0, 0, w, b);
+    size_t f = (size_t)g.maxS + 2 * (size_t)g.maxS * g.K + 3 * (size_t)g.KP * g.LD + g.P * 6 + 2 * g.K + 4 * (g.KP / 2);
+    return f * sizeof(float);
+}
+
+hipError_t bcd_launch_bayes_strong(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int nlist,
+                                   int W, int H, int w, int b, float min_eig, float *sum, int32_t *cnt, hipStream_t st)
+{
+    if (nlist <= 0) return hipSuccess;
+    BayesGeom g = make_geom(W, H, w, b);
+    if (g.words > 32) return hipErrorInvalidValue;
+    size_t lds = bcd_bayes_lds_bytes(w, b);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bayes_strong), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_bayes_strong, dim3(nlist), dim3(64), lds, st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
+    return hipGetLastError();
+}
+
+hipError_t bcd_launch_bayes_weak(const float *colors, const uint32_t *mask, const int32_t *list, int nlist,
+                                 int W, int H, int w, int b, float *sum, int32_t *cnt, hipStream_t st)
+{
+    if (nlist <= 0) return hipSuccess;
+    BayesGeom g = make_geom(W, H, w, b);
+    if (g.words > 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bayes_weak, dim3(nlist), dim3(64), (size_t)g.maxS * sizeof(int), st, colors, mask, list, g, sum, cnt);
+    return hipGetLastError();
+}

@@ -1,0 +1,197 @@
+// k_pointwise.hip -- per-pixel pre/post passes, multiscale pyramid + merge, spike prefilter.
+// All arithmetic is written in the reference's evaluation order and compiled with -ffp-contract=off,
+// so these kernels are bit-exact against the CPU path.
+#include "bcd_common.h"
+
+namespace {
+
+// Denoiser::computePixelCovFromSampleCov (src/core/Denoiser.cpp:357-373): cov * (1.f / n)
+__global__ void k_pixel_cov(const float *__restrict__ cov, const float *__restrict__ ns, int64_t npix, float *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 6) return;
+    float inv = 1.f / ns[i / 6];
+    out[i] = cov[i] * inv;
+}
+
+// Denoiser::finalAggregation tail (src/core/Denoiser.cpp:458-469): (1.f / count) * sum
+__global__ void k_finalize(const float *__restrict__ sum, const int32_t *__restrict__ cnt, int64_t npix, float *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 3) return;
+    float inv = 1.f / (float)cnt[i / 3];
+    out[i] = inv * sum[i];
+}
+
+// checkAndPutToZeroNegativeInfNaNValues (src/cli/main.cpp:389-420)
+__global__ void k_zero_bad(float *__restrict__ img, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = img[i];
+    if (v < 0.f || isnan(v) || isinf(v)) img[i] = 0.f;
+}
+
+// 2x2 block positions of MultiscaleDenoiser::downscale* (src/core/MultiscaleDenoiser.cpp:256-266):
+// p1=(2l,2c), p2 = next line, p3 = next column, p4 = both; clamped to the image.
+__device__ inline void block_pos(int W, int H, int l, int c, size_t p[4])
+{
+    int l1 = min(2 * l + 1, H - 1), c1 = min(2 * c + 1, W - 1);
+    p[0] = (size_t)(2 * l) * W + 2 * c;
+    p[1] = (size_t)l1 * W + 2 * c;
+    p[2] = (size_t)(2 * l) * W + c1;
+    p[3] = (size_t)l1 * W + c1;
+}
+
+// mode 0: downscaleSum (:243-268)   mode 1: downscaleAverage / downscale (:270-295,514-539)
+template <int MODE>
+__global__ void k_downscale(const float *__restrict__ in, int W, int H, int D, float *__restrict__ out)
+{
+    const int w2 = W / 2, h2 = H / 2;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)w2 * h2 * D) return;
+    int z = (int)(i % D);
+    int64_t pq = i / D;
+    int c = (int)(pq % w2), l = (int)(pq / w2);
+    size_t p[4];
+    block_pos(W, H, l, c, p);
+    float v = in[p[0] * D + z] + in[p[1] * D + z] + in[p[2] * D + z] + in[p[3] * D + z];
+    out[i] = MODE == 0 ? v : 0.25f * v;
+}
+
+// downscaleSampleCovarianceSum (:297-334): w_i = (1/16) * nSum / n_i
+__global__ void k_downscale_cov(const float *__restrict__ cov, const float *__restrict__ ns, int W, int H, float *__restrict__ out)
+{
+    const int w2 = W / 2, h2 = H / 2;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)w2 * h2 * 6) return;
+    int z = (int)(i % 6);
+    int64_t pq = i / 6;
+    int c = (int)(pq % w2), l = (int)(pq / w2);
+    size_t p[4];
+    block_pos(W, H, l, c, p);
+    const float sq = (1.f / 4.f) * (1.f / 4.f);
+    float n1 = ns[p[0]], n2 = ns[p[1]], n3 = ns[p[2]], n4 = ns[p[3]];
+    float nsum = n1 + n2 + n3 + n4;
+    float w1 = sq * nsum / n1, w2_ = sq * nsum / n2, w3 = sq * nsum / n3, w4 = sq * nsum / n4;
+    out[i] = w1 * cov[p[0] * 6 + z] + w2_ * cov[p[1] * 6 + z] + w3 * cov[p[2] * 6 + z] + w4 * cov[p[3] * 6 + z];
+}
+
+__device__ inline int clamp_pos(int v, int maxp1) { return v <= 0 ? 0 : (v >= maxp1 ? maxp1 - 1 : v); }
+
+// interpolate (:473-512): 9/16 main, 3/16 x (two adjacent, summed first), 1/16 diagonal.
+// MODE 0: hi = up(lo)     MODE 1: hi -= up(lo)     MODE 2: hi += up(lo)
+template <int MODE>
+__global__ void k_interpolate(const float *__restrict__ lo, int w, int h, int D, float *__restrict__ hi, int W, int H)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)W * H * D) return;
+    int z = (int)(i % D);
+    int64_t pq = i / D;
+    int uc = (int)(pq % W), ul = (int)(pq / W);
+    int l = ul / 2, c = uc / 2;
+    int al = clamp_pos(l + ((ul % 2) * 2 - 1), h);
+    int ac = clamp_pos(c + ((uc % 2) * 2 - 1), w);
+    int lc = max(0, min(l, h - 1)), cc = max(0, min(c, w - 1));
+    const float wm = 9.f / 16.f, wa = 3.f / 16.f, wd = 1.f / 16.f;
+    float v = wm * lo[((size_t)lc * w + cc) * D + z] +
+              wa * (lo[((size_t)lc * w + ac) * D + z] + lo[((size_t)al * w + cc) * D + z]) +
+              wd * lo[((size_t)al * w + ac) * D + z];
+    if (MODE == 0) hi[i] = v;
+    else if (MODE == 1) hi[i] -= v;
+    else hi[i] += v;
+}
+
+// SpikeRemovalFilter::filter (src/core/SpikeRemovalFilter.cpp:18-116), float-abs semantics; out of place.
+__global__ void k_spike(const float *__restrict__ col, const float *__restrict__ ns, const float *__restrict__ hist,
+                        const float *__restrict__ cov, int W, int H, int D, float factor,
+                        float *__restrict__ ocol, float *__restrict__ ons, float *__restrict__ ohist, float *__restrict__ ocov)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (c >= W) return;
+    int cl = l < 1 ? 1 : (l > H - 2 ? H - 2 : l);
+    int cc = c < 1 ? 1 : (c > W - 2 ? W - 2 : c);
+    float v[3][9];
+    int k = 0;
+    for (int nl = cl - 1; nl <= cl + 1; ++nl)
+        for (int nc = cc - 1; nc <= cc + 1; ++nc, ++k) {
+            const float *px = col + ((size_t)nl * W + nc) * 3;
+            v[0][k] = px[0]; v[1][k] = px[1]; v[2][k] = px[2];
+        }
+    const float *me = col + ((size_t)l * W + c) * 3;
+    bool spike = false;
+    for (int ch = 0; ch < 3; ++ch) {
+        float total = 0.f;
+        for (int i = 0; i < 9; ++i) total += v[ch][i];
+        float avg = total / 9;
+        total = 0;
+        for (int i = 0; i < 9; ++i) total += (v[ch][i] - avg) * (v[ch][i] - avg);
+        float sd = sqrtf(total / 8);
+        spike = spike || (fabsf(me[ch] - avg) > factor * sd);
+    }
+    size_t dst = (size_t)l * W + c, src = dst;
+    if (spike) {
+        int best = 0;
+        float bestd = -1.f;
+        for (int m = 0; m < 9; ++m) {
+            float tot = 0.f;
+            for (int i = 0; i < 9; ++i)
+                tot += fabsf(v[0][i] - v[0][m]) + fabsf(v[1][i] - v[1][m]) + fabsf(v[2][i] - v[2][m]);
+            if (bestd < 0 || tot < bestd) { bestd = tot; best = m; }
+        }
+        src = (size_t)(cl - 1 + best / 3) * W + (cc - 1 + best % 3);
+    }
+    for (int j = 0; j < 3; ++j) ocol[dst * 3 + j] = col[src * 3 + j];
+    ons[dst] = ns[src];
+    for (int j = 0; j < D; ++j) ohist[dst * D + j] = hist[src * D + j];
+    for (int j = 0; j < 6; ++j) ocov[dst * 6 + j] = cov[src * 6 + j];
+}
+
+inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+} // namespace
+
+hipError_t bcd_launch_pixel_cov(const float *cov, const float *ns, int64_t npix, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pixel_cov, dim3(nblk(npix * 6, 256)), dim3(256), 0, st, cov, ns, npix, out);
+    return hipGetLastError();
+}
+hipError_t bcd_launch_finalize(const float *sum, const int32_t *cnt, int64_t npix, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(nblk(npix * 3, 256)), dim3(256), 0, st, sum, cnt, npix, out);
+    return hipGetLastError();
+}
+hipError_t bcd_launch_zero_bad(float *img, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_zero_bad, dim3(nblk(n, 256)), dim3(256), 0, st, img, n);
+    return hipGetLastError();
+}
+hipError_t bcd_launch_downscale(int mode, const float *in, int W, int H, int D, float *out, hipStream_t st)
+{
+    int64_t n = (int64_t)(W / 2) * (H / 2) * D;
+    if (n <= 0) return hipSuccess;
+    if (mode == 0) hipLaunchKernelGGL(k_downscale<0>, dim3(nblk(n, 256)), dim3(256), 0, st, in, W, H, D, out);
+    else hipLaunchKernelGGL(k_downscale<1>, dim3(nblk(n, 256)), dim3(256), 0, st, in, W, H, D, out);
+    return hipGetLastError();
+}
+hipError_t bcd_launch_downscale_cov(const float *cov, const float *ns, int W, int H, float *out, hipStream_t st)
+{
+    int64_t n = (int64_t)(W / 2) * (H / 2) * 6;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_downscale_cov, dim3(nblk(n, 256)), dim3(256), 0, st, cov, ns, W, H, out);
+    return hipGetLastError();
+}
+hipError_t bcd_launch_interpolate(int mode, const float *lo, int w, int h, int D, float *hi, int W, int H, hipStream_t st)
+{
+    int64_t n = (int64_t)W * H * D;
+    if (mode == 0) hipLaunchKernelGGL(k_interpolate<0>, dim3(nblk(n, 256)), dim3(256), 0, st, lo, w, h, D, hi, W, H);
+    else if (mode == 1) hipLaunchKernelGGL(k_interpolate<1>, dim3(nblk(n, 256)), dim3(256), 0, st, lo, w, h, D, hi, W, H);
+    else hipLaunchKernelGGL(k_interpolate<2>, dim3(nblk(n, 256)), dim3(256), 0, st, lo, w, h, D, hi, W, H);
+    return hipGetLastError();
+}
+hipError_t bcd_launch_spike(const float *col, const float *ns, const float *hist, const float *cov, int W, int H, int D,
+                            float factor, float *ocol, float *ons, float *ohist, float *ocov, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_spike, dim3((W + 63) / 64, H), dim3(64), 0, st, col, ns, hist, cov, W, H, D, factor, ocol, ons, ohist, ocov);
+    return hipGetLastError();
+}

@@ -1,0 +1,278 @@
+// k_similarity.hip -- chi-square histogram patch distances and similar-patch bitmasks for a whole scale.
+//
+// Replaces, for every main pixel at once, DenoisingUnit::selectSimilarPatches ->
+// histogramPatchDistance -> pixelSummedHistogramDistance (src/core/DenoisingUnit.cpp:196-219,336-386),
+// and the per-main-pixel CUDA offload (src/core/CudaHistogramDistance.cu:72-239).
+//
+// Decomposition (exact, no reassociation of the reference's sums):
+//   d(p, p+delta) = ( ((T(p+o0) + T(p+o1)) + ...) ) / (float)(sum_o C(p+o)),   o over the patch, row-major
+//   T_delta(x) = sequential-in-bin chi-square sum between pixels x and x+delta, C_delta(x) its bin count.
+// T/C are bitwise symmetric (T_delta(x) == T_-delta(x+delta)), so only the half plane of displacements
+// is evaluated: kernel 1 writes the T/C planes, kernel 2 box-sums them into the 169-bit masks.
+// This file is compiled with -ffp-contract=off: the reference is built without FMA contraction and the
+// membership test d <= tau is discrete.
+#include "bcd_common.h"
+
+namespace {
+
+constexpr int PD_TW = 64; // tile width  (one wavefront per tile row)
+constexpr int PD_TH = 4;  // tile height (4 wavefronts per workgroup)
+
+// LDS pixel stride (floats): D/4 odd keeps ds_read_b128 at a per-lane stride of D*4 bytes conflict-free
+template <int D> struct PdStride { static constexpr int value = ((D / 4) % 2 == 1) ? D : D + 4; };
+
+// ---------------------------------------------------------------------------------------------------
+// kernel 1: pair-distance planes.  One thread per pixel x of a 4x64 tile; own histogram in VGPRs,
+// neighbour rows staged through LDS once per displacement row dl and re-used for the 2b+1 (or b+1)
+// displacements of that row.
+// ---------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist, const float *__restrict__ ns,
+                                                   int W, int H, int b,
+                                                   float *__restrict__ T, uint8_t *__restrict__ Cn)
+{
+    constexpr int DS = PdStride<D>::value;
+    constexpr int Q = D / 4;
+    extern __shared__ float4 lds4[];
+    const int ncols = PD_TW + 2 * b;
+    float *lds_n = reinterpret_cast<float *>(lds4 + PD_TH * ncols * (DS / 4));
+
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col0 = blockIdx.x * PD_TW, row0 = blockIdx.y * PD_TH;
+    const int c = col0 + tx, r = row0 + ty;
+    const bool inside = (c < W) && (r < H);
+    const size_t plane = (size_t)W * H;
+    const size_t pix = (size_t)r * W + c;
+
+    float h1[D];
+    float n1 = 1.f;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(hist) + (inside ? pix * Q : 0);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float4 v = inside ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            h1[4 * q] = v.x; h1[4 * q + 1] = v.y; h1[4 * q + 2] = v.z; h1[4 * q + 3] = v.w;
+        }
+        if (inside) n1 = ns[pix];
+    }
+
+    int didx = 0;
+    for (int dl = 0; dl <= b; ++dl) {
+        __syncthreads();
+        // stage rows row0+dl .. row0+dl+3, columns col0-b .. col0+63+b
+        const int npix = PD_TH * ncols;
+        for (int i = threadIdx.x; i < npix * Q; i += 256) {
+            int p = i / Q, q = i - p * Q;
+            int lr = p / ncols, lc = p - lr * ncols;
+            int gr = row0 + dl + lr, gc = col0 - b + lc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < H && gc >= 0 && gc < W) v = reinterpret_cast<const float4 *>(hist)[((size_t)gr * W + gc) * Q + q];
+            lds4[p * (DS / 4) + q] = v;
+        }
+        for (int i = threadIdx.x; i < npix; i += 256) {
+            int lr = i / ncols, lc = i - lr * ncols;
+            int gr = row0 + dl + lr, gc = col0 - b + lc;
+            lds_n[i] = (gr < H && gc >= 0 && gc < W) ? ns[(size_t)gr * W + gc] : 1.f;
+        }
+        __syncthreads();
+
+        const int dc0 = (dl == 0) ? 0 : -b;
+        for (int dc = dc0; dc <= b; ++dc, ++didx) {
+            const int lp = ty * ncols + tx + dc + b;
+            const float4 *nb = lds4 + lp * (DS / 4);
+            const float n2 = lds_n[lp];
+            const float n12 = n1 * n2;
+            float sum = 0.f;
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                float4 v = nb[q];
+                float b2[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float b1 = h1[4 * q + j];
+                    float s = b1 + b2[j];
+                    float diff = n2 * b1 - n1 * b2[j];
+                    float t = diff * diff / (n12 * s);
+                    bool use = s > 1.f; // reference skips bins with b1 + b2 <= 1 (DenoisingUnit.cpp:379)
+                    sum = use ? sum + t : sum;
+                    cnt += use ? 1 : 0;
+                }
+            }
+            const int nc = c + dc, nr = r + dl;
+            if (inside && nc >= 0 && nc < W && nr < H) {
+                T[(size_t)didx * plane + pix] = sum;
+                Cn[(size_t)didx * plane + pix] = (uint8_t)cnt;
+            }
+        }
+    }
+}
+
+// generic-depth variant (any D <= 255): both histograms read from global memory, no staging.
+__global__ __launch_bounds__(256) void k_pairdist_generic(const float *__restrict__ hist, const float *__restrict__ ns,
+                                                           int W, int H, int D, int b,
+                                                           float *__restrict__ T, uint8_t *__restrict__ Cn)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= W || r >= H) return;
+    const size_t plane = (size_t)W * H, pix = (size_t)r * W + c;
+    const float *h1 = hist + pix * D;
+    const float n1 = ns[pix];
+    int didx = 0;
+    for (int dl = 0; dl <= b; ++dl)
+        for (int dc = (dl == 0 ? 0 : -b); dc <= b; ++dc, ++didx) {
+            int nc = c + dc, nr = r + dl;
+            if (nc < 0 || nc >= W || nr >= H) continue;
+            size_t q = (size_t)nr * W + nc;
+            const float *h2 = hist + q * D;
+            float n2 = ns[q], n12 = n1 * n2, sum = 0.f;
+            int cnt = 0;
+            for (int k = 0; k < D; ++k) {
+                float b1 = h1[k], b2 = h2[k], s = b1 + b2;
+                if (s <= 1.f) continue;
+                ++cnt;
+                float diff = n2 * b1 - n1 * b2;
+                sum += diff * diff / (n12 * s);
+            }
+            T[(size_t)didx * plane + pix] = sum;
+            Cn[(size_t)didx * plane + pix] = (uint8_t)cnt;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernel 2: similarity masks.  Thread = (pixel, mask word).  For each window offset the 9 (or (2w+1)^2)
+// T values of the canonical (half-plane) displacement are added in the reference's patch order, the
+// integer counts likewise, then one IEEE division and the <= tau test.
+// The window is PixelWindow(center, radius b, border w) (DenoisingUnit.cpp:200-203): clipped.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_masks(const float *__restrict__ T, const uint8_t *__restrict__ Cn,
+                                               int W, int H, int w, int b, float tau, int words,
+                                               uint32_t *__restrict__ mask)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int r = blockIdx.y;
+    const int word = blockIdx.z * blockDim.y + threadIdx.y;
+    if (c >= W || word >= words) return;
+    const size_t plane = (size_t)W * H, pix = (size_t)r * W + c;
+    const int side = 2 * b + 1, nbits = side * side;
+    uint32_t m = 0;
+    const bool is_main = (r >= w && r <= H - 1 - w && c >= w && c <= W - 1 - w);
+    if (is_main) {
+        for (int bit = 0; bit < 32; ++bit) {
+            int k = word * 32 + bit;
+            if (k >= nbits) break;
+            int dl = k / side - b, dc = k % side - b;
+            int qr = r + dl, qc = c + dc;
+            if (qr < w || qr > H - 1 - w || qc < w || qc > W - 1 - w) continue;
+            // canonical displacement and base pixel
+            int br = r, bc = c, cl = dl, cc = dc;
+            if (dl < 0 || (dl == 0 && dc < 0)) { br = qr; bc = qc; cl = -dl; cc = -dc; }
+            const size_t base = (size_t)bcd_delta_index(cl, cc, b) * plane;
+            float s = 0.f;
+            int n = 0;
+            for (int ol = -w; ol <= w; ++ol)
+                for (int oc = -w; oc <= w; ++oc) {
+                    size_t idx = base + (size_t)(br + ol) * W + (bc + oc);
+                    s += T[idx];
+                    n += Cn[idx];
+                }
+            float d = s / (float)n; // 0/0 = NaN -> not similar
+            if (d <= tau) m |= 1u << bit;
+        }
+    }
+    mask[pix * words + word] = m;
+}
+
+__global__ void k_mask_count(const uint32_t *__restrict__ mask, int64_t npix, int words, int32_t *__restrict__ count)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    int n = 0;
+    for (int j = 0; j < words; ++j) n += __popc(mask[p * words + j]);
+    count[p] = n;
+}
+
+// debug / parity: raw distances of one main pixel to its window
+__global__ void k_window_distances(const float *__restrict__ T, const uint8_t *__restrict__ Cn,
+                                   int W, int H, int w, int b, int r, int c, float *__restrict__ out)
+{
+    const int side = 2 * b + 1;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= side * side) return;
+    const size_t plane = (size_t)W * H;
+    int dl = k / side - b, dc = k % side - b;
+    int qr = r + dl, qc = c + dc;
+    float d = INFINITY;
+    if (!(qr < w || qr > H - 1 - w || qc < w || qc > W - 1 - w)) {
+        int br = r, bc = c, cl = dl, cc = dc;
+        if (dl < 0 || (dl == 0 && dc < 0)) { br = qr; bc = qc; cl = -dl; cc = -dc; }
+        const size_t base = (size_t)bcd_delta_index(cl, cc, b) * plane;
+        float s = 0.f;
+        int n = 0;
+        for (int ol = -w; ol <= w; ++ol)
+            for (int oc = -w; oc <= w; ++oc) {
+                size_t idx = base + (size_t)(br + ol) * W + (bc + oc);
+                s += T[idx];
+                n += Cn[idx];
+            }
+        d = s / (float)n;
+    }
+    out[k] = d;
+}
+
+} // namespace
+
+// ---- launchers (called from bcd_api.hip) --------------------------------------------------------------
+size_t bcd_pairdist_lds_bytes(int D, int b)
+{
+    int DS = ((D / 4) % 2 == 1) ? D : D + 4;
+    return (size_t)PD_TH * (PD_TW + 2 * b) * (DS + 1) * sizeof(float);
+}
+
+hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H, int D, int b,
+                               float *T, uint8_t *Cn, hipStream_t st)
+{
+    dim3 grid((W + PD_TW - 1) / PD_TW, (H + PD_TH - 1) / PD_TH), block(256);
+    size_t lds = bcd_pairdist_lds_bytes(D, b);
+    bool fast = (D % 4 == 0) && lds <= 160 * 1024;
+#define BCD_PD_CASE(DD)                                                                                              \
+    case DD:                                                                                                         \
+        if (lds > 64 * 1024) {                                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist<DD>),                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+            if (e != hipSuccess) return e;                                                                           \
+        }                                                                                                            \
+        hipLaunchKernelGGL(k_pairdist<DD>, grid, block, lds, st, hist, ns, W, H, b, T, Cn);                          \
+        return hipGetLastError();
+    if (fast) switch (D) {
+        BCD_PD_CASE(60)
+        BCD_PD_CASE(120)
+        BCD_PD_CASE(36)
+        BCD_PD_CASE(24)
+        BCD_PD_CASE(12)
+        default: break;
+    }
+#undef BCD_PD_CASE
+    hipLaunchKernelGGL(k_pairdist_generic, grid, block, 0, st, hist, ns, W, H, D, b, T, Cn);
+    return hipGetLastError();
+}
+
+hipError_t bcd_launch_masks(const float *T, const uint8_t *Cn, int W, int H, int w, int b, float tau,
+                            uint32_t *mask, int32_t *count, hipStream_t st)
+{
+    const int side = 2 * b + 1, words = (side * side + 31) / 32;
+    dim3 block(64, 4);
+    dim3 grid((W + 63) / 64, H, (words + 3) / 4);
+    hipLaunchKernelGGL(k_masks, grid, block, 0, st, T, Cn, W, H, w, b, tau, words, mask);
+    int64_t npix = (int64_t)W * H;
+    hipLaunchKernelGGL(k_mask_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, mask, npix, words, count);
+    return hipGetLastError();
+}
+
+hipError_t bcd_launch_window_distances(const float *T, const uint8_t *Cn, int W, int H, int w, int b, int r, int c,
+                                       float *out, hipStream_t st)
+{
+    int n = (2 * b + 1) * (2 * b + 1);
+    hipLaunchKernelGGL(k_window_distances, dim3((n + 63) / 64), dim3(64), 0, st, T, Cn, W, H, w, b, r, c, out);
+    return hipGetLastError();
+}

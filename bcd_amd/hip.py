@@ -1,0 +1,246 @@
+"""ctypes binding of include/bcd_hip.h.  Fails loudly when libbcd_hip.so is missing: there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbcd_hip.so")
+
+_F = C.POINTER(C.c_float)
+_VP = C.c_void_p
+
+
+class Params(C.Structure):
+    """bcd_hip_params (mirrors bcd::DenoiserParameters, include/bcd/core/IDenoiser.h:20-44 of the reference)"""
+    _fields_ = [("hist_dist_threshold", C.c_float), ("patch_radius", C.c_int32), ("search_radius", C.c_int32),
+                ("min_eigen_value", C.c_float), ("use_random_pixel_order", C.c_int32),
+                ("marked_skip_probability", C.c_float), ("order_seed", C.c_uint32)]
+
+
+class ScaleStats(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("main_pixels", C.c_int64), ("processed", C.c_int64),
+                ("fallback", C.c_int64), ("similar_total", C.c_int64), ("active_rounds", C.c_int32),
+                ("ms_similarity", C.c_float), ("ms_active", C.c_float), ("ms_bayes", C.c_float), ("ms_total", C.c_float)]
+
+
+# every symbol include/bcd_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
+    "bcd_hip_set_profiling", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
+    "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_host",
+    "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set",
+    "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
+    "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_zero_bad_values",
+    "bcd_hip_visit_order", "bcd_hip_scale_seed",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libbcd_hip.so is not built (%s): run `python -m bcd_amd.build`; "
+                               "there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.bcd_hip_last_error.restype = C.c_char_p
+        _lib.bcd_hip_last_error.argtypes = [_VP]
+        _lib.bcd_hip_scale_seed.restype = C.c_uint32
+        _lib.bcd_hip_ctx_create.argtypes = [C.POINTER(_VP), C.c_int, _VP]
+        _lib.bcd_hip_ctx_destroy.argtypes = [_VP]
+        _lib.bcd_hip_ctx_destroy.restype = None
+    return _lib
+
+
+def default_params(**kw):
+    p = Params()
+    lib().bcd_hip_default_params(C.byref(p))
+    names = {"tau": "hist_dist_threshold", "w": "patch_radius", "b": "search_radius", "min_eig": "min_eigen_value",
+             "random_order": "use_random_pixel_order", "m": "marked_skip_probability", "seed": "order_seed"}
+    for k, v in kw.items():
+        setattr(p, names.get(k, k), v)
+    return p
+
+
+class BcdHipError(RuntimeError):
+    pass
+
+
+def _dp(t):
+    """device pointer of a contiguous torch tensor"""
+    assert t.is_cuda and t.is_contiguous(), "expected a contiguous device tensor"
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """bcd_hip_ctx bound to a torch device/stream."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+        self.torch = torch
+        self.device = device
+        h = _VP()
+        st = None
+        if stream is not None:
+            st = C.c_void_p(stream.cuda_stream)
+        rc = lib().bcd_hip_ctx_create(C.byref(h), int(device), st)
+        if rc != 0:
+            raise BcdHipError("bcd_hip_ctx_create failed: rc=%d" % rc)
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().bcd_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise BcdHipError("rc=%d: %s" % (rc, lib().bcd_hip_last_error(self.h).decode()))
+
+    # ---- whole path
+    def denoise(self, col, ns, hist, cov, nscales, prm, out=None):
+        torch = self.torch
+        H, W, D = hist.shape
+        if out is None:
+            out = torch.empty((H, W, 3), dtype=torch.float32, device=hist.device)
+        self._chk(lib().bcd_hip_denoise(self.h, _dp(col), _dp(ns), _dp(hist), _dp(cov), W, H, D, nscales, C.byref(prm), _dp(out)))
+        return out
+
+    def denoise_band(self, col, ns, hist, cov, row_begin, row_end, prm, seed, sum_, cnt):
+        H, W, D = hist.shape
+        self._chk(lib().bcd_hip_denoise_band(self.h, _dp(col), _dp(ns), _dp(hist), _dp(cov), W, H, D, row_begin, row_end,
+                                             C.byref(prm), C.c_uint32(seed), _dp(sum_), _dp(cnt)))
+
+    def denoise_host(self, col, ns, hist, cov, nscales, prm):
+        import numpy as np
+        H, W, D = hist.shape
+        out = np.empty((H, W, 3), np.float32)
+        f = lambda a: a.ctypes.data_as(_F)
+        self._chk(lib().bcd_hip_denoise_host(self.h, f(col), f(ns), f(hist), f(cov), W, H, D, nscales, C.byref(prm), f(out)))
+        return out
+
+    # ---- stages
+    def pixel_cov(self, cov, ns):
+        H, W, _ = cov.shape
+        out = self.torch.empty_like(cov)
+        self._chk(lib().bcd_hip_pixel_cov(self.h, _dp(cov), _dp(ns), W, H, _dp(out)))
+        return out
+
+    def similarity_masks(self, hist, ns, w, b, tau):
+        torch = self.torch
+        H, W, D = hist.shape
+        words = ((2 * b + 1) ** 2 + 31) // 32
+        mask = torch.zeros((H, W, words), dtype=torch.int32, device=hist.device)
+        cnt = torch.zeros((H, W), dtype=torch.int32, device=hist.device)
+        self._chk(lib().bcd_hip_similarity_masks(self.h, _dp(hist), _dp(ns), W, H, D, w, b, C.c_float(tau), _dp(mask), _dp(cnt)))
+        return mask, cnt
+
+    def window_distances(self, hist, ns, w, b, line, col):
+        import numpy as np
+        H, W, D = hist.shape
+        out = np.empty(((2 * b + 1) ** 2,), np.float32)
+        self._chk(lib().bcd_hip_window_distances(self.h, _dp(hist), _dp(ns), W, H, D, w, b, line, col, out.ctypes.data_as(_F)))
+        return out
+
+    def active_set(self, mask, cnt, w, b, m, random_order, seed, row_begin=0, row_end=None):
+        torch = self.torch
+        H, W, _ = mask.shape
+        state = torch.zeros((H, W), dtype=torch.uint8, device=mask.device)
+        rounds = C.c_int32(0)
+        self._chk(lib().bcd_hip_active_set(self.h, _dp(mask), _dp(cnt), W, H, w, b, row_begin, H if row_end is None else row_end,
+                                           C.c_float(m), int(random_order), C.c_uint32(seed), _dp(state), C.byref(rounds)))
+        return state, rounds.value
+
+    def bayes_accumulate(self, col, pixcov, mask, nsim, state, w, b, min_eig):
+        torch = self.torch
+        H, W, _ = col.shape
+        s = torch.zeros((H, W, 3), dtype=torch.float32, device=col.device)
+        c = torch.zeros((H, W), dtype=torch.int32, device=col.device)
+        self._chk(lib().bcd_hip_bayes_accumulate(self.h, _dp(col), _dp(pixcov), _dp(mask), _dp(nsim), _dp(state), W, H, w, b,
+                                                 C.c_float(min_eig), _dp(s), _dp(c)))
+        return s, c
+
+    def finalize(self, s, c):
+        out = self.torch.empty_like(s)
+        self._chk(lib().bcd_hip_finalize(self.h, _dp(s), _dp(c), C.c_int64(c.numel()), _dp(out)))
+        return out
+
+    def downscale_sum(self, a):
+        H, W, D = a.shape
+        o = self.torch.empty((H // 2, W // 2, D), dtype=a.dtype, device=a.device)
+        self._chk(lib().bcd_hip_downscale_sum(self.h, _dp(a), W, H, D, _dp(o)))
+        return o
+
+    def downscale_avg(self, a):
+        H, W, D = a.shape
+        o = self.torch.empty((H // 2, W // 2, D), dtype=a.dtype, device=a.device)
+        self._chk(lib().bcd_hip_downscale_avg(self.h, _dp(a), W, H, D, _dp(o)))
+        return o
+
+    def downscale_cov(self, cov, ns):
+        H, W, D = cov.shape
+        o = self.torch.empty((H // 2, W // 2, D), dtype=cov.dtype, device=cov.device)
+        self._chk(lib().bcd_hip_downscale_cov(self.h, _dp(cov), _dp(ns), W, H, _dp(o)))
+        return o
+
+    def interpolate(self, lo, H, W):
+        h, w, D = lo.shape
+        o = self.torch.empty((H, W, D), dtype=lo.dtype, device=lo.device)
+        self._chk(lib().bcd_hip_interpolate(self.h, _dp(lo), w, h, D, _dp(o), W, H))
+        return o
+
+    def merge(self, hi, lo):
+        H, W, D = hi.shape
+        o = hi.clone()
+        self._chk(lib().bcd_hip_merge(self.h, _dp(o), W, H, _dp(lo), D))
+        return o
+
+    def spike_filter(self, col, ns, hist, cov, factor):
+        H, W, D = hist.shape
+        o = [self.torch.empty_like(t) for t in (col, ns, hist, cov)]
+        self._chk(lib().bcd_hip_spike_filter(self.h, _dp(col), _dp(ns), _dp(hist), _dp(cov), W, H, D, C.c_float(factor),
+                                             _dp(o[0]), _dp(o[1]), _dp(o[2]), _dp(o[3])))
+        return o
+
+    def zero_bad_values(self, img):
+        self._chk(lib().bcd_hip_zero_bad_values(self.h, _dp(img), C.c_int64(img.numel())))
+        return img
+
+    # ---- stats / timing
+    def set_profiling(self, on):
+        self._chk(lib().bcd_hip_set_profiling(self.h, 1 if on else 0))
+
+    def stats(self, scale):
+        s = ScaleStats()
+        self._chk(lib().bcd_hip_get_stats(self.h, scale, C.byref(s)))
+        return s
+
+    def kernel_time(self):
+        ms, n = C.c_float(0), C.c_int32(0)
+        self._chk(lib().bcd_hip_kernel_time(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def reset_kernel_time(self):
+        self._chk(lib().bcd_hip_reset_kernel_time(self.h))
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+def visit_order(W, H, w, random_order, seed):
+    import numpy as np
+    out = np.empty(((W - 2 * w) * (H - 2 * w),), np.int32)
+    rc = lib().bcd_hip_visit_order(W, H, w, int(random_order), C.c_uint32(seed), out.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise BcdHipError("bcd_hip_visit_order rc=%d" % rc)
+    return out
+
+
+def scale_seed(seed0, scale):
+    return int(lib().bcd_hip_scale_seed(C.c_uint32(seed0), int(scale)))

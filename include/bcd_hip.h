@@ -1,0 +1,154 @@
+/*
+ * bcd_hip.h -- C ABI of the MI355X (gfx950) denoising engine: libbcd_hip.so
+ *
+ * This is the drop-in boundary UNDER the reference's C++ API.  The reference has no C ABI
+ * (SURVEY.md 8b); the entry points below are exactly the calls that the library's own
+ * bcd::Denoiser::denoise() / bcd::MultiscaleDenoiser::denoise() (bcd_amd/host/) make, i.e. what
+ * replaces, in the reference:
+ *     Denoiser::denoise()                 src/core/Denoiser.cpp:84-212
+ *     MultiscaleDenoiser::denoise()       src/core/MultiscaleDenoiser.cpp:31-136
+ *     DenoisingUnit::*                    src/core/DenoisingUnit.cpp:157-693
+ *     CudaHistogramDistance (per-pixel CUDA offload, not reproduced)  src/core/CudaHistogramDistance.cu:164-239
+ *
+ * Conventions
+ *   - every image is the reference's interleaved DeepImage layout, fp32:
+ *         index = (line * W + col) * depth + d      (include/bcd/core/DeepImage.hpp:385-396)
+ *     colours depth 3, nbOfSamples depth 1, histograms depth D (= 3 x bins), covariances depth 6 in
+ *     the order xx,yy,zz,yz,xz,xy (include/bcd/core/CovarianceMatrix.h:18-27).
+ *   - pointers named d_* are DEVICE pointers (HBM), h_* are host pointers.
+ *   - every function returns 0 on success, a negative BCD_HIP_E* code otherwise, and never calls
+ *     exit() (unlike HANDLE_ERROR, include/bcd/core/CudaUtils.h:18-30).
+ *   - work is enqueued on the context's stream; calls that return host-visible results synchronise it.
+ */
+#ifndef BCD_HIP_H
+#define BCD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCD_HIP_OK 0
+#define BCD_HIP_EINVAL (-1)   /* null / empty / mismatched inputs (Denoiser.cpp:266-347 returns false) */
+#define BCD_HIP_EDEVICE (-2)  /* HIP runtime error, message in bcd_hip_last_error()                     */
+#define BCD_HIP_ENOMEM (-3)
+#define BCD_HIP_EUNSUPPORTED (-4)
+
+typedef struct bcd_hip_ctx bcd_hip_ctx;
+
+/* mirrors bcd::DenoiserParameters (include/bcd/core/IDenoiser.h:20-44) */
+typedef struct bcd_hip_params {
+    float    hist_dist_threshold;     /* m_histogramDistanceThreshold          default 1     */
+    int32_t  patch_radius;            /* m_patchRadius                         default 1     */
+    int32_t  search_radius;           /* m_searchWindowRadius                  default 6     */
+    float    min_eigen_value;         /* m_minEigenValue                       default 1e-8  */
+    int32_t  use_random_pixel_order;  /* m_useRandomPixelOrder                 default 1     */
+    float    marked_skip_probability; /* m_markedPixelsSkippingProbability     default 1     */
+    uint32_t order_seed;              /* seed of the visiting order; the reference seeds its
+                                         shuffle from the wall clock (Denoiser.cpp:418)      */
+} bcd_hip_params;
+
+/* per-scale counters filled by the denoise calls (cf. COMPUTE_DENOISING_STATS,
+ * include/bcd/core/DenoisingUnit.h:35-65) */
+typedef struct bcd_hip_scale_stats {
+    int32_t width, height;
+    int64_t main_pixels;      /* (W-2w)(H-2w)                                    */
+    int64_t processed;        /* main pixels not skipped                          */
+    int64_t fallback;         /* processed through the <3P+1 similar-patch path   */
+    int64_t similar_total;    /* sum of |S| over processed pixels                 */
+    int32_t active_rounds;    /* fixed-point rounds of the marking strategy       */
+    float   ms_similarity;    /* GPU time of the distance + mask kernels (events) */
+    float   ms_active;
+    float   ms_bayes;
+    float   ms_total;
+} bcd_hip_scale_stats;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int  bcd_hip_ctx_create(bcd_hip_ctx **ctx, int device, void *hip_stream /* hipStream_t or NULL */);
+void bcd_hip_ctx_destroy(bcd_hip_ctx *ctx);
+const char *bcd_hip_last_error(const bcd_hip_ctx *ctx);
+int  bcd_hip_device_count(void);
+void bcd_hip_default_params(bcd_hip_params *p);
+/* enable per-stage event timing into the stats (adds stream synchronisations) */
+int  bcd_hip_set_profiling(bcd_hip_ctx *ctx, int enabled);
+int  bcd_hip_get_stats(const bcd_hip_ctx *ctx, int scale, bcd_hip_scale_stats *out);
+/* duration (ms, HIP events on the context's stream) and launch count of the pair-distance kernel
+ * accumulated since the last reset -- the dominant kernel measured by bench.py's roofline */
+int  bcd_hip_kernel_time(const bcd_hip_ctx *ctx, float *ms_pairdist, int32_t *launches);
+int  bcd_hip_reset_kernel_time(bcd_hip_ctx *ctx);
+
+/* ---- whole path, device-resident inputs (what bench.py times) ----------------------------------
+ * replaces Denoiser::denoise() (nb_scales == 1) / MultiscaleDenoiser::denoise() (nb_scales > 1).
+ * d_out: W*H*3 floats. */
+int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_nsamples,
+                    const float *d_histograms, const float *d_covariances,
+                    int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *d_out);
+
+/* row-block variant for multi-GPU tiling: the images are a horizontal band of a larger frame;
+ * only main pixels on local lines [main_row_begin, main_row_end) are processed, and instead of the
+ * finalised colours the raw accumulators are returned (d_sum W*H*3 floats, d_count W*H int32), so
+ * that neighbouring bands can exchange and add their halo lines before bcd_hip_finalize(). */
+int bcd_hip_denoise_band(bcd_hip_ctx *ctx, const float *d_colors, const float *d_nsamples,
+                         const float *d_histograms, const float *d_covariances,
+                         int W, int H, int D, int main_row_begin, int main_row_end,
+                         const bcd_hip_params *prm, uint32_t order_seed, float *d_sum, int32_t *d_count);
+
+/* ---- whole path, host buffers (what bcd::Denoiser / bcd_cli call): H2D + denoise + D2H -------- */
+int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_nsamples,
+                         const float *h_histograms, const float *h_covariances,
+                         int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out);
+
+/* ---- stages (device pointers) -- exposed for parity tests and multi-GPU composition ------------ */
+/* Denoiser::computePixelCovFromSampleCov   src/core/Denoiser.cpp:357-373 */
+int bcd_hip_pixel_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_nsamples, int W, int H, float *d_out);
+/* DenoisingUnit::selectSimilarPatches for every main pixel   src/core/DenoisingUnit.cpp:196-219,336-386
+ * d_mask: W*H*words uint32, bit (dl+b)*(2b+1)+(dc+b); d_count: W*H int32 = |S|.  words = ceil((2b+1)^2/32) */
+int bcd_hip_similarity_masks(bcd_hip_ctx *ctx, const float *d_histograms, const float *d_nsamples,
+                             int W, int H, int D, int patch_radius, int search_radius, float threshold,
+                             uint32_t *d_mask, int32_t *d_count);
+/* raw patch distances of one main pixel to its window (debug / parity): (2b+1)^2 floats, +inf outside */
+int bcd_hip_window_distances(bcd_hip_ctx *ctx, const float *d_histograms, const float *d_nsamples,
+                             int W, int H, int D, int patch_radius, int search_radius,
+                             int line, int col, float *h_out);
+/* the marking strategy (DenoisingUnit.cpp:164-173,690) as a parallel fixed point.
+ * d_state: W*H uint8: 0 = not a main pixel / outside band, 1 = processed, 2 = skipped. */
+int bcd_hip_active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_count,
+                       int W, int H, int patch_radius, int search_radius,
+                       int main_row_begin, int main_row_end,
+                       float skip_probability, int random_order, uint32_t seed,
+                       uint8_t *d_state, int32_t *rounds);
+/* denoiseSelectedPatches / denoiseOnlyMainPatch + aggregateOutputPatches for every processed pixel
+ * (DenoisingUnit.cpp:388-481,672-693); d_sum / d_count are accumulated into (zero them first). */
+int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixel_cov,
+                             const uint32_t *d_mask, const int32_t *d_nsim, const uint8_t *d_state,
+                             int W, int H, int patch_radius, int search_radius, float min_eigen_value,
+                             float *d_sum, int32_t *d_count);
+/* Denoiser::finalAggregation   src/core/Denoiser.cpp:458-469 */
+int bcd_hip_finalize(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int64_t npix, float *d_out);
+/* MultiscaleDenoiser pyramid + merge   src/core/MultiscaleDenoiser.cpp:243-334,453-548 */
+int bcd_hip_downscale_sum(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int D, float *d_out);
+int bcd_hip_downscale_avg(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int D, float *d_out);
+int bcd_hip_downscale_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_nsamples, int W, int H, float *d_out);
+int bcd_hip_interpolate(bcd_hip_ctx *ctx, const float *d_lo, int w, int h, int D, float *d_hi, int W, int H);
+/* d_hi (W x H x D) <- d_hi - up(down(d_hi)) + up(d_lo) */
+int bcd_hip_merge(bcd_hip_ctx *ctx, float *d_hi, int W, int H, const float *d_lo, int D);
+/* SpikeRemovalFilter::filter   src/core/SpikeRemovalFilter.cpp:18-116 (out of place) */
+int bcd_hip_spike_filter(bcd_hip_ctx *ctx, const float *d_colors, const float *d_nsamples,
+                         const float *d_histograms, const float *d_covariances, int W, int H, int D, float factor,
+                         float *d_colors_out, float *d_nsamples_out, float *d_histograms_out, float *d_covariances_out);
+/* checkAndPutToZeroNegativeInfNaNValues   src/cli/main.cpp:389-420 */
+int bcd_hip_zero_bad_values(bcd_hip_ctx *ctx, float *d_img, int64_t n);
+
+/* ---- host utilities (no device work) ----------------------------------------------------------- */
+/* the visiting order implied by (random_order, seed): main-pixel linear indices line*W+col in
+ * visiting order, written to h_order[(W-2w)*(H-2w)].  random_order == 0 is the reference's
+ * single-thread scanline order (Denoiser.cpp:136-146). */
+int bcd_hip_visit_order(int W, int H, int patch_radius, int random_order, uint32_t seed, int32_t *h_order);
+/* seed used for scale s of a multiscale run started with seed0 */
+uint32_t bcd_hip_scale_seed(uint32_t seed0, int scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
