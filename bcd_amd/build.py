@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # hard threshold; kernels call fmaf() explicitly where fusing is wanted.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
              "-Wno-unused-result", "-Wno-unused-value", "-fhip-fp32-correctly-rounded-divide-sqrt"]
-CXX_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-fopenmp"]
+CXX_FLAGS = ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-fopenmp"]
 
 
 def _newer(target, deps):
@@ -80,12 +80,12 @@ def build_host(verbose=False):
         list(ex.map(_run, jobs))
     so = os.path.join(LIB, "libbcdcore.so")
     if _newer(so, objs + [os.path.join(LIB, "libbcd_hip.so")]):
-        _run(["g++", "-shared", "-fPIC", "-fopenmp", "-o", so] + objs + ["-L" + LIB, "-lbcd_hip", "-lz", "-Wl,-rpath,$ORIGIN"])
+        _run(["g++", "-shared", "-fPIC", "-fopenmp", "-o", so] + objs + ["-L" + LIB, "-lbcd_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz", "-Wl,-rpath,$ORIGIN"])
     cli_src = os.path.join(HOST, "bcd_cli.cpp")
     if os.path.exists(cli_src):
         exe = os.path.join(LIB, "bcd_cli")
         if _newer(exe, [cli_src, so] + hdrs):
-            _run(["g++"] + CXX_FLAGS + inc + [cli_src, "-o", exe, "-L" + LIB, "-lbcdcore", "-lbcd_hip", "-lz", "-Wl,-rpath,$ORIGIN"])
+            _run(["g++"] + CXX_FLAGS + inc + [cli_src, "-o", exe, "-L" + LIB, "-lbcdcore", "-lbcd_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz", "-Wl,-rpath,$ORIGIN"])
     return so
 
 

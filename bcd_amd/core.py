@@ -1,0 +1,82 @@
+"""ctypes binding of the plain-C exports of libbcdcore.so (bcd_amd/host/capi.cpp): synthetic scenes, the
+SamplesAccumulator, and the C++ bcd::Denoiser / bcd::MultiscaleDenoiser classes.  Plumbing for bench.py and tests."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbcdcore.so")
+_F = C.POINTER(C.c_float)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libbcdcore.so is not built (%s): run `python -m bcd_amd.build`" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def _fp(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_F)
+
+
+def synthetic_scene(W, H, spp=32, seed=1234, sigma=0.35, spike_prob=0.01, first_line=0, nb_lines=None):
+    """(colors, nsamples, histograms, covariances) of lines [first_line, first_line+nb_lines) of a W x H frame"""
+    n = H - first_line if nb_lines is None else nb_lines
+    ns = np.empty((n, W, 1), np.float32)
+    mean = np.empty((n, W, 3), np.float32)
+    cov = np.empty((n, W, 6), np.float32)
+    hist = np.empty((n, W, 60), np.float32)
+    rc = lib().bcdcore_synthetic_scene(W, H, spp, C.c_uint(seed), C.c_float(sigma), C.c_float(spike_prob), first_line, n,
+                                       _fp(ns), _fp(mean), _fp(cov), _fp(hist))
+    if rc != 0:
+        raise ValueError("bcdcore_synthetic_scene rc=%d" % rc)
+    return mean, ns, hist, cov
+
+
+def accumulate(samples, W, H, nbins=20, gamma=2.2, maxval=2.5):
+    samples = np.ascontiguousarray(samples, np.float32)
+    ns = np.empty((H, W, 1), np.float32)
+    mean = np.empty((H, W, 3), np.float32)
+    cov = np.empty((H, W, 6), np.float32)
+    hist = np.empty((H, W, 3 * nbins), np.float32)
+    lib().bcdcore_accumulate(_fp(samples), C.c_longlong(samples.shape[0]), W, H, nbins, C.c_float(gamma), C.c_float(maxval),
+                             _fp(ns), _fp(mean), _fp(cov), _fp(hist))
+    return ns, mean, cov, hist
+
+
+def denoise(col, ns, hist, cov, nscales=1, tau=1.0, w=1, b=6, min_eig=1e-8, random_order=True, m=1.0, seed=1234):
+    """bcd::Denoiser / bcd::MultiscaleDenoiser via IDenoiser; returns (ok, out, progress_monotone)"""
+    H, W, D = hist.shape
+    out = np.zeros((H, W, 3), np.float32)
+    p = lambda a: None if a is None else _fp(a)
+    rc = lib().bcdcore_denoise(p(col), p(ns), p(hist), p(cov), W, H, D, nscales, C.c_float(tau), w, b, C.c_float(min_eig),
+                               1 if random_order else 0, C.c_float(m), C.c_uint(seed), _fp(out))
+    return rc != 0, out, rc == 1
+
+
+def spike_filter(col, ns, hist, cov, factor=2.0):
+    H, W, D = hist.shape
+    c, n, h, v = col.copy(), ns.copy(), hist.copy(), cov.copy()
+    lib().bcdcore_spike_filter(_fp(c), _fp(n), _fp(h), _fp(v), W, H, D, C.c_float(factor))
+    return c, n, h, v
+
+
+def merge_hist_ns(hist, ns):
+    H, W, D = hist.shape
+    out = np.empty((H, W, D + 1), np.float32)
+    lib().bcdcore_merge_hist_ns(_fp(hist), _fp(ns), W, H, D, _fp(out))
+    return out
+
+
+def split_hist_ns(merged):
+    H, W, D1 = merged.shape
+    hist = np.empty((H, W, D1 - 1), np.float32)
+    ns = np.empty((H, W, 1), np.float32)
+    rc = lib().bcdcore_split_hist_ns(_fp(merged), W, H, D1, _fp(hist), _fp(ns))
+    return (hist, ns) if rc == 0 else None

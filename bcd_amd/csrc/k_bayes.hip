@@ -211,7 +211,7 @@ __device__ int decode_members(const uint32_t *mask, int p, const BayesGeom &g, i
     return total;
 }
 
-__global__ __launch_bounds__(64) void k_bayes_strong(const float *__restrict__ colors, const float *__restrict__ pixcov,
+__global__ __launch_bounds__(64) void k_bayes_strong_generic(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                      const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
                                                      BayesGeom g, float min_eig, float *sum, int32_t *cnt)
 {
@@ -311,26 +311,33 @@ BayesGeom make_geom(int W, int H, int w, int b)
 
 } // namespace
 
+size_t bcd_bayes27_lds_bytes(int b);
+
 size_t bcd_bayes_lds_bytes(int w, int b)
 {
+    if (w == 1) return bcd_bayes27_lds_bytes(b);
     BayesGeom g = make_geom(0, 0, w, b);
     size_t f = (size_t)g.maxS + 2 * (size_t)g.maxS * g.K + 3 * (size_t)g.KP * g.LD + g.P * 6 + 2 * g.K + 4 * (g.KP / 2);
     return f * sizeof(float);
 }
 
+hipError_t bcd_launch_bayes27(const float *, const float *, const uint32_t *, const int32_t *, int, int, int, int, float, float *, int32_t *,
+                              hipStream_t);
+
 hipError_t bcd_launch_bayes_strong(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int nlist,
                                    int W, int H, int w, int b, float min_eig, float *sum, int32_t *cnt, hipStream_t st)
 {
     if (nlist <= 0) return hipSuccess;
+    if (w == 1) return bcd_launch_bayes27(colors, pixcov, mask, list, nlist, W, H, b, min_eig, sum, cnt, st);
     BayesGeom g = make_geom(W, H, w, b);
     if (g.words > 32) return hipErrorInvalidValue;
     size_t lds = bcd_bayes_lds_bytes(w, b);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bayes_strong), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bayes_strong_generic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_bayes_strong, dim3(nlist), dim3(64), lds, st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
+    hipLaunchKernelGGL(k_bayes_strong_generic, dim3(nlist), dim3(64), lds, st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
     return hipGetLastError();
 }
 

@@ -1,0 +1,103 @@
+// capi.cpp -- plain-C exports of libbcdcore for the Python plumbing (bench.py, tests): synthetic scenes,
+// the SamplesAccumulator, Utils packing, and the bcd::Denoiser / bcd::MultiscaleDenoiser classes themselves.
+#include "Denoiser.h"
+#include "MultiscaleDenoiser.h"
+#include "SamplesAccumulator.h"
+#include "SpikeRemovalFilter.h"
+#include "SyntheticScene.h"
+#include "Utils.h"
+
+#include <memory>
+
+using namespace bcd;
+
+extern "C" {
+
+// W x i_nbOfLines band of a W x H synthetic frame; outputs: ns [n], mean [n*3], cov [n*6], hist [n*60]
+int bcdcore_synthetic_scene(int W, int H, int spp, unsigned seed, float sigma, float spikeProbability, int firstLine, int nbOfLines,
+		float* o_ns, float* o_mean, float* o_cov, float* o_hist)
+{
+	if(W <= 0 || H <= 0 || spp <= 0 || firstLine < 0 || firstLine + nbOfLines > H) return -1;
+	SyntheticSceneParameters p;
+	p.m_width = W; p.m_height = H; p.m_samplesPerPixel = spp; p.m_seed = seed; p.m_noiseSigma = sigma; p.m_spikeProbability = spikeProbability;
+	SamplesStatisticsImages st = generateSyntheticScene(p, firstLine, nbOfLines);
+	st.m_nbOfSamplesImage.copyDataTo(o_ns);
+	st.m_meanImage.copyDataTo(o_mean);
+	st.m_covarImage.copyDataTo(o_cov);
+	st.m_histoImage.copyDataTo(o_hist);
+	return 0;
+}
+
+// samples: n x (line, col, r, g, b, weight)
+int bcdcore_accumulate(const float* s, long long n, int W, int H, int nbins, float gamma, float maxval, float* ns, float* mean, float* cov, float* hist)
+{
+	HistogramParameters hp;
+	hp.m_nbOfBins = nbins; hp.m_gamma = gamma; hp.m_maxValue = maxval;
+	SamplesAccumulator acc(W, H, hp);
+	for(long long i = 0; i < n; ++i, s += 6)
+		acc.addSample(int(s[0]), int(s[1]), s[2], s[3], s[4], s[5]);
+	SamplesStatisticsImages st = acc.getSamplesStatistics();
+	st.m_nbOfSamplesImage.copyDataTo(ns);
+	st.m_meanImage.copyDataTo(mean);
+	st.m_covarImage.copyDataTo(cov);
+	st.m_histoImage.copyDataTo(hist);
+	return 0;
+}
+
+// runs bcd::Denoiser (nscales == 1) or bcd::MultiscaleDenoiser through the IDenoiser interface; returns denoise()'s bool.
+// Null pointers are forwarded as null images to exercise the validation path.
+int bcdcore_denoise(const float* col, const float* ns, const float* hist, const float* cov, int W, int H, int D, int nscales,
+		float tau, int w, int b, float minEig, int randomOrder, float skipProbability, unsigned seed, float* out)
+{
+	Deepimf cImg, nImg, hImg, vImg, oImg(W > 0 ? W : 0, H > 0 ? H : 0, 3);
+	DenoiserInputs in;
+	if(col) { cImg.resize(W, H, 3); cImg.copyDataFrom(col); in.m_pColors = &cImg; }
+	if(ns) { nImg.resize(W, H, 1); nImg.copyDataFrom(ns); in.m_pNbOfSamples = &nImg; }
+	if(hist) { hImg.resize(W, H, D); hImg.copyDataFrom(hist); in.m_pHistograms = &hImg; }
+	if(cov) { vImg.resize(W, H, 6); vImg.copyDataFrom(cov); in.m_pSampleCovariances = &vImg; }
+	DenoiserOutputs o;
+	o.m_pDenoisedColors = &oImg;
+	DenoiserParameters p;
+	p.m_histogramDistanceThreshold = tau; p.m_patchRadius = w; p.m_searchWindowRadius = b; p.m_minEigenValue = minEig;
+	p.m_useRandomPixelOrder = randomOrder != 0; p.m_markedPixelsSkippingProbability = skipProbability;
+	std::unique_ptr<Denoiser> d(nscales > 1 ? new MultiscaleDenoiser(nscales) : new Denoiser());
+	d->setOrderSeed(seed);
+	IDenoiser* pDenoiser = d.get();
+	pDenoiser->setInputs(in);
+	pDenoiser->setOutputs(o);
+	pDenoiser->setParameters(p);
+	float last = -1.f;
+	bool monotone = true;
+	pDenoiser->setProgressCallback([&](float f) { if(f < last) monotone = false; last = f; });
+	const bool ok = pDenoiser->denoise();
+	if(ok && out) oImg.copyDataTo(out);
+	return ok ? (monotone ? 1 : 2) : 0;
+}
+
+int bcdcore_spike_filter(float* col, float* ns, float* hist, float* cov, int W, int H, int D, float factor)
+{
+	Deepimf c(W, H, 3), n(W, H, 1), h(W, H, D), v(W, H, 6);
+	c.copyDataFrom(col); n.copyDataFrom(ns); h.copyDataFrom(hist); v.copyDataFrom(cov);
+	SpikeRemovalFilter::filter(c, n, h, v, factor);
+	c.copyDataTo(col); n.copyDataTo(ns); h.copyDataTo(hist); v.copyDataTo(cov);
+	return 0;
+}
+
+int bcdcore_merge_hist_ns(const float* hist, const float* ns, int W, int H, int D, float* out)
+{
+	Deepimf h(W, H, D), n(W, H, 1);
+	h.copyDataFrom(hist); n.copyDataFrom(ns);
+	Utils::mergeHistogramAndNbOfSamples(h, n).copyDataTo(out);
+	return 0;
+}
+
+int bcdcore_split_hist_ns(const float* in, int W, int H, int Dp1, float* hist, float* ns)
+{
+	Deepimf m(W, H, Dp1), h, n;
+	m.copyDataFrom(in);
+	if(!Utils::separateNbOfSamplesFromHistogram(h, n, m)) return -1;
+	h.copyDataTo(hist); n.copyDataTo(ns);
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the denoising hot path on MI355X (BASELINE.json metric).
+
+A "step" is one full denoise of one synthetic frame (3-scale, b=6, w=1, tau=1, m=1, seeded random order): the
+pyramid build, and per scale the pair-distance / mask kernels, the marking fixed point, the Bayesian patch
+kernel, finalisation and merge.  Inputs are resident in HBM before the timed region.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into horizontal bands of
+main pixels (strong scaling); every rank owns a band plus (b+w)*2^(S-1) halo lines of input, rebuilds the pyramid
+for its band, and exchanges accumulator / output halo lines with its neighbours over RCCL.
+
+One JSON line on rank 0 (contract in the task statement), with the extra objects `roofline` (pair-distance
+kernel, HIP-event timed inside this process) and `cpu_baseline` (oracle on host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_READ_BYTES_PER_PIXEL = 280  # (D+1+3+6)*4 bytes read per pixel of a scale, D = 60
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--scales", type=int, default=3)
+    ap.add_argument("--spp", type=int, default=32)
+    ap.add_argument("--sigma", type=float, default=0.35, help="synthetic noise level (0.35 + 1%% spikes = SURVEY probe)")
+    ap.add_argument("--spikes", type=float, default=0.01)
+    ap.add_argument("--search-radius", type=int, default=6)
+    ap.add_argument("--skip-prob", type=float, default=1.0, help="-m of bcd_cli")
+    ap.add_argument("--random-order", type=int, default=1, help="-r of bcd_cli")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="480x270", help="frame size of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """oracle (own C port of the reference CPU/OpenMP path) on the host cores, bounded sample of the same workload:
+    same generator, same flags, reference-style OpenMP scheduling (racy marks, strip order)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    import bcd_amd.core as core
+    w, h = [int(v) for v in args.cpu_sample.split("x")]
+    col, ns, hist, cov = core.synthetic_scene(w, h, args.spp, 1234, args.sigma, args.spikes)
+    cores = os.cpu_count() or 1
+    prm = ol.params(tau=1.0, w=1, b=args.search_radius, m=args.skip_prob, threads=cores)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        ol.denoise_multiscale(col, ns, hist, cov, args.scales, prm, racy=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(w * h / 1e6 / best, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d synthetic frame (same generator/flags), %d-scale, OpenMP dynamic strips like the reference, "
+                      "best of 2, %.2f s" % (w, h, args.scales, best)}
+
+
+def main():
+    args = parse()
+    import torch
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, S, b, w = args.width, args.height, args.scales, args.search_radius, 1
+    prm = bh.default_params(b=b, w=w, m=args.skip_prob, random_order=args.random_order, seed=1234)
+    ctx = bh.Context(local_rank, torch.cuda.current_stream())
+
+    if world == 1:
+        col, ns, hist, cov = core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes)
+        d_in = [torch.from_numpy(a).cuda() for a in (col, ns, hist, cov)]
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+
+        def step():
+            ctx.denoise(*d_in, S, prm, out)
+    else:
+        from bcd_amd.tiling import BandDenoiser
+        band = BandDenoiser(ctx, dist, rank, world, W, H, 60, S, prm)
+        g0, g1 = band.input_lines()
+        col, ns, hist, cov = core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes, g0, g1 - g0)
+        band.upload(col, ns, hist, cov)
+        step = band.step
+
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.reset_kernel_time()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_step = elapsed * 1e3 / args.steps
+
+    # ---- roofline of the dominant kernel (pair-distance planes), HIP events on the engine's stream
+    pd_ms, pd_launches = ctx.kernel_time()
+    scale_pixels = []
+    for s in range(S):
+        st = ctx.stats(s)
+        scale_pixels.append(st.width * st.height)
+    algo_bytes_per_step = ALGO_READ_BYTES_PER_PIXEL * sum(scale_pixels)
+    achieved = (algo_bytes_per_step * args.steps / (pd_ms * 1e-3)) / 1e9 if pd_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "k_pairdist<60>", "launches": pd_launches,
+                "avg_launch_ms": round(pd_ms / max(1, pd_launches), 4),
+                "algorithmic_bytes_per_launch_avg": int(algo_bytes_per_step / S),
+                "note": "compute(VALU)-bound kernel: 85 displacements x 60 bins of IEEE-exact chi-square per pixel; see DESIGN.md"}
+    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            key = "%dx%d_s%d" % (W, H, S)
+            if key in tr:
+                roofline["traffic"] = tr[key]["hbm_bytes_per_launch_avg"]
+        except Exception:
+            pass
+
+    scales = []
+    for s in range(S):
+        st = ctx.stats(s)
+        scales.append({"scale": s, "w": st.width, "h": st.height, "processed_frac": round(st.processed / max(1, st.main_pixels), 4),
+                       "fallback_frac": round(st.fallback / max(1, st.processed), 4),
+                       "mean_similar": round(st.similar_total / max(1, st.processed), 2), "rounds": st.active_rounds})
+
+    if rank == 0:
+        res = {
+            "metric": "Mpixels/sec denoised (3-scale, b=6, w=1)", "value": round(W * H / 1e6 / (ms_step * 1e-3), 3), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d synthetic frame (%d spp, sigma %.2f, spikes %.2f), %d-scale, b=%d w=1 d=1 e=1e-8, -m %g -r %d (seeded), no prefilter"
+                                   % (W, H, args.spp, args.sigma, args.spikes, S, b, args.skip_prob, args.random_order),
+                       "parallelism": "rowband%d" % world if world > 1 else "single", "per_scale": scales},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

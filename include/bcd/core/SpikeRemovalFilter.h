@@ -1,0 +1,26 @@
+// SpikeRemovalFilter.h -- optional outlier prefilter (bcd_cli -p); API of the reference's
+// include/bcd/core/SpikeRemovalFilter.h.  Runs as a HIP kernel (bcd_hip_spike_filter).
+#ifndef SPIKE_REMOVAL_FILTER_H
+#define SPIKE_REMOVAL_FILTER_H
+
+namespace bcd
+{
+
+	template<typename T> class DeepImage;
+
+	class SpikeRemovalFilter
+	{
+	public:
+		/// replaces, in place, every pixel whose colour deviates from its 3x3 neighbourhood mean by more than
+		/// i_thresholdStDevFactor standard deviations (any channel) by the neighbour of median colour
+		static void filter(
+				DeepImage<float>& io_rInputColorImage,
+				DeepImage<float>& io_rInputNbOfSamplesImage,
+				DeepImage<float>& io_rInputHistogramImage,
+				DeepImage<float>& io_rInputCovImage,
+				float i_thresholdStDevFactor = 2.f);
+	};
+
+} // namespace bcd
+
+#endif // SPIKE_REMOVAL_FILTER_H
