@@ -14,8 +14,14 @@
 //     accepted only if every pivot is positive and ||M^-1||_F * minEig <= 1 (which proves
 //     lambda_min(M) >= minEig); otherwise the spectral form is evaluated with the Jacobi solver.
 #include "bcd_common.h"
+#include <cstdio>
+#include <cstdlib>
+
+__device__ long long bcd_dbg_cycles[16];
 
 namespace {
+
+#define DBG_T(i) do { if (DBG && blockIdx.x == 100 && lane == 0) bcd_dbg_cycles[i] = __builtin_readcyclecounter(); } while (0)
 
 constexpr int K = 27, KP = 28, LD = 29, P = 9, MSZ = KP * LD, CHUNK = 32;
 
@@ -255,6 +261,7 @@ __device__ inline void stage_chunk(float *chunk, const float *__restrict__ color
     __syncthreads();
 }
 
+template <bool DBG>
 __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                 const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
                                                 Geom27 g, float min_eig, float *sum, int32_t *cnt)
@@ -270,8 +277,10 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     int *rp = reinterpret_cast<int *>(rs + KP / 2), *rq = rp + KP / 2;
     int *mem = rq + KP / 2;
 
+    DBG_T(0);
     const int p = list[blockIdx.x];
     const int n = decode_members27(mask, p, g, mem, lane);
+    DBG_T(1);
     const float n_inv = 1.f / (float)n;
     const int W = g.W;
 
@@ -283,6 +292,8 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
         for (int i = 0; i < n; ++i) acc += pixcov[(size_t)(mem[i] + offp) * 6 + j];
         noise[lane] = acc * n_inv;
     }
+    __syncthreads();
+    DBG_T(2);
     // empiricalMean (:500-509), members in order
     {
         float acc = 0.f;
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
         if (lane < K) mean[lane] = acc * n_inv;
         __syncthreads();
     }
+    DBG_T(3);
     // centerPointCloud + empiricalCovarianceMatrix (:511-536): 378 lower-triangle entries, 6 per lane
     {
         constexpr int NE = (K * (K + 1) / 2 + 63) / 64;
@@ -329,11 +341,15 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     }
 
     // ---- Step 1 (:421-436): M1 = clamp(C - N) + N ; Cinv1 = inverse(M1)
+    DBG_T(4);
     add_noise27(A, noise, lane, -1.f);
     jacobi27(A, V, rc, rs, rp, rq, lane);
+    DBG_T(5);
     rebuild27(Bm, A, V, fl, lane, false, 0.f);
     add_noise27(Bm, noise, lane, +1.f);
+    DBG_T(6);
     inverse27(Bm, A, V, fl, rc, rs, rp, rq, lane, min_eig);
+    DBG_T(7);
     // ---- Step 2 (:438-453): the Step-1 estimates are xhat = x - G (x - m) with G = N Cinv1, hence their empirical
     // mean is m and their empirical covariance is F C F^T, F = I - G
     noise_times27(V, noise, Bm, lane, true);       // V  = F
@@ -347,8 +363,10 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; if (r < c) Bm[r * LD + c] = Cm[r * LD + c]; }
     __syncthreads();
     add_noise27(Bm, noise, lane, +1.f);
+    DBG_T(8);
     inverse27(Bm, A, V, fl, rc, rs, rp, rq, lane, min_eig);
-    noise_times27(Cm, noise, Bm, lane, false);     // Cm = G2 = N Cinv2
+    noise_times27(Cm, noise, Bm, lane, false);
+    DBG_T(9);     // Cm = G2 = N Cinv2
 
     // ---- finalDenoisingMatrixMultiplication (:656-670) on the noisy patches centred on m, aggregateOutputPatches (:672-693)
     for (int i0 = 0; i0 < n; i0 += CHUNK) {
@@ -372,6 +390,8 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
         }
         __syncthreads();
     }
+    DBG_T(10);
+    if (DBG && blockIdx.x == 100 && lane == 0) bcd_dbg_cycles[11] = n;
 }
 
 } // namespace
@@ -389,6 +409,14 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     Geom27 g;
     g.W = W; g.H = H; g.b = b; g.side = 2 * b + 1; g.words = (g.side * g.side + 31) / 32; g.maxS = g.side * g.side;
     if (g.words > 32) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_bayes27, dim3(nlist), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
+    if (getenv("BCD_DBG_BAYES")) {
+        hipLaunchKernelGGL(k_bayes27<true>, dim3(nlist), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
+        long long h[16];
+        hipStreamSynchronize(st);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(bcd_dbg_cycles), sizeof(h));
+        fprintf(stderr, "bayes27 dbg n=%lld: decode %lld noise %lld mean %lld cov %lld jacobi %lld rebuild %lld inv1 %lld step2mm %lld inv2 %lld final %lld total %lld\n", h[11], h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5], h[7]-h[6], h[8]-h[7], h[9]-h[8], h[10]-h[9], h[10]-h[0]);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_bayes27<false>, dim3(nlist), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
     return hipGetLastError();
 }

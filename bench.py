@@ -86,7 +86,10 @@ def main():
 
     W, H, S, b, w = args.width, args.height, args.scales, args.search_radius, 1
     prm = bh.default_params(b=b, w=w, m=args.skip_prob, random_order=args.random_order, seed=1234)
-    ctx = bh.Context(local_rank, torch.cuda.current_stream())
+    # one side stream for everything: engine kernels, torch glue and (N > 1) the RCCL point-to-point ops are stream-ordered
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx = bh.Context(local_rank, stream)
 
     if world == 1:
         col, ns, hist, cov = core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes)

@@ -599,6 +599,40 @@ int bcdo_denoise_mono(const float *colors, const float *nsamp, const float *hist
     return 0;
 }
 
+
+/* Band form used by the multi-GPU tests: main pixels on lines [row_begin,row_end) only, raw accumulators out
+ * (sum W*H*3, cnt W*H, zeroed here).  Serial; order == NULL -> scanline.  Same per-pixel code as above. */
+int bcdo_accumulate_band(const float *colors, const float *nsamp, const float *hist, const float *cov,
+                         int W, int H, int D, const BcdoParams *prm, int row_begin, int row_end,
+                         const int32_t *order, int64_t n_order, float *sum, int32_t *cnt)
+{
+    int rc = check_inputs(colors, nsamp, hist, cov, W, H, D, prm);
+    if (rc) return rc;
+    size_t npix = (size_t)W * H;
+    int w = prm->patch_radius;
+    float *pixcov = (float *)malloc(sizeof(float) * npix * 6);
+    bcdo_pixel_cov_from_sample_cov(cov, nsamp, W, H, pixcov);
+    uint8_t *marked = (uint8_t *)calloc(npix, 1);
+    memset(sum, 0, sizeof(float) * npix * 3);
+    memset(cnt, 0, sizeof(int32_t) * npix);
+    Unit u;
+    unit_init(&u, W, H, D, prm, colors, nsamp, hist, pixcov, sum, cnt, marked);
+    if (order) {
+        for (int64_t i = 0; i < n_order; ++i) {
+            int pl = order[i] / W, pc = order[i] % W;
+            if (pl >= row_begin && pl < row_end) denoise_patch_and_similar(&u, pl, pc, prm->skip_probability, NULL);
+        }
+    } else {
+        for (int pl = imax(w, row_begin); pl <= imin(H - 1 - w, row_end - 1); ++pl)
+            for (int pc = w; pc <= W - 1 - w; ++pc) denoise_patch_and_similar(&u, pl, pc, prm->skip_probability, NULL);
+    }
+    unit_free(&u);
+    free(marked); free(pixcov);
+    return 0;
+}
+
+void bcdo_finalize(const float *sum, const int32_t *cnt, int64_t npix, float *out) { final_divide(sum, cnt, (size_t)npix, out); }
+
 /* Reference-style parallel m=1 (racy, NOT reproducible): strip reorder (Denoiser.cpp:382-414),
  * schedule(dynamic, chunk) (:164-172), shared mark image (:161-162).  Timing baseline only. */
 int bcdo_denoise_mono_omp_racy(const float *colors, const float *nsamp, const float *hist, const float *cov,

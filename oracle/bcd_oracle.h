@@ -76,6 +76,12 @@ int bcdo_denoise_mono(const float *colors, const float *nsamp, const float *hist
                       const int32_t *order, int64_t n_order,
                       float *out, const BcdoDiag *diag);
 
+/* band form for the multi-GPU tests: main pixels on lines [row_begin,row_end), raw accumulators (zeroed here) */
+int bcdo_accumulate_band(const float *colors, const float *nsamp, const float *hist, const float *cov,
+                         int W, int H, int D, const BcdoParams *prm, int row_begin, int row_end,
+                         const int32_t *order, int64_t n_order, float *sum, int32_t *cnt);
+void bcdo_finalize(const float *sum, const int32_t *cnt, int64_t npix, float *out);
+
 /* reference-style racy OpenMP m=1 run (shared mark image, strip order, dynamic schedule;
  * Denoiser.cpp:164-205,375-414) -- for cpu_baseline timing only, NOT reproducible. */
 int bcdo_denoise_mono_omp_racy(const float *colors, const float *nsamp, const float *hist, const float *cov,

@@ -1,0 +1,107 @@
+"""CPU tests of the multi-GPU row-band path: partition bookkeeping, and the full orchestration (per-band pyramid,
+accumulator / output halo exchange, merge at band edges) executed with the oracle as the per-band engine --
+in-process ("virtual ranks") and as two real processes over gloo."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as ol
+from oracle_engine import OracleEngine
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bcd_amd.tiling import BandGeometry, run_distributed, run_virtual  # noqa: E402
+
+
+class Prm:
+    hist_dist_threshold = 1.0
+    patch_radius = 1
+    search_radius = 3
+    min_eigen_value = 1e-8
+    use_random_pixel_order = 0
+    marked_skip_probability = 0.0
+    order_seed = 5
+
+
+@pytest.mark.parametrize("W,H,S,b,world", [(64, 64, 3, 6, 2), (3840, 2160, 3, 6, 8), (1280, 720, 3, 6, 8), (101, 67, 2, 3, 3), (50, 40, 1, 6, 2)])
+def test_geometry_invariants(W, H, S, b, world):
+    g = BandGeometry(W, H, S, b, 1, world)
+    for s in range(S):
+        covered = []
+        for r in range(world):
+            sb = g.scale_bands(r)[s]
+            assert 0 <= sb.loc0 <= sb.own0 < sb.own1 <= sb.loc1 <= (H >> s)
+            assert sb.loc0 % 2 == 0
+            if r > 0:
+                assert sb.own0 - sb.loc0 >= g.halo      # input halo above
+            if r < world - 1:
+                assert sb.loc1 - sb.own1 >= g.halo      # input halo below
+            if s + 1 < S:
+                nxt = g.scale_bands(r)[s + 1]
+                assert sb.loc0 <= 2 * nxt.loc0 and 2 * nxt.loc1 <= sb.loc1   # the coarser level is buildable locally
+                assert sb.own0 % 2 == 0
+            covered.append((sb.own0, sb.own1))
+        assert covered[0][0] == 0 and covered[-1][1] == (H >> s)
+        assert all(covered[i][1] == covered[i + 1][0] for i in range(world - 1))   # a partition of the lines
+
+
+def test_geometry_rejects_thin_bands():
+    with pytest.raises(ValueError):
+        BandGeometry(64, 40, 3, 6, 1, 8)
+
+
+def _inputs(W, H, spp=6):
+    col, ns, hist, cov, _ = ol.synth_inputs(W, H, spp, 99, 0.2, 0.0)
+    return col, ns, hist, cov
+
+
+def _slice(arrs, g, r):
+    l0, l1 = g.input_lines(r)
+    return [torch.from_numpy(np.ascontiguousarray(a[l0:l1])) for a in arrs]
+
+
+@pytest.mark.parametrize("W,H,S,world", [(40, 48, 2, 2), (37, 58, 3, 2), (36, 49, 2, 3)])
+def test_virtual_ranks_match_full_frame_m0(W, H, S, world):
+    """-m 0 is order-free: the band decomposition must reproduce the full-frame multiscale result"""
+    arrs = _inputs(W, H)
+    prm = Prm()
+    g = BandGeometry(W, H, S, prm.search_radius, 1, world)
+    outs = run_virtual(OracleEngine(None), g, [_slice(arrs, g, r) for r in range(world)], prm, 5)
+    got = np.concatenate([o.numpy() for o in outs], 0)
+    want = ol.denoise_multiscale(*arrs, S, ol.params(b=prm.search_radius, m=0.0, threads=1))
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-6
+
+
+def _gloo_worker(rank, world, port, W, H, S, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    arrs = _inputs(W, H)
+    prm = Prm()
+    g = BandGeometry(W, H, S, prm.search_radius, 1, world)
+    out = run_distributed(OracleEngine(None), g, rank, dist, _slice(arrs, g, rank), prm, 5)
+    q.put((rank, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_gloo_match_full_frame():
+    import torch.multiprocessing as mp
+    W, H, S, world = 36, 40, 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, W, H, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got = np.concatenate([res[r] for r in range(world)], 0)
+    want = ol.denoise_multiscale(*_inputs(W, H), S, ol.params(b=Prm.search_radius, m=0.0, threads=1))
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-6
