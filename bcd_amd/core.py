@@ -50,13 +50,13 @@ def accumulate(samples, W, H, nbins=20, gamma=2.2, maxval=2.5):
     return ns, mean, cov, hist
 
 
-def denoise(col, ns, hist, cov, nscales=1, tau=1.0, w=1, b=6, min_eig=1e-8, random_order=True, m=1.0, seed=1234):
+def denoise(col, ns, hist, cov, nscales=1, tau=1.0, w=1, b=6, min_eig=1e-8, random_order=True, m=1.0, seed=1234, hist_width_override=0):
     """bcd::Denoiser / bcd::MultiscaleDenoiser via IDenoiser; returns (ok, out, progress_monotone)"""
     H, W, D = hist.shape
     out = np.zeros((H, W, 3), np.float32)
     p = lambda a: None if a is None else _fp(a)
     rc = lib().bcdcore_denoise(p(col), p(ns), p(hist), p(cov), W, H, D, nscales, C.c_float(tau), w, b, C.c_float(min_eig),
-                               1 if random_order else 0, C.c_float(m), C.c_uint(seed), _fp(out))
+                               1 if random_order else 0, C.c_float(m), C.c_uint(seed), _fp(out), int(hist_width_override))
     return rc != 0, out, rc == 1
 
 

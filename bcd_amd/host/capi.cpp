@@ -47,13 +47,14 @@ int bcdcore_accumulate(const float* s, long long n, int W, int H, int nbins, flo
 // runs bcd::Denoiser (nscales == 1) or bcd::MultiscaleDenoiser through the IDenoiser interface; returns denoise()'s bool.
 // Null pointers are forwarded as null images to exercise the validation path.
 int bcdcore_denoise(const float* col, const float* ns, const float* hist, const float* cov, int W, int H, int D, int nscales,
-		float tau, int w, int b, float minEig, int randomOrder, float skipProbability, unsigned seed, float* out)
+		float tau, int w, int b, float minEig, int randomOrder, float skipProbability, unsigned seed, float* out, int histWidthOverride)
 {
 	Deepimf cImg, nImg, hImg, vImg, oImg(W > 0 ? W : 0, H > 0 ? H : 0, 3);
 	DenoiserInputs in;
 	if(col) { cImg.resize(W, H, 3); cImg.copyDataFrom(col); in.m_pColors = &cImg; }
 	if(ns) { nImg.resize(W, H, 1); nImg.copyDataFrom(ns); in.m_pNbOfSamples = &nImg; }
-	if(hist) { hImg.resize(W, H, D); hImg.copyDataFrom(hist); in.m_pHistograms = &hImg; }
+	if(hist && histWidthOverride > 0) { hImg.resize(histWidthOverride, H, D); hImg.fill(0.f); in.m_pHistograms = &hImg; } // deliberately mismatched size
+	else if(hist) { hImg.resize(W, H, D); hImg.copyDataFrom(hist); in.m_pHistograms = &hImg; }
 	if(cov) { vImg.resize(W, H, 6); vImg.copyDataFrom(cov); in.m_pSampleCovariances = &vImg; }
 	DenoiserOutputs o;
 	o.m_pDenoisedColors = &oImg;

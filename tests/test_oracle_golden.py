@@ -1,0 +1,133 @@
+"""CPU tests: the oracle against the committed golden fixtures.
+
+ref_*.npz were computed by the reference's own compiled translation units (tests/golden/make_golden.py); the
+oracle must reproduce them bit for bit -- that is the pin.  core_*.npz are oracle-generated regression vectors of
+the Eigen-dependent core ("parity unpinned": the reference core is unbuildable without Eigen)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+def test_accumulator_matches_reference_bits():
+    f = load("ref_accumulator.npz")
+    got = ol.oracle_ops()["accumulate"](f["samples"], int(f["W"]), int(f["H"]))
+    for g, k in zip(got, ("ns", "mean", "cov", "hist")):
+        assert same(g, f[k]), k
+
+
+def test_pyramid_merge_match_reference_bits():
+    f = load("ref_pyramid.npz")
+    o = ol.oracle_ops()
+    H, W, _ = f["mean"].shape
+    assert same(o["dsum"](f["hist"]), f["dsum_hist"])
+    assert same(o["dsum"](f["ns"]), f["dsum_ns"])
+    assert same(o["davg"](f["mean"]), f["davg_mean"])
+    assert same(o["dcov"](f["cov"], f["ns"]), f["dcov"])
+    assert same(o["interp"](f["davg_mean"], H, W), f["interp"])
+    assert same(o["merge"](f["mean"], o["davg"](f["interp"])), f["merge"])
+
+
+def test_spike_filter_matches_reference_bits():
+    f = load("ref_spike.npz")
+    got = ol.oracle_ops()["spike"](f["mean"], f["ns"], f["hist"], f["cov"], float(f["factor"]))
+    for g, k in zip(got, ("o_mean", "o_ns", "o_hist", "o_cov")):
+        assert same(g, f[k]), k
+
+
+@pytest.mark.skipif(ol.ref() is None, reason="oracle/_ref not built (needs /root/reference; authoring container only)")
+def test_oracle_equals_live_reference_units():
+    """fresh seeded inputs through the compiled reference units and the oracle, bit for bit"""
+    o, r = ol.oracle_ops(), ol.ref_ops()
+    for seed, (W, H) in enumerate([(31, 22), (16, 16), (3, 3), (50, 9)]):
+        samples, _ = ol.synth_samples(W, H, 5, seed=seed, sigma=0.5, spike_prob=0.1)
+        a, b = o["accumulate"](samples, W, H), r["accumulate"](samples, W, H)
+        assert all(same(x, y) for x, y in zip(a, b))
+        ns, mean, cov, hist = a
+        if W >= 4 and H >= 4:
+            assert same(o["dsum"](hist), r["dsum"](hist)) and same(o["dcov"](cov, ns), r["dcov"](cov, ns))
+            lo = o["davg"](mean)
+            assert same(lo, r["davg"](mean)) and same(o["interp"](lo, H, W), r["interp"](lo, H, W))
+            assert same(o["merge"](mean, lo), r["merge"](mean, lo))
+        assert all(same(x, y) for x, y in zip(o["spike"](mean, ns, hist, cov, 1.5), r["spike"](mean, ns, hist, cov, 1.5)))
+
+
+def test_core_regression_vectors():
+    f = load("core_regression.npz")
+    col, ns, hist, cov = f["col"], f["ns"], f["hist"], f["cov"]
+    for (l, c), want in zip(f["pts"], f["dist"]):
+        assert same(ol.window_distances(ns, hist, 1, 6, int(l), int(c)), want)
+    mask, cnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
+    assert np.array_equal(mask, f["mask"]) and np.array_equal(cnt, f["cnt"])
+    out, (proc, fb, nsim) = ol.denoise_mono(col, ns, hist, cov, ol.params(m=1.0), want_diag=True)
+    assert np.array_equal(proc, f["processed"]) and np.array_equal(fb, f["fallback"]) and np.array_equal(nsim, f["nsim"])
+    assert np.allclose(out, f["out_m1"], rtol=0, atol=1e-6)
+    assert np.allclose(ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0, threads=1)), f["out_m0"], rtol=0, atol=1e-6)
+    assert np.allclose(ol.denoise_multiscale(col, ns, hist, cov, 2, ol.params(m=1.0)), f["out_ms2"], rtol=0, atol=1e-6)
+
+
+def test_low_sample_count_nan_semantics():
+    """1 spp: every bin pair has b1+b2 <= 1 somewhere -> 0/0 distances, empty similar sets, NaN outputs that the
+    CLI later zeroes (src/cli/main.cpp:389-420)"""
+    f = load("core_lowspp.npz")
+    assert np.isnan(f["dist"]).any()
+    mask, cnt = ol.similarity_masks(f["ns"], f["hist"], 1, 6, 1.0)
+    assert np.array_equal(mask, f["mask"]) and np.array_equal(cnt, f["cnt"])
+    out = ol.denoise_mono(f["col"], f["ns"], f["hist"], f["cov"], ol.params(m=1.0))
+    assert np.array_equal(np.isnan(out), np.isnan(f["out_m1"]))
+    z = out.copy()
+    ol.oracle().bcdo_zero_bad_values(ol._fp(z), z.size)
+    assert np.isfinite(z).all() and (z >= 0).all()
+
+
+def test_distance_is_bitwise_symmetric():
+    col, ns, hist, cov, _ = ol.synth_inputs(20, 14, 4, 11, 0.4, 0.05)
+    import ctypes as C
+    lib = ol.oracle()
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        pl, ql = rng.integers(1, 13, 2)
+        pc, qc = rng.integers(1, 19, 2)
+        a = lib.bcdo_patch_distance(ol._fp(hist), ol._fp(ns), 20, 14, 60, 1, int(pl), int(pc), int(ql), int(qc))
+        b = lib.bcdo_patch_distance(ol._fp(hist), ol._fp(ns), 20, 14, 60, 1, int(ql), int(qc), int(pl), int(pc))
+        assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32) or (np.isnan(a) and np.isnan(b))
+
+
+def test_eigensolver_against_lapack():
+    rng = np.random.default_rng(3)
+    for n in (3, 27, 28, 75):
+        M = rng.standard_normal((n, n + 5)).astype(np.float32)
+        A = M @ M.T - 2.0 * np.eye(n, dtype=np.float32)
+        ev, V = ol.sym_eig(A)
+        ref = np.linalg.eigvalsh(A.astype(np.float64))
+        assert np.all(np.diff(ev) >= 0)
+        assert np.max(np.abs(ev - ref)) < 2e-5 * np.max(np.abs(ref))
+        assert np.max(np.abs(V @ np.diag(ev) @ V.T - A)) < 5e-5 * np.max(np.abs(A))
+        assert np.max(np.abs(V.T @ V - np.eye(n))) < 1e-5
+    # only the lower triangle is read (Eigen's SelfAdjointEigenSolver contract)
+    A2 = A.copy()
+    A2[np.triu_indices(n, 1)] = 123.0
+    assert np.array_equal(ol.sym_eig(A2)[0], ev)
+
+
+def test_denoiser_reduces_error_and_orders_matter():
+    col, ns, hist, cov, base = ol.synth_inputs(48, 32, 16, 5, 0.3, 0.0)
+    rmse = lambda a: float(np.sqrt(np.mean((a - base) ** 2)))
+    o0 = ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0, threads=2))
+    o1 = ol.denoise_mono(col, ns, hist, cov, ol.params(m=1.0))
+    assert rmse(o0) < 0.7 * rmse(col) and rmse(o1) < 0.7 * rmse(col)
+    # -m 0 is order/thread independent up to summation order (1.5e-6)
+    o0b = ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0, threads=1))
+    assert np.max(np.abs(o0 - o0b)) / np.max(np.abs(o0b)) < 1e-5
