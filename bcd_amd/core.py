@@ -80,3 +80,23 @@ def split_hist_ns(merged):
     ns = np.empty((H, W, 1), np.float32)
     rc = lib().bcdcore_split_hist_ns(_fp(merged), W, H, D1, _fp(hist), _fp(ns))
     return (hist, ns) if rc == 0 else None
+
+
+def write_exr(path, img, multi_channels):
+    H, W, D = img.shape
+    rc = lib().bcdcore_write_exr(path.encode(), _fp(np.ascontiguousarray(img, np.float32)), W, H, D, 1 if multi_channels else 0)
+    if rc != 0:
+        lib().bcdcore_exr_last_error.restype = C.c_char_p
+        raise IOError(lib().bcdcore_exr_last_error().decode())
+
+
+def read_exr(path, multi_channels):
+    W, H, D = C.c_int(), C.c_int(), C.c_int()
+    lib().bcdcore_exr_last_error.restype = C.c_char_p
+    if lib().bcdcore_read_exr(path.encode(), 1 if multi_channels else 0, C.byref(W), C.byref(H), C.byref(D), None, C.c_longlong(0)) != 0:
+        raise IOError(lib().bcdcore_exr_last_error().decode())
+    out = np.empty((H.value, W.value, D.value), np.float32)
+    rc = lib().bcdcore_read_exr(path.encode(), 1 if multi_channels else 0, C.byref(W), C.byref(H), C.byref(D), _fp(out), C.c_longlong(out.size))
+    if rc != 0:
+        raise IOError("read_exr rc=%d" % rc)
+    return out

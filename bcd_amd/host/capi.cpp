@@ -102,3 +102,33 @@ int bcdcore_split_hist_ns(const float* in, int W, int H, int Dp1, float* hist, f
 }
 
 } // extern "C"
+
+// ---- EXR (ImageIO) ------------------------------------------------------------------------------------------
+#include "ImageIO.h"
+
+extern "C" {
+
+int bcdcore_write_exr(const char* path, const float* data, int W, int H, int D, int multiChannels)
+{
+	Deepimf img(W, H, D);
+	img.copyDataFrom(data);
+	return (multiChannels ? ImageIO::writeMultiChannelsEXR(img, path) : ImageIO::writeEXR(img, path)) ? 0 : -1;
+}
+
+// two-call protocol: out == nullptr -> only the dimensions are returned
+int bcdcore_read_exr(const char* path, int multiChannels, int* W, int* H, int* D, float* out, long long capacity)
+{
+	Deepimf img;
+	if(!(multiChannels ? ImageIO::loadMultiChannelsEXR(img, path) : ImageIO::loadEXR(img, path))) return -1;
+	*W = img.getWidth(); *H = img.getHeight(); *D = img.getDepth();
+	if(out)
+	{
+		if(capacity < (long long)img.getSize()) return -2;
+		img.copyDataTo(out);
+	}
+	return 0;
+}
+
+const char* bcdcore_exr_last_error() { return ImageIO::lastError().c_str(); }
+
+} // extern "C"

@@ -332,3 +332,33 @@ def test_1080p_m1_default_run_is_sane(hipctx):
     base = np.stack([0.2 + 0.6 * c / W, 0.5 + 0.4 * np.sin(12.0 * l / H), np.where(((l // 16 + c // 16) % 2) > 0, 0.8, 0.15)], -1)
     rmse = lambda x: float(np.sqrt(np.mean((x - base) ** 2)))
     assert rmse(a) < 0.6 * rmse(col)
+
+
+def test_bcd_cli_end_to_end(hipctx, tmp_path):
+    """the reference's front-end contract: three EXR inputs (hist file carries nSamples as last channel), flags, half RGBA
+    output with negative/NaN/Inf zeroed; result == the engine's in-memory result rounded to half"""
+    import subprocess
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H = 72, 56
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 21, 0.15, 0.02)
+    stem = str(tmp_path / "frame")
+    core.write_exr(stem + ".exr", col, False)
+    core.write_exr(stem + "_hist.exr", core.merge_hist_ns(hist, ns), True)
+    core.write_exr(stem + "_cov.exr", cov, True)
+    exe = _os.path.join(_os.path.dirname(core.LIB_PATH), "bcd_cli")
+    # colours go through half precision on disk, like the reference's own pipeline (raw2bcd writes half RGBA)
+    col_h = core.read_exr(stem + ".exr", False)
+    for p_flag in (0, 1):
+        out_path = str(tmp_path / ("out%d.exr" % p_flag))
+        r = subprocess.run([exe, "-i", stem + ".exr", "-o", out_path, "-p", str(p_flag), "-s", "2", "-b", "4", "-m", "0", "--seed", "5"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "assuming '" + stem + "_hist.exr'" in r.stdout            # -h / -c inferred from -i (main.cpp:344-370)
+        got = core.read_exr(out_path, False)
+        d = dev(col_h, ns, hist, cov)
+        if p_flag:
+            d = hipctx.spike_filter(*d, 2.0)
+        want = hipctx.denoise(*d, 2, bh.default_params(b=4, m=0.0, seed=5))
+        want = hipctx.zero_bad_values(want).cpu().numpy()
+        assert np.max(np.abs(got - want.astype(np.float16).astype(np.float32))) <= 2e-3 * np.max(want)
