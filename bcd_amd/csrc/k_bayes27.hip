@@ -41,96 +41,132 @@ __device__ inline int noise_idx(int i, int j)
     return i == j ? i : (i + j == 1 ? 5 : (i + j == 2 ? 4 : 3));
 }
 
-// ---- parallel (round-robin) two-sided Jacobi; A -> ~diag(lambda), V <- eigenvectors (columns) ----------
-__device__ void jacobi27(float *A, float *V, float *rc, float *rs, int *rp, int *rq, int lane)
+// ---- parallel two-sided Jacobi, Brent-Luk ordering, rows held in registers ------------------------------
+// Slots 0..27 (27 = zero padding) are paired (2i, 2i+1).  One round: lanes i < 14 compute the rotation of pair i from
+// LDS; then every lane loads ONE row (lanes 0..27: rows of A, lanes 32..58: rows of V) as 7 x ds_read_b128, applies the
+// 14 column-pair rotations on registers with static indices, lane pairs (2i, 2i+1) exchange their rows with a DPP
+// quad_perm (row rotation of A), and the result is written to the other (ping-pong) buffer at its Brent-Luk permuted
+// position: slot s moves to sigma(s), 0->0, 1->2, 2i->2i+2, 26->27, 2i+1->2i-1.  After 27 rounds every pair of slots
+// has met once (one sweep).  Eigenvalues = diagonal of A (in slot order), eigenvectors = columns of V (same order):
+// V f(diag) V^T needs no bookkeeping of the permutation.  Matrices here use a leading dimension of 28 floats.
+constexpr int JLD = 28;
+
+__device__ inline float dpp_xor1(float v)
 {
-    for (int e = lane; e < K * K; e += 64) {
-        int r = e / K, c = e - r * K;
-        V[r * LD + c] = (r == c) ? 1.f : 0.f;
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
+}
+
+__device__ inline int sigma_slot(int s)
+{
+    return s == 0 ? 0 : (s == 1 ? 2 : (s == 26 ? 27 : ((s & 1) ? s - 2 : s + 2)));
+}
+
+// A0 holds the symmetric input (JLD layout, row/col 27 zero); returns 0/1: index of the buffer pair holding the result
+__device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, int lane)
+{
+    for (int e = lane; e < K * JLD; e += 64) {
+        int r = e / JLD, c = e - r * JLD;
+        V0[e] = (r == c) ? 1.f : 0.f;
     }
     __syncthreads();
-    constexpr int N1 = KP - 1, NP = KP / 2;
+    const bool isA = lane < KP, isV = lane >= 32 && lane < 32 + K;
+    const int vrow = lane - 32;
+    int cur = 0;
     for (int sweep = 0; sweep < 12; ++sweep) {
+        float *A = cur ? A1 : A0;
         float off = 0.f, dg = 0.f;
-        for (int e = lane; e < K * K; e += 64) {
-            int r = e / K, c = e - r * K;
-            float v = A[r * LD + c];
+        for (int e = lane; e < KP * JLD; e += 64) {
+            int r = e / JLD, c = e - r * JLD;
+            float v = A[e];
             if (r == c) dg = fmaf(v, v, dg); else off = fmaf(v, v, off);
         }
         off = wsum(off);
         dg = wsum(dg);
+        if (blockIdx.x == 100 && lane == 0) { bcd_dbg_cycles[12] = sweep; reinterpret_cast<float *>(bcd_dbg_cycles + 13)[sweep < 6 ? sweep : 5] = off / dg; }
         if (off <= 1e-13f * dg) break;
-        for (int round = 0; round < N1; ++round) {
-            if (lane < NP) {
-                int a = (lane == 0) ? N1 : (round + lane) % N1;
-                int bb = (lane == 0) ? round : (round - lane + N1) % N1;
-                int p = min(a, bb), q = max(a, bb);
-                float c = 1.f, s = 0.f;
-                if (q < K) {
-                    float apq = A[p * LD + q];
-                    if (apq != 0.f) {
-                        float app = A[p * LD + p], aqq = A[q * LD + q];
-                        float theta = (aqq - app) / (2.f * apq);
-                        float t = 1.f / (fabsf(theta) + sqrtf(fmaf(theta, theta, 1.f)));
-                        t = theta < 0.f ? -t : t;
-                        c = 1.f / sqrtf(fmaf(t, t, 1.f));
-                        s = t * c;
-                    }
-                } else { p = 0; q = 0; }
-                rc[lane] = c; rs[lane] = s; rp[lane] = p; rq[lane] = q;
+        for (int round = 0; round < KP - 1; ++round) {
+            float *Ac = cur ? A1 : A0, *An = cur ? A0 : A1, *Vc = cur ? V1 : V0, *Vn = cur ? V0 : V1;
+            if (lane < KP / 2) {
+                int p = 2 * lane, q = p + 1;
+                float apq = Ac[p * JLD + q], c = 1.f, s = 0.f;
+                float app = Ac[p * JLD + p], aqq = Ac[q * JLD + q];
+                if (apq != 0.f) {
+                    // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working
+                    // precision (c^2 + s^2 = 1 +- 1e-7), not the exact minimiser
+                    float theta = (aqq - app) * __builtin_amdgcn_rcpf(2.f * apq);
+                    float t = __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.f)));
+                    t = theta < 0.f ? -t : t;
+                    c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
+                    s = t * c;
+                    if (!(fabsf(theta) < 1e18f)) { c = 1.f; s = 0.f; } // theta^2 overflows: the rotation is the identity to fp32
+                }
+                cs[2 * lane] = c; cs[2 * lane + 1] = s;
             }
             __syncthreads();
+            const float *src = isA ? Ac + lane * JLD : (isV ? Vc + vrow * JLD : Ac);
+            float row[JLD], rot[JLD];
 #pragma unroll
-            for (int it = 0; it < (NP * K + 63) / 64; ++it) { // A <- A J, V <- V J
-                int t = lane + it * 64;
-                if (t < NP * K) {
-                    int k = t / K, row = t - k * K;
-                    float c = rc[k], s = rs[k];
-                    int p = rp[k], q = rq[k];
-                    float ap = A[row * LD + p], aq = A[row * LD + q];
-                    float vp = V[row * LD + p], vq = V[row * LD + q];
-                    if (s != 0.f) {
-                        A[row * LD + p] = fmaf(c, ap, -s * aq);
-                        A[row * LD + q] = fmaf(s, ap, c * aq);
-                        V[row * LD + p] = fmaf(c, vp, -s * vq);
-                        V[row * LD + q] = fmaf(s, vp, c * vq);
-                    }
-                }
+            for (int q4 = 0; q4 < JLD / 4; ++q4) {
+                float4 v = reinterpret_cast<const float4 *>(src)[q4];
+                float4 w = reinterpret_cast<const float4 *>(cs)[q4];
+                row[4 * q4] = v.x; row[4 * q4 + 1] = v.y; row[4 * q4 + 2] = v.z; row[4 * q4 + 3] = v.w;
+                rot[4 * q4] = w.x; rot[4 * q4 + 1] = w.y; rot[4 * q4 + 2] = w.z; rot[4 * q4 + 3] = w.w;
             }
-            __syncthreads();
+            // column rotations: (x, y) <- (c x - s y, s x + c y) for every slot pair
 #pragma unroll
-            for (int it = 0; it < (NP * K + 63) / 64; ++it) { // A <- J^T A
-                int t = lane + it * 64;
-                if (t < NP * K) {
-                    int k = t / K, col = t - k * K;
-                    float c = rc[k], s = rs[k];
-                    int p = rp[k], q = rq[k];
-                    float ap = A[p * LD + col], aq = A[q * LD + col];
-                    if (s != 0.f) {
-                        A[p * LD + col] = fmaf(c, ap, -s * aq);
-                        A[q * LD + col] = fmaf(s, ap, c * aq);
-                    }
-                }
+            for (int j = 0; j < KP / 2; ++j) {
+                float c = rot[2 * j], s = rot[2 * j + 1], x = row[2 * j], y = row[2 * j + 1];
+                row[2 * j] = fmaf(c, x, -s * y);
+                row[2 * j + 1] = fmaf(s, x, c * y);
             }
+            // row rotations of A: rows (2i, 2i+1) live in lanes (2i, 2i+1)
+            const float2 mine = reinterpret_cast<const float2 *>(cs)[isA ? (lane >> 1) : 0];
+            const float sg = (lane & 1) ? mine.y : -mine.y;
+            float out[JLD];
+#pragma unroll
+            for (int k = 0; k < JLD; ++k) {
+                float partner = dpp_xor1(row[k]);
+                float v = isA ? fmaf(mine.x, row[k], sg * partner) : row[k];
+                out[sigma_slot(k)] = v;          // Brent-Luk column move (static register renaming)
+            }
+            float *dst = isA ? An + sigma_slot(lane) * JLD : Vn + vrow * JLD;
+            if (isA || isV) {
+#pragma unroll
+                for (int q4 = 0; q4 < JLD / 4; ++q4)
+                    reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
+            }
+            cur ^= 1;
             __syncthreads();
         }
     }
+    return cur;
 }
 
-// out = V f(lambda) V^T ; f = max(0,.) (clamp) or 1/max(minEig,.) (inverse)
+// out (LD layout) = V f(lambda) V^T ; f = max(0,.) (clamp) or 1/max(minEig,.) (inverse); A, V in the Jacobi (JLD) layout
 __device__ void rebuild27(float *out, const float *A, const float *V, float *fl, int lane, bool inverse, float min_eig)
 {
-    if (lane < K) {
-        float lam = A[lane * LD + lane];
+    if (lane < KP) {
+        float lam = A[lane * JLD + lane];
         fl[lane] = inverse ? 1.f / fmaxf(min_eig, lam) : fmaxf(0.f, lam);
     }
     __syncthreads();
     for (int e = lane; e < K * K; e += 64) {
         int r = e / K, c = e - r * K;
         float s = 0.f;
-#pragma unroll 9
-        for (int k = 0; k < K; ++k) s = fmaf(V[r * LD + k], fl[k] * V[c * LD + k], s);
+#pragma unroll 7
+        for (int k = 0; k < KP; ++k) s = fmaf(V[r * JLD + k], fl[k] * V[c * JLD + k], s);
         out[r * LD + c] = s;
+    }
+    __syncthreads();
+}
+
+// JLD-layout copy of the lower triangle of M (LD layout), mirrored, padding row/column zeroed (what Eigen's
+// SelfAdjointEigenSolver reads)
+__device__ void to_jacobi_layout(float *J, const float *M, int lane)
+{
+    for (int e = lane; e < KP * JLD; e += 64) {
+        int r = e / JLD, c = e - r * JLD;
+        J[e] = (r < K && c < K) ? M[(r >= c ? r : c) * LD + (r >= c ? c : r)] : 0.f;
     }
     __syncthreads();
 }
@@ -144,61 +180,58 @@ __device__ void add_noise27(float *M, const float *noise, int lane, float sign)
     __syncthreads();
 }
 
-// in-place inverse of the symmetric positive definite M by the sweep operator.  Returns false (wave-uniform) if a
-// pivot is not positive or the bound ||M^-1||_F * min_eig <= 1 fails (then lambda_min >= min_eig is not proven).
+// in-place inverse of the symmetric positive definite M (LD layout) by the sweep operator, rows held in registers:
+// lane r owns row r; at step k the pivot row is broadcast with v_readlane (k is a compile-time constant), so the 27
+// steps need no LDS traffic and no barrier.  Returns false (wave-uniform) if a pivot is not positive or the bound
+// ||M^-1||_F * min_eig <= 1 fails (then lambda_min >= min_eig is not proven); M is then unspecified.
+__device__ inline float bcast_lane(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
 __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
 {
-    constexpr int NE = (K * K + 63) / 64;
+    const int r = lane < K ? lane : 0;
+    float m[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) m[c] = M[r * LD + c];
     bool ok = true;
+#pragma unroll
     for (int k = 0; k < K; ++k) {
-        float d = M[k * LD + k];
-        if (!(d > 0.f)) { ok = false; break; } // uniform: every lane reads the same element
-        float inv_d = 1.f / d;
-        float nv[NE];
+        const float d = bcast_lane(m[k], k);
+        ok = ok && (d > 0.f);
+        const float inv_d = 1.f / d;
+        const bool pivot_row = (lane == k);
+        const float f = m[k] * inv_d; // a_rk / d
 #pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            int e = lane + it * 64;
-            float v = 0.f;
-            if (e < K * K) {
-                int r = e / K, c = e - r * K;
-                float mrk = M[r * LD + k], mkc = M[k * LD + c], mrc = M[r * LD + c];
-                if (r == k && c == k) v = -inv_d;
-                else if (r == k) v = mkc * inv_d;
-                else if (c == k) v = mrk * inv_d;
-                else v = fmaf(-mrk * inv_d, mkc, mrc);
-            }
-            nv[it] = v;
+        for (int c = 0; c < K; ++c) {
+            if (c == k) continue;
+            const float pkc = bcast_lane(m[c], k); // a_kc (old)
+            m[c] = pivot_row ? pkc * inv_d : fmaf(-f, pkc, m[c]);
         }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            int e = lane + it * 64;
-            if (e < K * K) { int r = e / K, c = e - r * K; M[r * LD + c] = nv[it]; }
-        }
-        __syncthreads();
+        m[k] = pivot_row ? -inv_d : f;
     }
-    if (!ok) return false;
     float fro = 0.f;
-    for (int e = lane; e < K * K; e += 64) {
-        int r = e / K, c = e - r * K;
-        float v = -M[r * LD + c];
-        M[r * LD + c] = v;
-        fro = fmaf(v, v, fro);
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        m[c] = -m[c];
+        fro = fmaf(m[c], m[c], fro);
     }
+    if (lane >= K) fro = 0.f;
     fro = wsum(fro);
     __syncthreads();
-    return sqrtf(fro) * min_eig <= 1.f && isfinite(fro);
+    if (lane < K) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) M[r * LD + c] = m[c];
+    }
+    __syncthreads();
+    return ok && isfinite(fro) && sqrtf(fro) * min_eig <= 1.f;
 }
 
-// M <- inverseSymmetricMatrix(M) (DenoisingUnit.cpp:578-604), in place.  scratch: A (backup / Jacobi), V
-__device__ void inverse27(float *M, float *A, float *V, float *fl, float *rc, float *rs, int *rp, int *rq, int lane, float min_eig)
+// M <- inverseSymmetricMatrix(M) (DenoisingUnit.cpp:578-604), in place.  scratch: S0..S3 (each >= KP*JLD floats), cs
+__device__ void inverse27(float *M, float *S0, float *S1, float *S2, float *S3, float *fl, float *cs, int lane, float min_eig)
 {
-    // backup: lower triangle mirrored, like Eigen's SelfAdjointEigenSolver reads it
-    for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; A[r * LD + c] = M[(r >= c ? r : c) * LD + (r >= c ? c : r)]; }
-    __syncthreads();
+    to_jacobi_layout(S0, M, lane); // backup for the spectral path, taken before the sweep destroys M
     if (sweep_inverse27(M, lane, min_eig)) return;
-    jacobi27(A, V, rc, rs, rp, rq, lane);
-    rebuild27(M, A, V, fl, lane, true, min_eig);
+    int w = jacobi27(S0, S1, S2, S3, cs, lane);
+    rebuild27(M, w ? S1 : S0, w ? S3 : S2, fl, lane, true, min_eig);
 }
 
 // out[3o+i][c] = delta*(r==c) - sign * sum_j N_o[i][j] * in[3o+j][c]   (block-diagonal noise covariance times a dense matrix)
@@ -269,13 +302,13 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
     float *A = lds, *V = A + MSZ, *Cm = V + MSZ, *Bm = Cm + MSZ;
-    float *chunk = Bm + MSZ;
-    float *noise = chunk + CHUNK * K;
+    float *X2 = Bm + MSZ;                      // fifth matrix-sized scratch (Jacobi ping-pong)
+    float *chunk = X2 + MSZ;
+    float *cs = chunk + CHUNK * K;             // 28 floats read as float4: every offset so far is a multiple of 16 bytes
+    float *noise = cs + KP;
     float *mean = noise + P * 6;
     float *fl = mean + K + 1;
-    float *rc = fl + KP, *rs = rc + KP / 2;
-    int *rp = reinterpret_cast<int *>(rs + KP / 2), *rq = rp + KP / 2;
-    int *mem = rq + KP / 2;
+    int *mem = reinterpret_cast<int *>(fl + KP);
 
     DBG_T(0);
     const int p = list[blockIdx.x];
@@ -343,12 +376,20 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     // ---- Step 1 (:421-436): M1 = clamp(C - N) + N ; Cinv1 = inverse(M1)
     DBG_T(4);
     add_noise27(A, noise, lane, -1.f);
-    jacobi27(A, V, rc, rs, rp, rq, lane);
-    DBG_T(5);
-    rebuild27(Bm, A, V, fl, lane, false, 0.f);
+    to_jacobi_layout(Bm, A, lane);
+    {
+        int w = jacobi27(Bm, A, V, X2, cs, lane);   // ping-pong pairs (Bm, V) <-> (A, X2)
+        DBG_T(5);
+        float *EA = w ? A : Bm, *EV = w ? X2 : V, *OUT = w ? Bm : A;
+        rebuild27(OUT, EA, EV, fl, lane, false, 0.f);
+        if (OUT != Bm) { // keep the convention "M1 lives in Bm"
+            for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; Bm[r * LD + c] = OUT[r * LD + c]; }
+            __syncthreads();
+        }
+    }
     add_noise27(Bm, noise, lane, +1.f);
     DBG_T(6);
-    inverse27(Bm, A, V, fl, rc, rs, rp, rq, lane, min_eig);
+    inverse27(Bm, A, V, X2, chunk, fl, cs, lane, min_eig);
     DBG_T(7);
     // ---- Step 2 (:438-453): the Step-1 estimates are xhat = x - G (x - m) with G = N Cinv1, hence their empirical
     // mean is m and their empirical covariance is F C F^T, F = I - G
@@ -364,7 +405,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     __syncthreads();
     add_noise27(Bm, noise, lane, +1.f);
     DBG_T(8);
-    inverse27(Bm, A, V, fl, rc, rs, rp, rq, lane, min_eig);
+    inverse27(Bm, A, V, X2, chunk, fl, cs, lane, min_eig);
     noise_times27(Cm, noise, Bm, lane, false);
     DBG_T(9);     // Cm = G2 = N Cinv2
 
@@ -399,7 +440,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 size_t bcd_bayes27_lds_bytes(int b)
 {
     int side = 2 * b + 1;
-    return (size_t)(4 * MSZ + CHUNK * K + P * 6 + (K + 1) + KP + 4 * (KP / 2) + side * side) * sizeof(float);
+    return (size_t)(5 * MSZ + CHUNK * K + P * 6 + (K + 1) + KP + KP + side * side) * sizeof(float);
 }
 
 hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int nlist,
@@ -414,6 +455,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         long long h[16];
         hipStreamSynchronize(st);
         hipMemcpyFromSymbol(h, HIP_SYMBOL(bcd_dbg_cycles), sizeof(h));
+        { float *fr = reinterpret_cast<float *>(h + 13); fprintf(stderr, "sweeps %lld ratios %g %g %g %g %g %g\n", h[12], fr[0], fr[1], fr[2], fr[3], fr[4], fr[5]); }
         fprintf(stderr, "bayes27 dbg n=%lld: decode %lld noise %lld mean %lld cov %lld jacobi %lld rebuild %lld inv1 %lld step2mm %lld inv2 %lld final %lld total %lld\n", h[11], h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5], h[7]-h[6], h[8]-h[7], h[9]-h[8], h[10]-h[9], h[10]-h[0]);
         return hipGetLastError();
     }

@@ -77,32 +77,58 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
         __syncthreads();
 
         const int dc0 = (dl == 0) ? 0 : -b;
-        for (int dc = dc0; dc <= b; ++dc, ++didx) {
-            const int lp = ty * ncols + tx + dc + b;
-            const float4 *nb = lds4 + lp * (DS / 4);
-            const float n2 = lds_n[lp];
+        // neighbour histograms are double-buffered in registers: the 15 ds_read_b128 of displacement dc+1 are in
+        // flight while displacement dc is evaluated
+        float4 bufA[Q], bufB[Q];
+        auto fetch = [&](float4 *buf, int dc) {
+            const float4 *nb = lds4 + (ty * ncols + tx + dc + b) * (DS / 4);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) buf[q] = nb[q];
+        };
+        auto evaluate = [&](const float4 *buf, int dc, int di) {
+            const float n2 = lds_n[ty * ncols + tx + dc + b];
             const float n12 = n1 * n2;
             float sum = 0.f;
             int cnt = 0;
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                float4 v = nb[q];
-                float b2[4] = { v.x, v.y, v.z, v.w };
+                const float b2[4] = { buf[q].x, buf[q].y, buf[q].z, buf[q].w };
+                float s[4];
+                bool use[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float b1 = h1[4 * q + j];
-                    float s = b1 + b2[j];
-                    float diff = n2 * b1 - n1 * b2[j];
-                    float t = diff * diff / (n12 * s);
-                    bool use = s > 1.f; // reference skips bins with b1 + b2 <= 1 (DenoisingUnit.cpp:379)
-                    sum = use ? sum + t : sum;
-                    cnt += use ? 1 : 0;
+                    s[j] = h1[4 * q + j] + b2[j];
+                    use[j] = s[j] > 1.f; // reference skips bins with b1 + b2 <= 1 (DenoisingUnit.cpp:379)
+                }
+                // wave-uniform skip of a group of 4 bins that is empty for all 64 pixels of the tile row (exact:
+                // skipped bins contribute nothing); inside an active group the 4 divisions are independent
+                if (__builtin_amdgcn_ballot_w64(use[0] || use[1] || use[2] || use[3]) != 0) {
+                    float t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float diff = n2 * h1[4 * q + j] - n1 * b2[j];
+                        t[j] = diff * diff / (n12 * s[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { // bins in order: the reference's sequential sum
+                        sum = use[j] ? sum + t[j] : sum;
+                        cnt += use[j] ? 1 : 0;
+                    }
                 }
             }
             const int nc = c + dc, nr = r + dl;
             if (inside && nc >= 0 && nc < W && nr < H) {
-                T[(size_t)didx * plane + pix] = sum;
-                Cn[(size_t)didx * plane + pix] = (uint8_t)cnt;
+                T[(size_t)di * plane + pix] = sum;
+                Cn[(size_t)di * plane + pix] = (uint8_t)cnt;
+            }
+        };
+        fetch(bufA, dc0);
+        for (int dc = dc0; dc <= b; dc += 2) {
+            if (dc + 1 <= b) fetch(bufB, dc + 1);
+            evaluate(bufA, dc, didx++);
+            if (dc + 1 <= b) {
+                if (dc + 2 <= b) fetch(bufA, dc + 2);
+                evaluate(bufB, dc + 1, didx++);
             }
         }
     }
