@@ -15,7 +15,7 @@
 // launchers implemented in the k_*.hip files
 size_t bcd_pairdist_lds_bytes(int D, int b);
 hipError_t bcd_launch_pairdist(const float *, const float *, int, int, int, int, float *, uint8_t *, hipStream_t);
-hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, hipStream_t);
+hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t);
 hipError_t bcd_launch_window_distances(const float *, const uint8_t *, int, int, int, int, int, int, float *, hipStream_t);
 hipError_t bcd_launch_pixel_cov(const float *, const float *, int64_t, float *, hipStream_t);
 hipError_t bcd_launch_finalize(const float *, const int32_t *, int64_t, float *, hipStream_t);
@@ -27,6 +27,7 @@ hipError_t bcd_launch_spike(const float *, const float *, const float *, const f
                             float *, float *, hipStream_t);
 hipError_t bcd_launch_active_init(const int32_t *, int, int, int, int, int, float, uint32_t, uint8_t *, hipStream_t);
 hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int *, hipStream_t);
+hipError_t bcd_launch_active_tile(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int *, hipStream_t);
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t bcd_bayes_lds_bytes(int w, int b);
 hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, int, int, int, int, int, float,
@@ -55,7 +56,7 @@ struct bcd_hip_ctx {
     std::string err;
     bcd_hip_scale_stats stats[MAX_SCALES];
     // grow-only workspace
-    DevBuf T, Cn, mask, nsim, state, strong, weak, counters, pixcov, sum, cnt, tmp_lo;
+    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, tmp_lo;
     DevBuf pyr[MAX_SCALES][5]; // colours, nsamples, hist, cov, out
     int32_t *h_counters = nullptr; // pinned
     // pair-distance kernel timing
@@ -122,6 +123,7 @@ int similarity(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, 
     const int nd = bcd_delta_count(b);
     RCCHK(ensure(ctx, ctx->T, npix * nd * sizeof(float)));
     RCCHK(ensure(ctx, ctx->Cn, npix * nd));
+    RCCHK(ensure(ctx, ctx->fwd, npix * ((nd + 31) / 32) * sizeof(uint32_t)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->ev_used < MAX_EVENT_PAIRS) {
         if (ctx->ev_used == (int)ctx->ev_pool.size()) {
@@ -137,7 +139,7 @@ int similarity(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, 
     }
     HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, ctx->stream));
     if (e1) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
-    HIPCHK(ctx, bcd_launch_masks((const float *)ctx->T.p, (const uint8_t *)ctx->Cn.p, W, H, w, b, tau, d_mask, d_count, ctx->stream));
+    HIPCHK(ctx, bcd_launch_masks((const float *)ctx->T.p, (const uint8_t *)ctx->Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)ctx->fwd.p, ctx->stream));
     return BCD_HIP_OK;
 }
 
@@ -152,13 +154,20 @@ int active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_nsim, 
         int *d_cnt = (int *)ctx->counters.p;
         const int max_rounds = 4 * (W + H) + 64;
         bool done = false;
+        const int side = 2 * b + 1, words = (side * side + 31) / 32;
+        const bool tiled = (words == 6 || words == 20);
+        const int batch = tiled ? 2 : ROUND_BATCH;
         while (!done && rounds < max_rounds) {
             HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), ctx->stream));
-            for (int i = 0; i < ROUND_BATCH; ++i)
-                HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, d_cnt + i, ctx->stream));
+            for (int i = 0; i < batch; ++i) {
+                if (tiled)
+                    HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, 16, d_cnt + i, ctx->stream));
+                else
+                    HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, d_cnt + i, ctx->stream));
+            }
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            for (int i = 0; i < ROUND_BATCH; ++i) {
+            for (int i = 0; i < batch; ++i) {
                 ++rounds;
                 if (ctx->h_counters[i] == 0) { done = true; break; }
             }
@@ -305,7 +314,7 @@ void bcd_hip_ctx_destroy(bcd_hip_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = { &ctx->T, &ctx->Cn, &ctx->mask, &ctx->nsim, &ctx->state, &ctx->strong, &ctx->weak, &ctx->counters,
+    DevBuf *bufs[] = { &ctx->T, &ctx->Cn, &ctx->mask, &ctx->fwd, &ctx->nsim, &ctx->state, &ctx->strong, &ctx->weak, &ctx->counters,
                        &ctx->pixcov, &ctx->sum, &ctx->cnt, &ctx->tmp_lo };
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (int s = 0; s < MAX_SCALES; ++s)

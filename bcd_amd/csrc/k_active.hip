@@ -65,32 +65,102 @@ __global__ __launch_bounds__(256) void k_active_round(const uint32_t *__restrict
     if (bal && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)bal) - 1)) atomicAdd(undecided, __popcll(bal));
 }
 
-// compact lists of processed pixels: strong (full Bayesian path) and weak (fallback path)
-__global__ __launch_bounds__(256) void k_active_lists(const uint8_t *__restrict__ state, const int32_t *__restrict__ nsim,
-                                                      int64_t npix, int min_strong,
-                                                      int32_t *__restrict__ strong_list, int32_t *__restrict__ weak_list,
-                                                      int32_t *__restrict__ counters /* [0]=strong [1]=weak, [2..3] sum |S| (lo,hi) */)
+// Tile-iterated round: a 16x16 tile of pixels per workgroup.  On entry every undecided pixel extracts its dependency
+// bits (similar AND visited earlier AND strong) into registers; the tile then iterates in place -- updates made by the
+// same workgroup are visible through the CU's write-through L1 (volatile loads), updates of other workgroups may be
+// seen late, which only delays a decision (the iteration is monotone and its fixed point unique).  One launch
+// resolves every dependency chain that stays inside a tile, so a frame needs 2-3 launches instead of one per level.
+template <int WORDS>
+__global__ __launch_bounds__(256) void k_active_tile(const uint32_t *__restrict__ mask, const int32_t *__restrict__ nsim,
+                                                     uint8_t *state, int W, int H, int b, int min_strong, int random_order,
+                                                     uint32_t seed, int inner_iters, int *__restrict__ undecided)
 {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int side = 2 * b + 1;
+    volatile uint8_t *vstate = state;
+    const bool inside = c < W && r < H;
+    const size_t p = inside ? (size_t)r * W + c : 0;
+    bool pending = inside && state[p] == BCD_ST_UNDECIDED;
+    uint32_t dep[WORDS];
+    if (pending) {
+        const uint64_t keyp = bcd_order_key((uint32_t)p, random_order, seed);
+#pragma unroll
+        for (int j = 0; j < WORDS; ++j) {
+            uint32_t m = mask[p * WORDS + j], keep = 0;
+            while (m) {
+                int bit = __ffs(m) - 1;
+                m &= m - 1;
+                int k = j * 32 + bit;
+                int dl = k / side - b, dc = k - (k / side) * side - b;
+                size_t q = (size_t)(r + dl) * W + (c + dc);
+                if (q == p) continue;
+                if (nsim[q] < min_strong) continue;                                  // fallback pixels mark nobody
+                if (bcd_order_key((uint32_t)q, random_order, seed) > keyp) continue; // visited later
+                keep |= 1u << bit;
+            }
+            dep[j] = keep;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < WORDS; ++j) dep[j] = 0;
+    }
+    for (int it = 0; it < inner_iters; ++it) {
+        bool changed = false;
+        if (pending) {
+            bool any_in = false, wait = false;
+#pragma unroll
+            for (int j = 0; j < WORDS; ++j) {
+                uint32_t m = dep[j];
+                while (m && !any_in) {
+                    int bit = __ffs(m) - 1;
+                    m &= m - 1;
+                    int k = j * 32 + bit;
+                    int dl = k / side - b, dc = k - (k / side) * side - b;
+                    uint8_t sq = vstate[(size_t)(r + dl) * W + (c + dc)];
+                    if (sq == BCD_ST_IN) any_in = true;
+                    else if (sq == BCD_ST_UNDECIDED) wait = true;
+                    else dep[j] &= ~(1u << bit); // decided and not processed: can never mark p
+                }
+            }
+            if (any_in) { state[p] = BCD_ST_OUT; pending = false; changed = true; }
+            else if (!wait) { state[p] = BCD_ST_IN; pending = false; changed = true; }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    int left = __syncthreads_count(pending);
+    if (threadIdx.x == 0 && left) atomicAdd(undecided, left);
+}
+
+// compact lists of processed pixels: strong (full Bayesian path) and weak (fallback path); one atomic per counter
+// per workgroup, wavefront offsets through LDS
+__global__ __launch_bounds__(1024) void k_active_lists(const uint8_t *__restrict__ state, const int32_t *__restrict__ nsim,
+                                                       int64_t npix, int min_strong,
+                                                       int32_t *__restrict__ strong_list, int32_t *__restrict__ weak_list,
+                                                       int32_t *__restrict__ counters /* [0]=strong [1]=weak, [2..3] sum |S| (64-bit) */)
+{
+    __shared__ int ws[16], ww[16], wt[16], base[2];
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool in = p < npix && state[p] == BCD_ST_IN;
     int n = in ? nsim[p] : 0;
     bool strong = in && n >= min_strong, weak = in && n < min_strong;
     unsigned long long bs = __ballot(strong), bw = __ballot(weak);
-    int lane = threadIdx.x & 63;
-    unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    int base_s = 0, base_w = 0;
-    if (lane == 0) {
-        if (bs) base_s = atomicAdd(&counters[0], __popcll(bs));
-        if (bw) base_w = atomicAdd(&counters[1], __popcll(bw));
-    }
-    base_s = __shfl(base_s, 0);
-    base_w = __shfl(base_w, 0);
-    if (strong) strong_list[base_s + __popcll(bs & lower)] = (int32_t)p;
-    if (weak) weak_list[base_w + __popcll(bw & lower)] = (int32_t)p;
-    // statistics: sum of |S| over processed pixels
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int tot = n;
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-    if (lane == 0 && tot) atomicAdd(reinterpret_cast<unsigned long long *>(&counters[2]), (unsigned long long)tot);
+    if (lane == 0) { ws[wave] = __popcll(bs); ww[wave] = __popcll(bw); wt[wave] = tot; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0, w = 0;
+        long long t = 0;
+        for (int i = 0; i < 16; ++i) { int a = ws[i], bq = ww[i]; ws[i] = s; ww[i] = w; s += a; w += bq; t += wt[i]; }
+        base[0] = s ? atomicAdd(&counters[0], s) : 0;
+        base[1] = w ? atomicAdd(&counters[1], w) : 0;
+        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(&counters[2]), (unsigned long long)t);
+    }
+    __syncthreads();
+    unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (strong) strong_list[base[0] + ws[wave] + __popcll(bs & lower)] = (int32_t)p;
+    if (weak) weak_list[base[1] + ww[wave] + __popcll(bw & lower)] = (int32_t)p;
 }
 
 } // namespace
@@ -114,7 +184,21 @@ hipError_t bcd_launch_active_round(const uint32_t *mask, const int32_t *nsim, ui
 hipError_t bcd_launch_active_lists(const uint8_t *state, const int32_t *nsim, int64_t npix, int min_strong,
                                    int32_t *strong_list, int32_t *weak_list, int32_t *counters, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_active_lists, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, state, nsim, npix, min_strong,
+    hipLaunchKernelGGL(k_active_lists, dim3((unsigned)((npix + 1023) / 1024)), dim3(1024), 0, st, state, nsim, npix, min_strong,
                        strong_list, weak_list, counters);
+    return hipGetLastError();
+}
+
+hipError_t bcd_launch_active_tile(const uint32_t *mask, const int32_t *nsim, uint8_t *state, int W, int H, int b,
+                                  int min_strong, int random_order, uint32_t seed, int inner_iters, int *undecided, hipStream_t st)
+{
+    int side = 2 * b + 1, words = (side * side + 31) / 32;
+    dim3 grid((W + 15) / 16, (H + 15) / 16), block(256);
+    if (words == 6)
+        hipLaunchKernelGGL(k_active_tile<6>, grid, block, 0, st, mask, nsim, state, W, H, b, min_strong, random_order, seed, inner_iters, undecided);
+    else if (words == 20)
+        hipLaunchKernelGGL(k_active_tile<20>, grid, block, 0, st, mask, nsim, state, W, H, b, min_strong, random_order, seed, inner_iters, undecided);
+    else
+        return hipErrorNotSupported;
     return hipGetLastError();
 }

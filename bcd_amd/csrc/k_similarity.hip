@@ -209,6 +209,88 @@ __global__ __launch_bounds__(256) void k_masks(const float *__restrict__ T, cons
     mask[pix * words + word] = m;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// kernel 2 (w = 1): forward similarity bits.  One wavefront covers 62 consecutive pixels of a line (lanes 0 and 63
+// only feed their neighbours); per displacement plane every lane loads T and C of its own column on the three patch
+// lines and obtains the left / right columns from the adjacent lanes, so a 3x3 box sum costs 3 loads instead of 9.
+// The nine values are added in the reference's patch order (row-major), the counts as integers, then one IEEE
+// division and the <= tau test (DenoisingUnit.cpp:336-358, 209).  Output: ceil(ndelta/32) words per pixel, bit i =
+// similar(p, p + delta_i) for the half-plane displacements; 0 when p or p + delta is not a main pixel.
+// ---------------------------------------------------------------------------------------------------
+__device__ inline float lane_up(float v)   { return __shfl_up(v, 1); }   // value of lane - 1
+__device__ inline float lane_down(float v) { return __shfl_down(v, 1); } // value of lane + 1
+__device__ inline int lane_up(int v)       { return __shfl_up(v, 1); }
+__device__ inline int lane_down(int v)     { return __shfl_down(v, 1); }
+
+__global__ __launch_bounds__(64) void k_fwd_masks_w1(const float *__restrict__ T, const uint8_t *__restrict__ Cn,
+                                                     int W, int H, int b, float tau, int fwords,
+                                                     uint32_t *__restrict__ fwd)
+{
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * 62 + lane - 1; // lanes 1..62 produce output
+    const int r = blockIdx.y;
+    const bool col_ok = c >= 0 && c < W;
+    const bool is_main = (r >= 1 && r <= H - 2 && c >= 1 && c <= W - 2);
+    const bool writer = lane >= 1 && lane <= 62 && c < W;
+    const size_t plane = (size_t)W * H;
+    // rows r-1, r, r+1 clamped for the loads (values of non-main pixels are never used)
+    const int r0 = max(r - 1, 0), r2 = min(r + 1, H - 1), cc = min(max(c, 0), W - 1);
+    const size_t o0 = (size_t)r0 * W + cc, o1 = (size_t)r * W + cc, o2 = (size_t)r2 * W + cc;
+    uint32_t word = 0;
+    int didx = 0, wi = 0;
+    for (int dl = 0; dl <= b; ++dl)
+        for (int dc = (dl == 0 ? 0 : -b); dc <= b; ++dc, ++didx) {
+            const float *Tp = T + (size_t)didx * plane;
+            const uint8_t *Cp = Cn + (size_t)didx * plane;
+            float t0 = Tp[o0], t1 = Tp[o1], t2 = Tp[o2];
+            int n0 = Cp[o0], n1 = Cp[o1], n2 = Cp[o2];
+            float s = lane_up(t0);
+            s += t0; s += lane_down(t0);
+            s += lane_up(t1); s += t1; s += lane_down(t1);
+            s += lane_up(t2); s += t2; s += lane_down(t2);
+            int n = lane_up(n0) + n0 + lane_down(n0) + lane_up(n1) + n1 + lane_down(n1) + lane_up(n2) + n2 + lane_down(n2);
+            const int qr = r + dl, qc = c + dc;
+            const bool q_main = qr <= H - 2 && qc >= 1 && qc <= W - 2;
+            float d = s / (float)n; // 0/0 = NaN -> not similar
+            if (is_main && q_main && d <= tau) word |= 1u << (didx & 31);
+            if ((didx & 31) == 31) {
+                if (writer) fwd[((size_t)r * W + c) * fwords + wi] = word;
+                word = 0; ++wi;
+            }
+        }
+    if ((didx & 31) != 0 && writer) fwd[((size_t)r * W + c) * fwords + wi] = word;
+    (void)col_ok;
+}
+
+// kernel 3: full (2b+1)^2-bit masks and |S| from the forward bits: bit(p, -delta) = bit(p - delta, +delta)
+__global__ __launch_bounds__(256) void k_sym_masks(const uint32_t *__restrict__ fwd, int W, int H, int b, int fwords, int words,
+                                                   uint32_t *__restrict__ mask, int32_t *__restrict__ count)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= W || r >= H) return;
+    const int side = 2 * b + 1;
+    const size_t pix = (size_t)r * W + c;
+    uint32_t out[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) out[j] = 0;
+    int n = 0;
+    for (int dl = -b; dl <= b; ++dl)
+        for (int dc = -b; dc <= b; ++dc) {
+            const bool forward = dl > 0 || (dl == 0 && dc >= 0);
+            const int br = forward ? r : r + dl, bc = forward ? c : c + dc; // pixel holding the forward bit
+            if (br < 0 || bc < 0 || bc >= W) continue;
+            const int di = bcd_delta_index(forward ? dl : -dl, forward ? dc : -dc, b);
+            const uint32_t wv = fwd[((size_t)br * W + bc) * fwords + (di >> 5)];
+            if ((wv >> (di & 31)) & 1u) {
+                const int k = (dl + b) * side + (dc + b);
+                out[k >> 5] |= 1u << (k & 31);
+                ++n;
+            }
+        }
+    for (int j = 0; j < words; ++j) mask[pix * words + j] = out[j];
+    count[pix] = n;
+}
+
 __global__ void k_mask_count(const uint32_t *__restrict__ mask, int64_t npix, int words, int32_t *__restrict__ count)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,13 +366,19 @@ hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H,
 }
 
 hipError_t bcd_launch_masks(const float *T, const uint8_t *Cn, int W, int H, int w, int b, float tau,
-                            uint32_t *mask, int32_t *count, hipStream_t st)
+                            uint32_t *mask, int32_t *count, uint32_t *fwd_scratch, hipStream_t st)
 {
     const int side = 2 * b + 1, words = (side * side + 31) / 32;
+    int64_t npix = (int64_t)W * H;
+    if (w == 1 && fwd_scratch) {
+        const int fwords = (bcd_delta_count(b) + 31) / 32;
+        hipLaunchKernelGGL(k_fwd_masks_w1, dim3((W + 61) / 62, H), dim3(64), 0, st, T, Cn, W, H, b, tau, fwords, fwd_scratch);
+        hipLaunchKernelGGL(k_sym_masks, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, st, fwd_scratch, W, H, b, fwords, words, mask, count);
+        return hipGetLastError();
+    }
     dim3 block(64, 4);
     dim3 grid((W + 63) / 64, H, (words + 3) / 4);
     hipLaunchKernelGGL(k_masks, grid, block, 0, st, T, Cn, W, H, w, b, tau, words, mask);
-    int64_t npix = (int64_t)W * H;
     hipLaunchKernelGGL(k_mask_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, mask, npix, words, count);
     return hipGetLastError();
 }
