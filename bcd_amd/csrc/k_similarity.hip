@@ -38,7 +38,16 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
     float *lds_n = reinterpret_cast<float *>(lds4 + PD_TH * ncols * (DS / 4));
 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int col0 = blockIdx.x * PD_TW, row0 = blockIdx.y * PD_TH;
+    // XCD-aware tile order: workgroup id i runs on XCD i % 8 (each XCD has its own 4 MiB L2); give every XCD one
+    // contiguous horizontal band of tiles in row-major order, so the tiles that re-read the same neighbour rows
+    // (vertical neighbours, for the 7 displacement rows) hit the same L2 instead of eight different ones.
+    int tile;
+    {
+        const int nt = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = id & 7, k = id >> 3, q = nt >> 3, rem = nt & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+    }
+    const int col0 = (tile % gridDim.x) * PD_TW, row0 = (tile / gridDim.x) * PD_TH;
     const int c = col0 + tx, r = row0 + ty;
     const bool inside = (c < W) && (r < H);
     const size_t plane = (size_t)W * H;

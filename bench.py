@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--skip-prob", type=float, default=1.0, help="-m of bcd_cli")
     ap.add_argument("--random-order", type=int, default=1, help="-r of bcd_cli")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--band-path", action="store_true", help="use the multi-GPU row-band code path even with one rank (debug)")
     ap.add_argument("--cpu-sample", default="480x270", help="frame size of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -80,9 +81,11 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.band_path:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W, H, S, b, w = args.width, args.height, args.scales, args.search_radius, 1
     prm = bh.default_params(b=b, w=w, m=args.skip_prob, random_order=args.random_order, seed=1234)
@@ -91,7 +94,7 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = bh.Context(local_rank, stream)
 
-    if world == 1:
+    if world == 1 and not args.band_path:
         col, ns, hist, cov = core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes)
         d_in = [torch.from_numpy(a).cuda() for a in (col, ns, hist, cov)]
         out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
