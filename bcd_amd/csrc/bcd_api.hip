@@ -14,7 +14,8 @@
 
 // launchers implemented in the k_*.hip files
 size_t bcd_pairdist_lds_bytes(int D, int b);
-hipError_t bcd_launch_pairdist(const float *, const float *, int, int, int, int, float *, uint8_t *, hipStream_t);
+hipError_t bcd_launch_pairdist(const float *, const float *, int, int, int, int, float *, uint8_t *, int, int *, hipStream_t);
+hipError_t bcd_launch_selftest_div(uint32_t, int, int, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t);
 hipError_t bcd_launch_window_distances(const float *, const uint8_t *, int, int, int, int, int, int, float *, hipStream_t);
 hipError_t bcd_launch_pixel_cov(const float *, const float *, int64_t, float *, hipStream_t);
@@ -137,8 +138,16 @@ int similarity(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, 
         ++ctx->ev_used;
         HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     }
-    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, ctx->stream));
+    RCCHK(ensure(ctx, ctx->counters, 64 * sizeof(int32_t)));
+    int *d_flag = (int *)ctx->counters.p + 40;
+    HIPCHK(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, 1, d_flag, ctx->stream));
     if (e1) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    // the fast kernel flags inputs outside the range where its division is proven exact: redo with the compiler's division
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_counters[40] != 0)
+        HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, 0, d_flag, ctx->stream));
     HIPCHK(ctx, bcd_launch_masks((const float *)ctx->T.p, (const uint8_t *)ctx->Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)ctx->fwd.p, ctx->stream));
     return BCD_HIP_OK;
 }
@@ -469,7 +478,7 @@ int bcd_hip_window_distances(bcd_hip_ctx *ctx, const float *d_hist, const float 
     RCCHK(ensure(ctx, ctx->T, npix * nd * sizeof(float)));
     RCCHK(ensure(ctx, ctx->Cn, npix * nd));
     RCCHK(ensure(ctx, ctx->tmp_lo, n * sizeof(float)));
-    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, ctx->stream));
+    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, 0, nullptr, ctx->stream));
     HIPCHK(ctx, bcd_launch_window_distances((const float *)ctx->T.p, (const uint8_t *)ctx->Cn.p, W, H, w, b, line, col, (float *)ctx->tmp_lo.p, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->tmp_lo.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -552,6 +561,21 @@ int bcd_hip_zero_bad_values(bcd_hip_ctx *ctx, float *d_img, int64_t n)
 {
     if (!ctx || !d_img || n <= 0) return bad(ctx, "bad argument");
     HIPCHK(ctx, bcd_launch_zero_bad(d_img, n, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, int64_t *mismatches)
+{
+    if (!ctx || !mismatches || samples <= 0) return bad(ctx, "bad argument");
+    RCCHK(ensure(ctx, ctx->counters, 64 * sizeof(int32_t)));
+    unsigned long long *d = reinterpret_cast<unsigned long long *>((int32_t *)ctx->counters.p + 32);
+    HIPCHK(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+    const int per_thread = 1024, blocks = (int)std::min<int64_t>(1 << 20, (samples + 256ll * per_thread - 1) / (256ll * per_thread));
+    HIPCHK(ctx, bcd_launch_selftest_div(seed, blocks, per_thread, d, ctx->stream));
+    unsigned long long h = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *mismatches = (int64_t)h;
     return BCD_HIP_OK;
 }
 

@@ -12,6 +12,7 @@
 // This file is compiled with -ffp-contract=off: the reference is built without FMA contraction and the
 // membership test d <= tau is discrete.
 #include "bcd_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -19,6 +20,32 @@ constexpr int PD_TW = 64; // tile width  (one wavefront per tile row)
 constexpr int PD_TH = 4;  // tile height (4 wavefronts per workgroup)
 
 // LDS pixel stride (floats): D/4 odd keeps ds_read_b128 at a per-lane stride of D*4 bytes conflict-free
+// IEEE-754 correctly rounded a / b without the range scaling of the compiler's sequence.  hipcc lowers an fp32 division to
+//   v_div_scale x2, v_rcp, fma, fma, mul, fma, fma, fma, v_div_fmas, v_div_fixup;
+// v_div_scale / v_div_fixup only act when an operand or the quotient is zero, subnormal, huge or non-finite (CDNA4 ISA,
+// V_DIV_SCALE_F32).  For operands inside the guarded range below they are the identity and v_div_fmas is a plain fma, so the
+// eight operations here produce bit-identical results (self-test: bcd_hip_selftest_division).  a == 0 gives +0 like a / b.
+constexpr float PD_BIN_MAX = 1048576.f;   // 2^20   histogram bins must be in [0, 2^20]
+constexpr float PD_N_MIN = 0.0009765625f; // 2^-10  sample counts must be in [2^-10, 2^16]
+constexpr float PD_N_MAX = 65536.f;       //        => 1 < s <= 2^21, den in (2^-20, 2^53], num in {0} U [2^-70, 2^74], quotient >= 2^-123
+
+template <bool FAST>
+__device__ inline float pd_div(float a, float b)
+{
+    if (!FAST) return a / b;
+    float y = __builtin_amdgcn_rcpf(b);
+    float e = fmaf(-b, y, 1.f);
+    y = fmaf(e, y, y);
+    float q = a * y;
+    float r = fmaf(-b, q, a);
+    q = fmaf(r, y, q);
+    r = fmaf(-b, q, a);
+    return fmaf(r, y, q);
+}
+
+__device__ inline bool pd_bin_bad(float v) { return !(v >= 0.f && v <= PD_BIN_MAX); }
+__device__ inline bool pd_n_bad(float v) { return !(v >= PD_N_MIN && v <= PD_N_MAX); }
+
 template <int D> struct PdStride { static constexpr int value = ((D / 4) % 2 == 1) ? D : D + 4; };
 
 // ---------------------------------------------------------------------------------------------------
@@ -26,10 +53,12 @@ template <int D> struct PdStride { static constexpr int value = ((D / 4) % 2 == 
 // neighbour rows staged through LDS once per displacement row dl and re-used for the 2b+1 (or b+1)
 // displacements of that row.
 // ---------------------------------------------------------------------------------------------------
-template <int D>
+// FAST = true: scale-free division (pd_div<true>); any staged value outside its guarded range raises *range_flag and the
+// host re-runs the scale with FAST = false (the compiler's division), so results are exact either way.
+template <int D, bool FAST>
 __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist, const float *__restrict__ ns,
                                                    int W, int H, int b,
-                                                   float *__restrict__ T, uint8_t *__restrict__ Cn)
+                                                   float *__restrict__ T, uint8_t *__restrict__ Cn, int *range_flag)
 {
     constexpr int DS = PdStride<D>::value;
     constexpr int Q = D / 4;
@@ -64,12 +93,19 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
         }
         if (inside) n1 = ns[pix];
     }
+    bool own_bad = false;
+    if (FAST) {
+        own_bad = pd_n_bad(n1);
+#pragma unroll
+        for (int k = 0; k < D; ++k) own_bad = own_bad || pd_bin_bad(h1[k]);
+    }
 
     int didx = 0;
     for (int dl = 0; dl <= b; ++dl) {
         __syncthreads();
         // stage rows row0+dl .. row0+dl+3, columns col0-b .. col0+63+b
         const int npix = PD_TH * ncols;
+        bool stage_bad = own_bad;
         for (int i = threadIdx.x; i < npix * Q; i += 256) {
             int p = i / Q, q = i - p * Q;
             int lr = p / ncols, lc = p - lr * ncols;
@@ -77,24 +113,28 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gr < H && gc >= 0 && gc < W) v = reinterpret_cast<const float4 *>(hist)[((size_t)gr * W + gc) * Q + q];
             lds4[p * (DS / 4) + q] = v;
+            if (FAST) stage_bad = stage_bad || pd_bin_bad(v.x) || pd_bin_bad(v.y) || pd_bin_bad(v.z) || pd_bin_bad(v.w);
         }
         for (int i = threadIdx.x; i < npix; i += 256) {
             int lr = i / ncols, lc = i - lr * ncols;
             int gr = row0 + dl + lr, gc = col0 - b + lc;
-            lds_n[i] = (gr < H && gc >= 0 && gc < W) ? ns[(size_t)gr * W + gc] : 1.f;
+            float nv = (gr < H && gc >= 0 && gc < W) ? ns[(size_t)gr * W + gc] : 1.f;
+            lds_n[i] = nv;
+            if (FAST) stage_bad = stage_bad || pd_n_bad(nv);
         }
+        if (FAST && stage_bad) atomicOr(range_flag, 1); // some value is outside the range where pd_div<true> is proven exact
         __syncthreads();
 
         const int dc0 = (dl == 0) ? 0 : -b;
         // neighbour histograms are double-buffered in registers: the 15 ds_read_b128 of displacement dc+1 are in
         // flight while displacement dc is evaluated
         float4 bufA[Q], bufB[Q];
-        auto fetch = [&](float4 *buf, int dc) {
+        auto fetch = [&](float4 *buf, int dc) __attribute__((always_inline)) {
             const float4 *nb = lds4 + (ty * ncols + tx + dc + b) * (DS / 4);
 #pragma unroll
             for (int q = 0; q < Q; ++q) buf[q] = nb[q];
         };
-        auto evaluate = [&](const float4 *buf, int dc, int di) {
+        auto evaluate = [&](const float4 *buf, int dc, int di) __attribute__((always_inline)) {
             const float n2 = lds_n[ty * ncols + tx + dc + b];
             const float n12 = n1 * n2;
             float sum = 0.f;
@@ -116,7 +156,7 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float diff = n2 * h1[4 * q + j] - n1 * b2[j];
-                        t[j] = diff * diff / (n12 * s[j]);
+                        t[j] = pd_div<FAST>(diff * diff, n12 * s[j]);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { // bins in order: the reference's sequential sum
@@ -337,7 +377,36 @@ __global__ void k_window_distances(const float *__restrict__ T, const uint8_t *_
     out[k] = d;
 }
 
+// self-test of pd_div<true> against the compiler's IEEE division on hashed operands drawn from the guarded range
+__global__ void k_selftest_div(uint32_t seed, int per_thread, unsigned long long *mismatches)
+{
+    uint32_t st = bcd_mix32(seed ^ (blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B1u);
+    unsigned bad = 0;
+    for (int i = 0; i < per_thread; ++i) {
+        st = bcd_mix32(st + 0x6D2B79F5u); uint32_t ma = st;
+        st = bcd_mix32(st + 0x6D2B79F5u); uint32_t mb = st;
+        st = bcd_mix32(st + 0x6D2B79F5u); uint32_t ex = st;
+        // random mantissas (every 16th: all-ones / all-zeros patterns), exponents spanning the guarded range
+        uint32_t fa = (ma & 0x7fffffu), fb = (mb & 0x7fffffu);
+        if ((ex & 0xf00000u) == 0) { fa = (ex & 1) ? 0x7fffffu : 0u; }
+        if ((ex & 0x0f0000u) == 0) { fb = (ex & 2) ? 0x7fffffu : 0x7ffffeu; }
+        int ea = 127 - 70 + (int)((ex & 0xffu) % 145u);        // 2^-70 .. 2^74
+        int eb = 127 - 20 + (int)(((ex >> 8) & 0xffu) % 74u);  // 2^-20 .. 2^53
+        float a = __int_as_float((uint32_t)ea << 23 | fa), b = __int_as_float((uint32_t)eb << 23 | fb);
+        if ((ex >> 28) == 0) a = 0.f;
+        float q1 = pd_div<true>(a, b), q2 = a / b;
+        if (__float_as_int(q1) != __float_as_int(q2)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 } // namespace
+
+hipError_t bcd_launch_selftest_div(uint32_t seed, int blocks, int per_thread, unsigned long long *d_mismatches, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_selftest_div, dim3(blocks), dim3(256), 0, st, seed, per_thread, d_mismatches);
+    return hipGetLastError();
+}
 
 // ---- launchers (called from bcd_api.hip) --------------------------------------------------------------
 size_t bcd_pairdist_lds_bytes(int D, int b)
@@ -346,22 +415,27 @@ size_t bcd_pairdist_lds_bytes(int D, int b)
     return (size_t)PD_TH * (PD_TW + 2 * b) * (DS + 1) * sizeof(float);
 }
 
+// fast != 0: scale-free division + range flag (d_range_flag must be zeroed by the caller); fast == 0: compiler division
 hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H, int D, int b,
-                               float *T, uint8_t *Cn, hipStream_t st)
+                               float *T, uint8_t *Cn, int fast, int *d_range_flag, hipStream_t st)
 {
     dim3 grid((W + PD_TW - 1) / PD_TW, (H + PD_TH - 1) / PD_TH), block(256);
     size_t lds = bcd_pairdist_lds_bytes(D, b);
-    bool fast = (D % 4 == 0) && lds <= 160 * 1024;
-#define BCD_PD_CASE(DD)                                                                                              \
-    case DD:                                                                                                         \
+    bool tiled = (D % 4 == 0) && lds <= 160 * 1024;
+#define BCD_PD_LAUNCH(DD, FF)                                                                                        \
+    {                                                                                                                \
         if (lds > 64 * 1024) {                                                                                       \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist<DD>),                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist<DD, FF>),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
-        hipLaunchKernelGGL(k_pairdist<DD>, grid, block, lds, st, hist, ns, W, H, b, T, Cn);                          \
-        return hipGetLastError();
-    if (fast) switch (D) {
+        hipLaunchKernelGGL((k_pairdist<DD, FF>), grid, block, lds, st, hist, ns, W, H, b, T, Cn, d_range_flag);      \
+        return hipGetLastError();                                                                                    \
+    }
+#define BCD_PD_CASE(DD)                                                                                              \
+    case DD:                                                                                                         \
+        if (fast) BCD_PD_LAUNCH(DD, true) else BCD_PD_LAUNCH(DD, false)
+    if (tiled) switch (D) {
         BCD_PD_CASE(60)
         BCD_PD_CASE(120)
         BCD_PD_CASE(36)
@@ -370,6 +444,7 @@ hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H,
         default: break;
     }
 #undef BCD_PD_CASE
+#undef BCD_PD_LAUNCH
     hipLaunchKernelGGL(k_pairdist_generic, grid, block, 0, st, hist, ns, W, H, D, b, T, Cn);
     return hipGetLastError();
 }

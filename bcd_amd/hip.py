@@ -30,7 +30,7 @@ SYMBOLS = [
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_zero_bad_values",
-    "bcd_hip_visit_order", "bcd_hip_scale_seed",
+    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_selftest_division",
 ]
 
 _lib = None
@@ -228,6 +228,11 @@ class Context:
 
     def reset_kernel_time(self):
         self._chk(lib().bcd_hip_reset_kernel_time(self.h))
+
+    def selftest_division(self, samples, seed=1):
+        n = C.c_int64(-1)
+        self._chk(lib().bcd_hip_selftest_division(self.h, C.c_uint32(seed), C.c_int64(samples), C.byref(n)))
+        return n.value
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)

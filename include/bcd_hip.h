@@ -140,6 +140,10 @@ int bcd_hip_spike_filter(bcd_hip_ctx *ctx, const float *d_colors, const float *d
 /* checkAndPutToZeroNegativeInfNaNValues   src/cli/main.cpp:389-420 */
 int bcd_hip_zero_bad_values(bcd_hip_ctx *ctx, float *d_img, int64_t n);
 
+/* self-test: the scale-free division used by the pair-distance kernel against the compiler's IEEE division on
+ * `samples` hashed operand pairs drawn from its guarded range; *mismatches must come back 0 */
+int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, int64_t *mismatches);
+
 /* ---- host utilities (no device work) ----------------------------------------------------------- */
 /* the visiting order implied by (random_order, seed): main-pixel linear indices line*W+col in
  * visiting order, written to h_order[(W-2w)*(H-2w)].  random_order == 0 is the reference's

@@ -362,3 +362,26 @@ def test_bcd_cli_end_to_end(hipctx, tmp_path):
         want = hipctx.denoise(*d, 2, bh.default_params(b=4, m=0.0, seed=5))
         want = hipctx.zero_bad_values(want).cpu().numpy()
         assert np.max(np.abs(got - want.astype(np.float16).astype(np.float32))) <= 2e-3 * np.max(want)
+
+
+def test_scale_free_division_is_ieee_exact(hipctx):
+    """the 8-operation division of k_pairdist == hipcc's correctly rounded a / b on 2e9 operand pairs of its guarded range"""
+    assert hipctx.selftest_division(2_000_000_000, seed=7) == 0
+    assert hipctx.selftest_division(500_000_000, seed=12345) == 0
+
+
+def test_out_of_range_inputs_take_the_exact_fallback(hipctx):
+    """histogram bins / sample counts outside the guarded range switch the workgroup to the compiler's division: still bit-exact"""
+    W, H = 70, 21
+    col, ns, hist, cov, _ = inputs(W, H, 4, 0.3)
+    hist = hist.copy(); ns = ns.copy()
+    hist[5, 7, :] *= 4.0e6      # bins > 2^20
+    ns[5, 7] *= 4.0e6
+    ns[12, 40] = 3.0e-4         # n < 2^-10
+    hist[12, 40, :] *= 1e-4
+    d_hist, d_ns = dev(hist, ns)
+    mask, cnt = hipctx.similarity_masks(d_hist, d_ns, 1, 6, 1.0)
+    wmask, wcnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask) and np.array_equal(cnt.cpu().numpy(), wcnt)
+    for (l, c) in [(5, 7), (6, 8), (12, 40), (11, 41)]:
+        assert bits_equal(hipctx.window_distances(d_hist, d_ns, 1, 6, l, c), ol.window_distances(ns, hist, 1, 6, l, c))
