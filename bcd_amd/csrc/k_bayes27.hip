@@ -459,6 +459,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         fprintf(stderr, "bayes27 dbg n=%lld: decode %lld noise %lld mean %lld cov %lld jacobi %lld rebuild %lld inv1 %lld step2mm %lld inv2 %lld final %lld total %lld\n", h[11], h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5], h[7]-h[6], h[8]-h[7], h[9]-h[8], h[10]-h[9], h[10]-h[0]);
         return hipGetLastError();
     }
+    { const char *pad = getenv("BCD_BAYES_LDS_PAD"); if (pad) { size_t lds2 = bcd_bayes27_lds_bytes(b) + (size_t)atoi(pad); hipLaunchKernelGGL(k_bayes27<false>, dim3(nlist), dim3(64), lds2, st, colors, pixcov, mask, list, g, min_eig, sum, cnt); return hipGetLastError(); } }
     hipLaunchKernelGGL(k_bayes27<false>, dim3(nlist), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
     return hipGetLastError();
 }

@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
     const int ncols = PD_TW + 2 * b;
     float *lds_n = reinterpret_cast<float *>(lds4 + PD_TH * ncols * (DS / 4));
 
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // a wavefront covers a compact 16 x 4 pixel patch of the 64 x 4 tile (not a 64 x 1 line): neighbouring pixels in 2-D share
+    // their occupied histogram bins, which makes the wave-uniform bin skipping below bite more often
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    const int tx = (wave_ << 4) | (lane_ & 15), ty = lane_ >> 4;
     // XCD-aware tile order: workgroup id i runs on XCD i % 8 (each XCD has its own 4 MiB L2); give every XCD one
     // contiguous horizontal band of tiles in row-major order, so the tiles that re-read the same neighbour rows
     // (vertical neighbours, for the 7 displacement rows) hit the same L2 instead of eight different ones.

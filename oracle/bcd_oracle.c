@@ -492,11 +492,24 @@ static void aggregate(Unit *u)
     }
 }
 
-/* a9 denoisePatchAndSimilarPatches (:157-194).  skip_probability is honoured for 0 and 1 only. */
+/* per-pixel uniform in [0,1) standing in for `rand() / RAND_MAX` of DenoisingUnit.cpp:168 (build-defined, see bcd_common.h) */
+static uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+static float unit_hash(uint32_t idx, uint32_t seed)
+{
+    return (float)(mix32(idx * 0x9E3779B1u + mix32(seed ^ 0x51ed270bu)) >> 8) * (1.0f / 16777216.0f);
+}
+static uint32_t g_skip_seed = 0; /* set by the entry points (serial paths only) */
+
+/* a9 denoisePatchAndSimilarPatches (:157-194): a marked pixel is skipped with probability skip_prob */
 static void denoise_patch_and_similar(Unit *u, int pl, int pc, float skip_prob, const BcdoDiag *diag)
 {
     size_t pi = (size_t)pl * u->W + pc;
-    if (skip_prob != 0.f && u->marked[pi]) return;
+    if (skip_prob != 0.f && u->marked[pi])
+        if (skip_prob == 1.f || unit_hash((uint32_t)pi, g_skip_seed) < skip_prob) return;
     select_similar(u, pl, pc);
     if (diag && diag->processed) diag->processed[pi] = 1;
     if (diag && diag->nb_similar) diag->nb_similar[pi] = u->nS;
@@ -564,6 +577,7 @@ int bcdo_denoise_mono(const float *colors, const float *nsamp, const float *hist
     }
     if (serial) {
         Unit u;
+        g_skip_seed = prm->skip_seed;
         unit_init(&u, W, H, D, prm, colors, nsamp, hist, pixcov, sums[0], cnts[0], marked);
         int64_t n = order ? n_order : nmain;
         for (int64_t i = 0; i < n; ++i) {
@@ -616,6 +630,7 @@ int bcdo_accumulate_band(const float *colors, const float *nsamp, const float *h
     memset(sum, 0, sizeof(float) * npix * 3);
     memset(cnt, 0, sizeof(int32_t) * npix);
     Unit u;
+    g_skip_seed = prm->skip_seed;
     unit_init(&u, W, H, D, prm, colors, nsamp, hist, pixcov, sum, cnt, marked);
     if (order) {
         for (int64_t i = 0; i < n_order; ++i) {
@@ -822,10 +837,12 @@ int bcdo_denoise_multiscale(const float *colors, const float *nsamp, const float
         col[s] = own[s][0]; ns[s] = own[s][1]; hs[s] = own[s][2]; cv[s] = own[s][3];
     }
     for (int s = nb_scales - 1; s >= 0; --s) {
+        BcdoParams ps = *prm;
+        ps.skip_seed = prm->skip_seed + (uint32_t)s;
         if (racy_omp)
             rc = bcdo_denoise_mono_omp_racy(col[s], ns[s], hs[s], cv[s], ws[s], hs_[s], D, prm, outs[s]);
         else
-            rc = bcdo_denoise_mono(col[s], ns[s], hs[s], cv[s], ws[s], hs_[s], D, prm,
+            rc = bcdo_denoise_mono(col[s], ns[s], hs[s], cv[s], ws[s], hs_[s], D, &ps,
                                    orders ? orders[s] : NULL, n_orders ? n_orders[s] : 0, outs[s], NULL);
         if (rc) break;
         if (s < nb_scales - 1) bcdo_merge(outs[s], ws[s], hs_[s], outs[s + 1], 3);

@@ -41,6 +41,9 @@ typedef struct BcdoParams {
     float skip_probability;    /* m_markedPixelsSkippingProbability (:41); only 0 and 1 are
                                   deterministic in the reference (rand() otherwise)          */
     int   nb_threads;          /* OpenMP threads for the m=0 path (order-free); m=1 is serial */
+    uint32_t skip_seed;        /* 0 < skip_probability < 1 only: the reference draws unseeded rand() (DenoisingUnit.cpp:168);
+                                  the build replaces it by a per-pixel hash of (pixel index, seed) -- mirrored here so that
+                                  the marking logic can be checked; scale s of a multiscale run uses skip_seed + s       */
 } BcdoParams;
 
 /* per-pixel diagnostics (all optional, may be NULL); W*H entries each */

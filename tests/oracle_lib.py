@@ -13,7 +13,7 @@ _FP = C.POINTER(C.c_float)
 
 class BcdoParams(C.Structure):
     _fields_ = [("hist_dist_threshold", C.c_float), ("patch_radius", C.c_int), ("search_radius", C.c_int),
-                ("min_eigen_value", C.c_float), ("skip_probability", C.c_float), ("nb_threads", C.c_int)]
+                ("min_eigen_value", C.c_float), ("skip_probability", C.c_float), ("nb_threads", C.c_int), ("skip_seed", C.c_uint32)]
 
 
 class BcdoDiag(C.Structure):
@@ -55,8 +55,8 @@ def ref():
     return _ref
 
 
-def params(tau=1.0, w=1, b=6, min_eig=1e-8, m=1.0, threads=0):
-    return BcdoParams(tau, w, b, min_eig, m, threads)
+def params(tau=1.0, w=1, b=6, min_eig=1e-8, m=1.0, threads=0, skip_seed=0):
+    return BcdoParams(tau, w, b, min_eig, m, threads, skip_seed)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -385,3 +385,34 @@ def test_out_of_range_inputs_take_the_exact_fallback(hipctx):
     assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask) and np.array_equal(cnt.cpu().numpy(), wcnt)
     for (l, c) in [(5, 7), (6, 8), (12, 40), (11, 41)]:
         assert bits_equal(hipctx.window_distances(d_hist, d_ns, 1, 6, l, c), ol.window_distances(ns, hist, 1, 6, l, c))
+
+
+@pytest.mark.parametrize("m,nscales", [(0.5, 1), (0.25, 2), (0.9, 1)])
+def test_fractional_skip_probability(hipctx, m, nscales):
+    """0 < -m < 1: marked pixels are skipped with probability m.  The reference draws unseeded rand(); the build uses a
+    per-pixel hash, mirrored by the oracle, so the whole marking logic (non-skippable pixels still mark others) is checked"""
+    import bcd_amd.hip as bh
+    W, H = 72, 52
+    col, ns, hist, cov, _ = inputs(W, H, 32, 0.08, 0.0)
+    prm = bh.default_params(m=m, random_order=1, seed=21)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), nscales, prm).cpu().numpy()
+    orders = _orders(W, H, 1, 1, 21, nscales)
+    op = ol.params(m=m, skip_seed=21)
+    want = ol.denoise_multiscale(col, ns, hist, cov, nscales, op, orders=orders) if nscales > 1 else ol.denoise_mono(col, ns, hist, cov, op, order=orders[0])
+    assert rel_linf(got, want) < TOL
+    st = hipctx.stats(0)
+    full = ol.denoise_mono(col, ns, hist, cov, ol.params(m=1.0), order=orders[0], want_diag=True)[1][0].sum()
+    assert st.processed > full          # fewer pixels are skipped than with -m 1
+
+
+def test_mono_parity_large_search_window(hipctx):
+    """-b 12 (BASELINE config 5): 625-bit masks, 313 displacement planes"""
+    import bcd_amd.hip as bh
+    W, H = 70, 44
+    col, ns, hist, cov, _ = inputs(W, H, 16, 0.12, 0.0)
+    prm = bh.default_params(m=1.0, random_order=1, seed=2, b=12)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), 1, prm).cpu().numpy()
+    want = ol.denoise_mono(col, ns, hist, cov, ol.params(m=1.0, b=12), order=_orders(W, H, 1, 1, 2, 1)[0])
+    assert rel_linf(got, want) < TOL
+    got0 = hipctx.denoise(*dev(col, ns, hist, cov), 1, bh.default_params(m=0.0, b=12)).cpu().numpy()
+    assert rel_linf(got0, ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0, b=12))) < TOL
