@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -28,7 +29,7 @@ hipError_t bcd_launch_spike(const float *, const float *, const float *, const f
                             float *, float *, hipStream_t);
 hipError_t bcd_launch_active_init(const int32_t *, int, int, int, int, int, float, uint32_t, uint8_t *, hipStream_t);
 hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int *, hipStream_t);
-hipError_t bcd_launch_active_tile(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int *, hipStream_t);
+hipError_t bcd_launch_active_tile(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int *, hipStream_t);
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t bcd_bayes_lds_bytes(int w, int b);
 hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, int, int, int, int, int, float,
@@ -164,13 +165,14 @@ int active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_nsim, 
         const int max_rounds = 4 * (W + H) + 64;
         bool done = false;
         const int side = 2 * b + 1, words = (side * side + 31) / 32;
-        const bool tiled = (words == 6 || words == 20);
+        const bool tiled = (b == 6 || b == 12);
+        (void)words;
         const int batch = tiled ? 2 : ROUND_BATCH;
         while (!done && rounds < max_rounds) {
             HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), ctx->stream));
             for (int i = 0; i < batch; ++i) {
                 if (tiled)
-                    HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, 16, d_cnt + i, ctx->stream));
+                    HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, getenv("BCD_INNER") ? atoi(getenv("BCD_INNER")) : 6, (rounds == 0 && i == 0 && skip_prob >= 1.f) ? 1 : 0, d_cnt + i, ctx->stream));
                 else
                     HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, d_cnt + i, ctx->stream));
             }

@@ -70,20 +70,45 @@ __global__ __launch_bounds__(256) void k_active_round(const uint32_t *__restrict
 // same workgroup are visible through the CU's write-through L1 (volatile loads), updates of other workgroups may be
 // seen late, which only delays a decision (the iteration is monotone and its fixed point unique).  One launch
 // resolves every dependency chain that stays inside a tile, so a frame needs 2-3 launches instead of one per level.
-template <int WORDS>
+template <int B>
 __global__ __launch_bounds__(256) void k_active_tile(const uint32_t *__restrict__ mask, const int32_t *__restrict__ nsim,
-                                                     uint8_t *state, int W, int H, int b, int min_strong, int random_order,
-                                                     uint32_t seed, int inner_iters, int *__restrict__ undecided)
+                                                     uint8_t *state, int W, int H, int min_strong, int random_order,
+                                                     uint32_t seed, int inner_iters, int first_launch, int *__restrict__ undecided)
 {
+    constexpr int b = B, WORDS = ((2 * B + 1) * (2 * B + 1) + 31) / 32; // compile-time window: k / side is a multiply-shift
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = blockIdx.y * 16 + (threadIdx.x >> 4);
-    const int side = 2 * b + 1;
+    constexpr int side = 2 * b + 1;
     volatile uint8_t *vstate = state;
+    // stage, for the tile and its b-pixel halo, the high word of the visiting key and the "strong" flag (|S| >= 3P+1):
+    // the dependency extraction below then probes LDS instead of chasing dependent global loads
+    extern __shared__ uint32_t lds_u[];
+    constexpr int tw = 16 + 2 * b;
+    uint32_t *s_hash = lds_u;
+    uint8_t *s_strong = reinterpret_cast<uint8_t *>(lds_u + tw * tw);
+    volatile uint8_t *s_state = s_strong + tw * tw; // states of the tile + halo, refreshed from global every iteration
+    const int r0 = blockIdx.y * 16 - b, c0 = blockIdx.x * 16 - b;
+    for (int i = threadIdx.x; i < tw * tw; i += 256) {
+        int lr = i / tw, lc = i - lr * tw, gr = r0 + lr, gc = c0 + lc;
+        uint32_t h = 0;
+        uint8_t st = 0, sv = BCD_ST_NONE;
+        if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
+            size_t q = (size_t)gr * W + gc;
+            h = (uint32_t)(bcd_order_key((uint32_t)q, random_order, seed) >> 32);
+            st = nsim[q] >= min_strong;
+            sv = state[q];
+        }
+        s_hash[i] = h;
+        s_strong[i] = st;
+        s_state[i] = sv;
+    }
+    __syncthreads();
     const bool inside = c < W && r < H;
     const size_t p = inside ? (size_t)r * W + c : 0;
     bool pending = inside && state[p] == BCD_ST_UNDECIDED;
     uint32_t dep[WORDS];
     if (pending) {
-        const uint64_t keyp = bcd_order_key((uint32_t)p, random_order, seed);
+        const int lp = ((threadIdx.x >> 4) + b) * tw + (threadIdx.x & 15) + b;
+        const uint32_t hp = s_hash[lp];
 #pragma unroll
         for (int j = 0; j < WORDS; ++j) {
             uint32_t m = mask[p * WORDS + j], keep = 0;
@@ -92,11 +117,11 @@ __global__ __launch_bounds__(256) void k_active_tile(const uint32_t *__restrict_
                 m &= m - 1;
                 int k = j * 32 + bit;
                 int dl = k / side - b, dc = k - (k / side) * side - b;
-                size_t q = (size_t)(r + dl) * W + (c + dc);
-                if (q == p) continue;
-                if (nsim[q] < min_strong) continue;                                  // fallback pixels mark nobody
-                if (bcd_order_key((uint32_t)q, random_order, seed) > keyp) continue; // visited later
-                keep |= 1u << bit;
+                int lq = lp + dl * tw + dc;
+                uint32_t hq = s_hash[lq];
+                // strong, and visited earlier: key = (hash, index), index order == (dl, dc) lexicographic order
+                bool earlier = hq < hp || (hq == hp && (dl < 0 || (dl == 0 && dc < 0)));
+                if (s_strong[lq] && earlier) keep |= 1u << bit;
             }
             dep[j] = keep;
         }
@@ -104,26 +129,44 @@ __global__ __launch_bounds__(256) void k_active_tile(const uint32_t *__restrict_
 #pragma unroll
         for (int j = 0; j < WORDS; ++j) dep[j] = 0;
     }
+    const int lp_own = ((threadIdx.x >> 4) + b) * tw + (threadIdx.x & 15) + b;
     for (int it = 0; it < inner_iters; ++it) {
         bool changed = false;
         if (pending) {
             bool any_in = false, wait = false;
+            // very first pass of a scale: every neighbour is still undecided, so only pixels without any earlier strong
+            // similar neighbour (local minima of the visiting order) can be decided -- no need to probe states
+            const bool skip_probe = first_launch && it == 0;
 #pragma unroll
             for (int j = 0; j < WORDS; ++j) {
                 uint32_t m = dep[j];
+                if (skip_probe) { wait = wait || m != 0; continue; }
                 while (m && !any_in) {
                     int bit = __ffs(m) - 1;
                     m &= m - 1;
                     int k = j * 32 + bit;
                     int dl = k / side - b, dc = k - (k / side) * side - b;
-                    uint8_t sq = vstate[(size_t)(r + dl) * W + (c + dc)];
+                    uint8_t sq = s_state[lp_own + dl * tw + dc];
                     if (sq == BCD_ST_IN) any_in = true;
                     else if (sq == BCD_ST_UNDECIDED) wait = true;
                     else dep[j] &= ~(1u << bit); // decided and not processed: can never mark p
                 }
             }
-            if (any_in) { state[p] = BCD_ST_OUT; pending = false; changed = true; }
-            else if (!wait) { state[p] = BCD_ST_IN; pending = false; changed = true; }
+            if (any_in) { state[p] = BCD_ST_OUT; s_state[lp_own] = BCD_ST_OUT; pending = false; changed = true; }
+            else if (!wait) { state[p] = BCD_ST_IN; s_state[lp_own] = BCD_ST_IN; pending = false; changed = true; }
+        }
+        // halo cells are owned by other workgroups running concurrently: re-read them (late values only delay decisions)
+        for (int i = threadIdx.x; i < tw * tw; i += 256) {
+            int lr = i / tw, lc = i - lr * tw;
+            if (lr >= b && lr < b + 16 && lc >= b && lc < b + 16) continue;
+            int gr = r0 + lr, gc = c0 + lc;
+            if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
+                uint8_t old = s_state[i];
+                if (old == BCD_ST_UNDECIDED) {
+                    uint8_t nv = vstate[(size_t)gr * W + gc];
+                    if (nv != old) { s_state[i] = nv; changed = true; }
+                }
+            }
         }
         if (!__syncthreads_or(changed)) break;
     }
@@ -190,14 +233,18 @@ hipError_t bcd_launch_active_lists(const uint8_t *state, const int32_t *nsim, in
 }
 
 hipError_t bcd_launch_active_tile(const uint32_t *mask, const int32_t *nsim, uint8_t *state, int W, int H, int b,
-                                  int min_strong, int random_order, uint32_t seed, int inner_iters, int *undecided, hipStream_t st)
+                                  int min_strong, int random_order, uint32_t seed, int inner_iters, int first_launch, int *undecided,
+                                  hipStream_t st)
 {
     int side = 2 * b + 1, words = (side * side + 31) / 32;
     dim3 grid((W + 15) / 16, (H + 15) / 16), block(256);
-    if (words == 6)
-        hipLaunchKernelGGL(k_active_tile<6>, grid, block, 0, st, mask, nsim, state, W, H, b, min_strong, random_order, seed, inner_iters, undecided);
-    else if (words == 20)
-        hipLaunchKernelGGL(k_active_tile<20>, grid, block, 0, st, mask, nsim, state, W, H, b, min_strong, random_order, seed, inner_iters, undecided);
+    const int tw = 16 + 2 * b;
+    const size_t lds = (size_t)tw * tw * 4 + 2 * (((size_t)tw * tw + 3) & ~(size_t)3);
+    (void)words;
+    if (b == 6)
+        hipLaunchKernelGGL(k_active_tile<6>, grid, block, lds, st, mask, nsim, state, W, H, min_strong, random_order, seed, inner_iters, first_launch, undecided);
+    else if (b == 12)
+        hipLaunchKernelGGL(k_active_tile<12>, grid, block, lds, st, mask, nsim, state, W, H, min_strong, random_order, seed, inner_iters, first_launch, undecided);
     else
         return hipErrorNotSupported;
     return hipGetLastError();
