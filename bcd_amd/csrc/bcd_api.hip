@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -50,30 +52,49 @@ struct DevBuf {
 
 } // namespace
 
+// everything one scale's pipeline needs: a multiscale run drives one Work per scale concurrently (own stream, own host
+// thread), because the scales are independent until the merge and the coarse ones cannot fill 256 CUs on their own
+struct Work {
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt; // grow-only
+    int32_t *h_counters = nullptr; // pinned
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; // pair-distance kernel timing
+    int ev_used = 0;
+    hipEvent_t ev_stage[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev_done = nullptr;
+};
+
 struct bcd_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     bool profiling = false;
+    bool concurrent_scales = true;
+    std::mutex err_mutex;
     std::string err;
     bcd_hip_scale_stats stats[MAX_SCALES];
-    // grow-only workspace
-    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, tmp_lo;
+    Work main;               // bound to `stream`
+    Work extra[MAX_SCALES];  // lazily created streams for scales 1.. of a multiscale run
+    DevBuf tmp_lo;
     DevBuf pyr[MAX_SCALES][5]; // colours, nsamples, hist, cov, out
-    int32_t *h_counters = nullptr; // pinned
-    // pair-distance kernel timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    int ev_used = 0;
-    hipEvent_t ev_stage[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev_pyramid = nullptr;
 };
 
 namespace {
+
+void set_err(bcd_hip_ctx *ctx, const std::string &msg)
+{
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lock(ctx->err_mutex);
+    ctx->err = msg;
+}
 
 #define HIPCHK(ctx, expr)                                                                                             \
     do {                                                                                                              \
         hipError_t e__ = (expr);                                                                                      \
         if (e__ != hipSuccess) {                                                                                      \
-            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                          \
+            set_err((ctx), std::string(#expr) + ": " + hipGetErrorString(e__));                                       \
             return BCD_HIP_EDEVICE;                                                                                   \
         }                                                                                                             \
     } while (0)
@@ -90,14 +111,14 @@ int ensure(bcd_hip_ctx *ctx, DevBuf &b, size_t bytes)
     if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
     size_t want = bytes + bytes / 16 + 256;
     hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) { ctx->err = "hipMalloc failed: " + std::string(hipGetErrorString(e)); b.p = nullptr; return BCD_HIP_ENOMEM; }
+    if (e != hipSuccess) { set_err(ctx, "hipMalloc failed: " + std::string(hipGetErrorString(e))); b.p = nullptr; return BCD_HIP_ENOMEM; }
     b.bytes = want;
     return BCD_HIP_OK;
 }
 
 int bad(bcd_hip_ctx *ctx, const char *msg)
 {
-    if (ctx) ctx->err = msg;
+    set_err(ctx, msg);
     return BCD_HIP_EINVAL;
 }
 
@@ -107,61 +128,61 @@ int check_params(bcd_hip_ctx *ctx, int W, int H, int D, const bcd_hip_params *pr
     if (W <= 0 || H <= 0 || D <= 0) return bad(ctx, "empty input image");            // Denoiser.cpp:294-320
     if (prm->patch_radius < 0 || prm->search_radius < 0) return bad(ctx, "negative radius");
     if (W < 2 * prm->patch_radius + 1 || H < 2 * prm->patch_radius + 1) return bad(ctx, "image smaller than a patch");
-    if (D > 255) { ctx->err = "histogram depth > 255 is not supported"; return BCD_HIP_EUNSUPPORTED; }
+    if (D > 255) { set_err(ctx, "histogram depth > 255 is not supported"); return BCD_HIP_EUNSUPPORTED; }
     int side = 2 * prm->search_radius + 1;
-    if ((side * side + 31) / 32 > 32) { ctx->err = "search radius > 15 is not supported"; return BCD_HIP_EUNSUPPORTED; }
+    if ((side * side + 31) / 32 > 32) { set_err(ctx, "search radius > 15 is not supported"); return BCD_HIP_EUNSUPPORTED; }
     if (bcd_bayes_lds_bytes(prm->patch_radius, prm->search_radius) > 160 * 1024) {
-        ctx->err = "patch/search radius combination exceeds the 160 KiB LDS working set";
+        set_err(ctx, "patch/search radius combination exceeds the 160 KiB LDS working set");
         return BCD_HIP_EUNSUPPORTED;
     }
     if ((int64_t)W * H >= (1ll << 31) / (D > 6 ? D : 6)) return bad(ctx, "image too large for 32-bit DeepImage indices");
     return BCD_HIP_OK;
 }
 
-int similarity(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
+int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
                uint32_t *d_mask, int32_t *d_count)
 {
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(b);
-    RCCHK(ensure(ctx, ctx->T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, ctx->Cn, npix * nd));
-    RCCHK(ensure(ctx, ctx->fwd, npix * ((nd + 31) / 32) * sizeof(uint32_t)));
+    RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
+    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.fwd, npix * ((nd + 31) / 32) * sizeof(uint32_t)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->ev_used < MAX_EVENT_PAIRS) {
-        if (ctx->ev_used == (int)ctx->ev_pool.size()) {
+    if (wk.ev_used < MAX_EVENT_PAIRS) {
+        if (wk.ev_used == (int)wk.ev_pool.size()) {
             hipEvent_t a, c;
             HIPCHK(ctx, hipEventCreate(&a));
             HIPCHK(ctx, hipEventCreate(&c));
-            ctx->ev_pool.emplace_back(a, c);
+            wk.ev_pool.emplace_back(a, c);
         }
-        e0 = ctx->ev_pool[ctx->ev_used].first;
-        e1 = ctx->ev_pool[ctx->ev_used].second;
-        ++ctx->ev_used;
-        HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+        e0 = wk.ev_pool[wk.ev_used].first;
+        e1 = wk.ev_pool[wk.ev_used].second;
+        ++wk.ev_used;
+        HIPCHK(ctx, hipEventRecord(e0, wk.stream));
     }
-    RCCHK(ensure(ctx, ctx->counters, 64 * sizeof(int32_t)));
-    int *d_flag = (int *)ctx->counters.p + 40;
-    HIPCHK(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
-    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, 1, d_flag, ctx->stream));
-    if (e1) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+    int *d_flag = (int *)wk.counters.p + 40;
+    HIPCHK(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), wk.stream));
+    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, 1, d_flag, wk.stream));
+    if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
     // the fast kernel flags inputs outside the range where its division is proven exact: redo with the compiler's division
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->h_counters[40] != 0)
-        HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, 0, d_flag, ctx->stream));
-    HIPCHK(ctx, bcd_launch_masks((const float *)ctx->T.p, (const uint8_t *)ctx->Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)ctx->fwd.p, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
+    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    if (wk.h_counters[40] != 0)
+        HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, 0, d_flag, wk.stream));
+    HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream));
     return BCD_HIP_OK;
 }
 
-int active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
+int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
                int row_end, float skip_prob, int random_order, uint32_t seed, uint8_t *d_state, int32_t *rounds_out)
 {
     const int K = 3 * (2 * w + 1) * (2 * w + 1);
-    HIPCHK(ctx, bcd_launch_active_init(d_nsim, W, H, w, row_begin, row_end, skip_prob, seed, d_state, ctx->stream));
+    HIPCHK(ctx, bcd_launch_active_init(d_nsim, W, H, w, row_begin, row_end, skip_prob, seed, d_state, wk.stream));
     int rounds = 0;
     if (skip_prob > 0.f) {
-        RCCHK(ensure(ctx, ctx->counters, 64 * sizeof(int32_t)));
-        int *d_cnt = (int *)ctx->counters.p;
+        RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+        int *d_cnt = (int *)wk.counters.p;
         const int max_rounds = 4 * (W + H) + 64;
         bool done = false;
         const int side = 2 * b + 1, words = (side * side + 31) / 32;
@@ -169,108 +190,134 @@ int active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_nsim, 
         (void)words;
         const int batch = tiled ? 2 : ROUND_BATCH;
         while (!done && rounds < max_rounds) {
-            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), wk.stream));
             for (int i = 0; i < batch; ++i) {
                 if (tiled)
-                    HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, getenv("BCD_INNER") ? atoi(getenv("BCD_INNER")) : 6, (rounds == 0 && i == 0 && skip_prob >= 1.f) ? 1 : 0, d_cnt + i, ctx->stream));
+                    HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, getenv("BCD_INNER") ? atoi(getenv("BCD_INNER")) : 6, (rounds == 0 && i == 0 && skip_prob >= 1.f) ? 1 : 0, d_cnt + i, wk.stream));
                 else
-                    HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, d_cnt + i, ctx->stream));
+                    HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, d_cnt + i, wk.stream));
             }
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(wk.h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, wk.stream));
+            HIPCHK(ctx, hipStreamSynchronize(wk.stream));
             for (int i = 0; i < batch; ++i) {
                 ++rounds;
-                if (ctx->h_counters[i] == 0) { done = true; break; }
+                if (wk.h_counters[i] == 0) { done = true; break; }
             }
         }
-        if (!done) { ctx->err = "marking fixed point did not converge"; return BCD_HIP_EDEVICE; }
+        if (!done) { set_err(ctx, "marking fixed point did not converge"); return BCD_HIP_EDEVICE; }
     }
     if (rounds_out) *rounds_out = rounds;
     return BCD_HIP_OK;
 }
 
-int bayes(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask, const int32_t *d_nsim,
+int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask, const int32_t *d_nsim,
           const uint8_t *d_state, int W, int H, int w, int b, float min_eig, float *d_sum, int32_t *d_count,
           int64_t *n_strong, int64_t *n_weak, int64_t *sim_total)
 {
     const int64_t npix = (int64_t)W * H;
     const int K = 3 * (2 * w + 1) * (2 * w + 1);
-    RCCHK(ensure(ctx, ctx->strong, npix * sizeof(int32_t)));
-    RCCHK(ensure(ctx, ctx->weak, npix * sizeof(int32_t)));
-    RCCHK(ensure(ctx, ctx->counters, 64 * sizeof(int32_t)));
-    int32_t *d_c = (int32_t *)ctx->counters.p + 16;
-    HIPCHK(ctx, hipMemsetAsync(d_c, 0, 4 * sizeof(int32_t), ctx->stream));
-    HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)ctx->strong.p, (int32_t *)ctx->weak.p, d_c, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    int ns = ctx->h_counters[16], nw = ctx->h_counters[17];
+    RCCHK(ensure(ctx, wk.strong, npix * sizeof(int32_t)));
+    RCCHK(ensure(ctx, wk.weak, npix * sizeof(int32_t)));
+    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+    int32_t *d_c = (int32_t *)wk.counters.p + 16;
+    HIPCHK(ctx, hipMemsetAsync(d_c, 0, 4 * sizeof(int32_t), wk.stream));
+    HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)wk.strong.p, (int32_t *)wk.weak.p, d_c, wk.stream));
+    HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream));
+    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    int ns = wk.h_counters[16], nw = wk.h_counters[17];
     int64_t tot;
-    memcpy(&tot, ctx->h_counters + 18, sizeof(tot));
+    memcpy(&tot, wk.h_counters + 18, sizeof(tot));
     if (n_strong) *n_strong = ns;
     if (n_weak) *n_weak = nw;
     if (sim_total) *sim_total = tot;
-    HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)ctx->strong.p, ns, W, H, w, b, min_eig, d_sum, d_count, ctx->stream));
-    HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)ctx->weak.p, nw, W, H, w, b, d_sum, d_count, ctx->stream));
+    HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, ns, W, H, w, b, min_eig, d_sum, d_count, wk.stream));
+    HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, nw, W, H, w, b, d_sum, d_count, wk.stream));
     return BCD_HIP_OK;
 }
 
-float stage_ms(bcd_hip_ctx *ctx, int a, int b)
+float stage_ms(Work &wk, int a, int b)
 {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, ctx->ev_stage[a], ctx->ev_stage[b]);
+    hipEventElapsedTime(&ms, wk.ev_stage[a], wk.ev_stage[b]);
     return ms;
 }
 
 // one scale: accumulators only (d_sum / d_count are zeroed here)
-int mono_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov,
+int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov,
                     int W, int H, int D, int row_begin, int row_end, const bcd_hip_params *prm, uint32_t seed, int scale,
                     float *d_sum, int32_t *d_count)
 {
     const int w = prm->patch_radius, b = prm->search_radius;
     const size_t npix = (size_t)W * H;
     const int side = 2 * b + 1, words = (side * side + 31) / 32;
-    RCCHK(ensure(ctx, ctx->pixcov, npix * 6 * sizeof(float)));
-    RCCHK(ensure(ctx, ctx->mask, npix * words * sizeof(uint32_t)));
-    RCCHK(ensure(ctx, ctx->nsim, npix * sizeof(int32_t)));
-    RCCHK(ensure(ctx, ctx->state, npix));
+    RCCHK(ensure(ctx, wk.pixcov, npix * 6 * sizeof(float)));
+    RCCHK(ensure(ctx, wk.mask, npix * words * sizeof(uint32_t)));
+    RCCHK(ensure(ctx, wk.nsim, npix * sizeof(int32_t)));
+    RCCHK(ensure(ctx, wk.state, npix));
     bcd_hip_scale_stats &st = ctx->stats[scale < MAX_SCALES ? scale : MAX_SCALES - 1];
     memset(&st, 0, sizeof(st));
     st.width = W; st.height = H;
     st.main_pixels = (int64_t)std::max(0, W - 2 * w) * std::max(0, std::min(row_end, H - w) - std::max(row_begin, w));
     const bool prof = ctx->profiling;
-    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev_stage[0], ctx->stream));
-    HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)ctx->pixcov.p, ctx->stream));
-    RCCHK(similarity(ctx, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)ctx->mask.p, (int32_t *)ctx->nsim.p));
-    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev_stage[1], ctx->stream));
-    RCCHK(active_set(ctx, (const uint32_t *)ctx->mask.p, (const int32_t *)ctx->nsim.p, W, H, w, b, row_begin, row_end,
-                     prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)ctx->state.p, &st.active_rounds));
-    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev_stage[2], ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), ctx->stream));
+    if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[0], wk.stream));
+    HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, wk.stream));
+    RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p));
+    if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
+    RCCHK(active_set(ctx, wk, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, W, H, w, b, row_begin, row_end,
+                     prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)wk.state.p, &st.active_rounds));
+    if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
+    HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.stream));
+    HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), wk.stream));
     int64_t ns = 0, nw = 0, tot = 0;
-    RCCHK(bayes(ctx, d_colors, (const float *)ctx->pixcov.p, (const uint32_t *)ctx->mask.p, (const int32_t *)ctx->nsim.p,
-                (const uint8_t *)ctx->state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count, &ns, &nw, &tot));
+    RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p,
+                (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count, &ns, &nw, &tot));
     st.processed = ns + nw; st.fallback = nw; st.similar_total = tot;
     if (prof) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_stage[3], ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        st.ms_similarity = stage_ms(ctx, 0, 1);
-        st.ms_active = stage_ms(ctx, 1, 2);
-        st.ms_bayes = stage_ms(ctx, 2, 3);
-        st.ms_total = stage_ms(ctx, 0, 3);
+        HIPCHK(ctx, hipEventRecord(wk.ev_stage[3], wk.stream));
+        HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+        st.ms_similarity = stage_ms(wk, 0, 1);
+        st.ms_active = stage_ms(wk, 1, 2);
+        st.ms_bayes = stage_ms(wk, 2, 3);
+        st.ms_total = stage_ms(wk, 0, 3);
     }
     return BCD_HIP_OK;
 }
 
-int mono(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov, int W, int H, int D,
+int mono(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov, int W, int H, int D,
          const bcd_hip_params *prm, uint32_t seed, int scale, float *d_out)
 {
     const size_t npix = (size_t)W * H;
-    RCCHK(ensure(ctx, ctx->sum, npix * 3 * sizeof(float)));
-    RCCHK(ensure(ctx, ctx->cnt, npix * sizeof(int32_t)));
-    RCCHK(mono_accumulate(ctx, d_colors, d_ns, d_hist, d_cov, W, H, D, 0, H, prm, seed, scale, (float *)ctx->sum.p, (int32_t *)ctx->cnt.p));
-    HIPCHK(ctx, bcd_launch_finalize((const float *)ctx->sum.p, (const int32_t *)ctx->cnt.p, (int64_t)npix, d_out, ctx->stream));
+    RCCHK(ensure(ctx, wk.sum, npix * 3 * sizeof(float)));
+    RCCHK(ensure(ctx, wk.cnt, npix * sizeof(int32_t)));
+    RCCHK(mono_accumulate(ctx, wk, d_colors, d_ns, d_hist, d_cov, W, H, D, 0, H, prm, seed, scale, (float *)wk.sum.p, (int32_t *)wk.cnt.p));
+    HIPCHK(ctx, bcd_launch_finalize((const float *)wk.sum.p, (const int32_t *)wk.cnt.p, (int64_t)npix, d_out, wk.stream));
     return BCD_HIP_OK;
+}
+
+
+int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
+{
+    if (w.h_counters) return BCD_HIP_OK; // already initialised
+    if (stream) w.stream = stream;
+    else {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        w.owns_stream = true;
+    }
+    HIPCHK(ctx, hipHostMalloc((void **)&w.h_counters, 64 * sizeof(int32_t), hipHostMallocDefault));
+    for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipEventCreate(&w.ev_stage[i]));
+    HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+    return BCD_HIP_OK;
+}
+
+void work_destroy(Work &w)
+{
+    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt };
+    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    if (w.h_counters) (void)hipHostFree(w.h_counters);
+    for (auto &pr : w.ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (int i = 0; i < 4; ++i) if (w.ev_stage[i]) (void)hipEventDestroy(w.ev_stage[i]);
+    if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+    if (w.owns_stream && w.stream) (void)hipStreamDestroy(w.stream);
 }
 
 } // namespace
@@ -313,9 +360,12 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
         if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return BCD_HIP_EDEVICE; }
         ctx->owns_stream = true;
     }
-    if (hipHostMalloc((void **)&ctx->h_counters, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { delete ctx; return BCD_HIP_ENOMEM; }
-    for (int i = 0; i < 4; ++i)
-        if (hipEventCreate(&ctx->ev_stage[i]) != hipSuccess) { delete ctx; return BCD_HIP_EDEVICE; }
+    if (work_init(ctx, ctx->main, ctx->stream) != BCD_HIP_OK || hipEventCreateWithFlags(&ctx->ev_pyramid, hipEventDisableTiming) != hipSuccess) {
+        bcd_hip_ctx_destroy(ctx);
+        return BCD_HIP_EDEVICE;
+    }
+    const char *env = getenv("BCD_HIP_SERIAL_SCALES");
+    ctx->concurrent_scales = !(env && env[0] == '1');
     *out = ctx;
     return BCD_HIP_OK;
 }
@@ -323,17 +373,15 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
 void bcd_hip_ctx_destroy(bcd_hip_ctx *ctx)
 {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = { &ctx->T, &ctx->Cn, &ctx->mask, &ctx->fwd, &ctx->nsim, &ctx->state, &ctx->strong, &ctx->weak, &ctx->counters,
-                       &ctx->pixcov, &ctx->sum, &ctx->cnt, &ctx->tmp_lo };
-    for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    work_destroy(ctx->main);
+    for (int s = 0; s < MAX_SCALES; ++s) work_destroy(ctx->extra[s]);
+    if (ctx->tmp_lo.p) (void)hipFree(ctx->tmp_lo.p);
     for (int s = 0; s < MAX_SCALES; ++s)
-        for (int k = 0; k < 5; ++k) if (ctx->pyr[s][k].p) hipFree(ctx->pyr[s][k].p);
-    if (ctx->h_counters) hipHostFree(ctx->h_counters);
-    for (auto &pr : ctx->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    for (int i = 0; i < 4; ++i) if (ctx->ev_stage[i]) hipEventDestroy(ctx->ev_stage[i]);
-    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+        for (int k = 0; k < 5; ++k) if (ctx->pyr[s][k].p) (void)hipFree(ctx->pyr[s][k].p);
+    if (ctx->ev_pyramid) (void)hipEventDestroy(ctx->ev_pyramid);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -343,6 +391,13 @@ int bcd_hip_set_profiling(bcd_hip_ctx *ctx, int enabled)
 {
     if (!ctx) return BCD_HIP_EINVAL;
     ctx->profiling = enabled != 0;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_set_concurrent_scales(bcd_hip_ctx *ctx, int enabled)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    ctx->concurrent_scales = enabled != 0;
     return BCD_HIP_OK;
 }
 
@@ -357,23 +412,32 @@ int bcd_hip_kernel_time(const bcd_hip_ctx *cctx, float *ms_pairdist, int32_t *la
 {
     bcd_hip_ctx *ctx = const_cast<bcd_hip_ctx *>(cctx);
     if (!ctx) return BCD_HIP_EINVAL;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
     float tot = 0.f;
-    for (int i = 0; i < ctx->ev_used; ++i) {
-        float ms = 0.f;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
-        tot += ms;
-    }
+    int count = 0;
+    Work *works[MAX_SCALES + 1];
+    works[0] = &ctx->main;
+    for (int s = 0; s < MAX_SCALES; ++s) works[s + 1] = &ctx->extra[s];
+    for (Work *w : works)
+        for (int i = 0; i < w->ev_used; ++i) {
+            float ms = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, w->ev_pool[i].first, w->ev_pool[i].second));
+            tot += ms;
+            ++count;
+        }
     if (ms_pairdist) *ms_pairdist = tot;
-    if (launches) *launches = ctx->ev_used;
+    if (launches) *launches = count;
     return BCD_HIP_OK;
 }
 
 int bcd_hip_reset_kernel_time(bcd_hip_ctx *ctx)
 {
     if (!ctx) return BCD_HIP_EINVAL;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->ev_used = 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    ctx->main.ev_used = 0;
+    for (int s = 0; s < MAX_SCALES; ++s) ctx->extra[s].ev_used = 0;
     return BCD_HIP_OK;
 }
 
@@ -385,7 +449,7 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
     RCCHK(check_params(ctx, W, H, D, prm));
     if (nb_scales < 1 || nb_scales > MAX_SCALES) return bad(ctx, "bad number of scales");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (nb_scales == 1) return mono(ctx, d_colors, d_ns, d_hist, d_cov, W, H, D, prm, bcd_hip_scale_seed(prm->order_seed, 0), 0, d_out);
+    if (nb_scales == 1) return mono(ctx, ctx->main, d_colors, d_ns, d_hist, d_cov, W, H, D, prm, bcd_hip_scale_seed(prm->order_seed, 0), 0, d_out);
 
     // ---- pyramids (MultiscaleDenoiser.cpp:41-53): level s has dims of level s-1 // 2
     const float *col[MAX_SCALES], *ns[MAX_SCALES], *hs[MAX_SCALES], *cv[MAX_SCALES];
@@ -408,9 +472,33 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
         col[s] = (float *)ctx->pyr[s][0].p; ns[s] = (float *)ctx->pyr[s][1].p; hs[s] = (float *)ctx->pyr[s][2].p;
         cv[s] = (float *)ctx->pyr[s][3].p; out[s] = (float *)ctx->pyr[s][4].p;
     }
-    // ---- coarse to fine (MultiscaleDenoiser.cpp:79-134)
+    // ---- the scales are independent until the merges (MultiscaleDenoiser.cpp:79-134 runs them coarse to fine, but each
+    // Denoiser only reads its own pyramid level): run them concurrently, one stream + host thread + workspace per scale
+    if (ctx->concurrent_scales) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pyramid, ctx->stream));
+        int rcs[MAX_SCALES];
+        std::thread threads[MAX_SCALES];
+        for (int s = 1; s < nb_scales; ++s) RCCHK(work_init(ctx, ctx->extra[s], nullptr));
+        for (int s = nb_scales - 1; s >= 0; --s) {
+            Work *w = s == 0 ? &ctx->main : &ctx->extra[s];
+            rcs[s] = BCD_HIP_OK;
+            auto job = [=, &rcs]() {
+                if (hipSetDevice(ctx->device) != hipSuccess) { rcs[s] = BCD_HIP_EDEVICE; return; }
+                if (s != 0 && hipStreamWaitEvent(w->stream, ctx->ev_pyramid, 0) != hipSuccess) { rcs[s] = BCD_HIP_EDEVICE; return; }
+                rcs[s] = mono(ctx, *w, col[s], ns[s], hs[s], cv[s], ws[s], hh[s], D, prm, bcd_hip_scale_seed(prm->order_seed, s), s, out[s]);
+                if (rcs[s] == BCD_HIP_OK && s != 0 && hipEventRecord(w->ev_done, w->stream) != hipSuccess) rcs[s] = BCD_HIP_EDEVICE;
+            };
+            if (s == 0) job(); else threads[s] = std::thread(job);
+        }
+        for (int s = 1; s < nb_scales; ++s) threads[s].join();
+        for (int s = 0; s < nb_scales; ++s) RCCHK(rcs[s]);
+        for (int s = 1; s < nb_scales; ++s) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->extra[s].ev_done, 0));
+        for (int s = nb_scales - 2; s >= 0; --s) RCCHK(bcd_hip_merge(ctx, out[s], ws[s], hh[s], out[s + 1], 3));
+        return BCD_HIP_OK;
+    }
+    // ---- coarse to fine, one after the other
     for (int s = nb_scales - 1; s >= 0; --s) {
-        RCCHK(mono(ctx, col[s], ns[s], hs[s], cv[s], ws[s], hh[s], D, prm, bcd_hip_scale_seed(prm->order_seed, s), s, out[s]));
+        RCCHK(mono(ctx, ctx->main, col[s], ns[s], hs[s], cv[s], ws[s], hh[s], D, prm, bcd_hip_scale_seed(prm->order_seed, s), s, out[s]));
         if (s < nb_scales - 1) RCCHK(bcd_hip_merge(ctx, out[s], ws[s], hh[s], out[s + 1], 3));
     }
     return BCD_HIP_OK;
@@ -425,7 +513,7 @@ int bcd_hip_denoise_band(bcd_hip_ctx *ctx, const float *d_colors, const float *d
     RCCHK(check_params(ctx, W, H, D, prm));
     if (main_row_begin < 0 || main_row_end > H || main_row_begin > main_row_end) return bad(ctx, "bad main row range");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    return mono_accumulate(ctx, d_colors, d_ns, d_hist, d_cov, W, H, D, main_row_begin, main_row_end, prm, order_seed, 0, d_sum, d_count);
+    return mono_accumulate(ctx, ctx->main, d_colors, d_ns, d_hist, d_cov, W, H, D, main_row_begin, main_row_end, prm, order_seed, 0, d_sum, d_count);
 }
 
 int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_ns, const float *h_hist, const float *h_cov,
@@ -441,11 +529,11 @@ int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h
     const float *src[4] = { h_colors, h_ns, h_hist, h_cov };
     int rc = BCD_HIP_OK;
     for (int i = 0; i < 5 && rc == BCD_HIP_OK; ++i)
-        if (hipMalloc((void **)&d[i], sz[i] * sizeof(float)) != hipSuccess) { ctx->err = "hipMalloc failed for host-path staging"; rc = BCD_HIP_ENOMEM; }
+        if (hipMalloc((void **)&d[i], sz[i] * sizeof(float)) != hipSuccess) { set_err(ctx, "hipMalloc failed for host-path staging"); rc = BCD_HIP_ENOMEM; }
     for (int i = 0; i < 4 && rc == BCD_HIP_OK; ++i)
-        if (hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D copy failed"; rc = BCD_HIP_EDEVICE; }
+        if (hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { set_err(ctx, "H2D copy failed"); rc = BCD_HIP_EDEVICE; }
     if (rc == BCD_HIP_OK) rc = bcd_hip_denoise(ctx, d[0], d[1], d[2], d[3], W, H, D, nb_scales, prm, d[4]);
-    if (rc == BCD_HIP_OK && hipMemcpyAsync(h_out, d[4], sz[4] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = BCD_HIP_EDEVICE; }
+    if (rc == BCD_HIP_OK && hipMemcpyAsync(h_out, d[4], sz[4] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { set_err(ctx, "D2H copy failed"); rc = BCD_HIP_EDEVICE; }
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 5; ++i) if (d[i]) hipFree(d[i]);
     return rc;
@@ -465,7 +553,7 @@ int bcd_hip_similarity_masks(bcd_hip_ctx *ctx, const float *d_hist, const float 
     if (!ctx || !d_hist || !d_ns || !d_mask || !d_count) return bad(ctx, "bad argument");
     bcd_hip_params p; bcd_hip_default_params(&p); p.patch_radius = w; p.search_radius = b;
     RCCHK(check_params(ctx, W, H, D, &p));
-    return similarity(ctx, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count);
+    return similarity(ctx, ctx->main, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count);
 }
 
 int bcd_hip_window_distances(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b,
@@ -477,11 +565,11 @@ int bcd_hip_window_distances(bcd_hip_ctx *ctx, const float *d_hist, const float 
     if (line < w || line > H - 1 - w || col < w || col > W - 1 - w) return bad(ctx, "not a main pixel");
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(b), n = (2 * b + 1) * (2 * b + 1);
-    RCCHK(ensure(ctx, ctx->T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, ctx->Cn, npix * nd));
+    RCCHK(ensure(ctx, ctx->main.T, npix * nd * sizeof(float)));
+    RCCHK(ensure(ctx, ctx->main.Cn, npix * nd));
     RCCHK(ensure(ctx, ctx->tmp_lo, n * sizeof(float)));
-    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->T.p, (uint8_t *)ctx->Cn.p, 0, nullptr, ctx->stream));
-    HIPCHK(ctx, bcd_launch_window_distances((const float *)ctx->T.p, (const uint8_t *)ctx->Cn.p, W, H, w, b, line, col, (float *)ctx->tmp_lo.p, ctx->stream));
+    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->main.T.p, (uint8_t *)ctx->main.Cn.p, 0, nullptr, ctx->stream));
+    HIPCHK(ctx, bcd_launch_window_distances((const float *)ctx->main.T.p, (const uint8_t *)ctx->main.Cn.p, W, H, w, b, line, col, (float *)ctx->tmp_lo.p, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->tmp_lo.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return BCD_HIP_OK;
@@ -492,7 +580,7 @@ int bcd_hip_active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *
                        uint8_t *d_state, int32_t *rounds)
 {
     if (!ctx || !d_mask || !d_count || !d_state) return bad(ctx, "bad argument");
-    return active_set(ctx, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, skip_probability, random_order, seed, d_state, rounds);
+    return active_set(ctx, ctx->main, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, skip_probability, random_order, seed, d_state, rounds);
 }
 
 int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask,
@@ -500,7 +588,7 @@ int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const floa
                              float *d_sum, int32_t *d_count)
 {
     if (!ctx || !d_colors || !d_pixcov || !d_mask || !d_nsim || !d_state || !d_sum || !d_count) return bad(ctx, "bad argument");
-    return bayes(ctx, d_colors, d_pixcov, d_mask, d_nsim, d_state, W, H, w, b, min_eig, d_sum, d_count, nullptr, nullptr, nullptr);
+    return bayes(ctx, ctx->main, d_colors, d_pixcov, d_mask, d_nsim, d_state, W, H, w, b, min_eig, d_sum, d_count, nullptr, nullptr, nullptr);
 }
 
 int bcd_hip_finalize(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int64_t npix, float *d_out)
@@ -569,8 +657,8 @@ int bcd_hip_zero_bad_values(bcd_hip_ctx *ctx, float *d_img, int64_t n)
 int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, int64_t *mismatches)
 {
     if (!ctx || !mismatches || samples <= 0) return bad(ctx, "bad argument");
-    RCCHK(ensure(ctx, ctx->counters, 64 * sizeof(int32_t)));
-    unsigned long long *d = reinterpret_cast<unsigned long long *>((int32_t *)ctx->counters.p + 32);
+    RCCHK(ensure(ctx, ctx->main.counters, 64 * sizeof(int32_t)));
+    unsigned long long *d = reinterpret_cast<unsigned long long *>((int32_t *)ctx->main.counters.p + 32);
     HIPCHK(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
     const int per_thread = 1024, blocks = (int)std::min<int64_t>(1 << 20, (samples + 256ll * per_thread - 1) / (256ll * per_thread));
     HIPCHK(ctx, bcd_launch_selftest_div(seed, blocks, per_thread, d, ctx->stream));

@@ -25,7 +25,7 @@ class ScaleStats(C.Structure):
 # every symbol include/bcd_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
-    "bcd_hip_set_profiling", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
+    "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_host",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
@@ -215,6 +215,9 @@ class Context:
     # ---- stats / timing
     def set_profiling(self, on):
         self._chk(lib().bcd_hip_set_profiling(self.h, 1 if on else 0))
+
+    def set_concurrent_scales(self, on):
+        self._chk(lib().bcd_hip_set_concurrent_scales(self.h, 1 if on else 0))
 
     def stats(self, scale):
         s = ScaleStats()

@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--random-order", type=int, default=1, help="-r of bcd_cli")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--band-path", action="store_true", help="use the multi-GPU row-band code path even with one rank (debug)")
-    ap.add_argument("--cpu-sample", default="480x270", help="frame size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample", default="960x540", help="frame size of the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -131,8 +131,21 @@ def main():
         elapsed = float(t.item())
     ms_step = elapsed * 1e3 / args.steps
 
-    # ---- roofline of the dominant kernel (pair-distance planes), HIP events on the engine's stream
+    # ---- roofline of the dominant kernel (pair-distance planes), HIP events on the engine's streams over the timed region
     pd_ms, pd_launches = ctx.kernel_time()
+    # the three scales run concurrently on separate streams, so a launch's event-to-event time includes the kernels it
+    # overlaps with; the same kernel timed in isolation (scales one after the other, two extra untimed steps):
+    iso_ms = None
+    if world == 1 and not args.band_path:
+        ctx.set_concurrent_scales(False)
+        step()
+        torch.cuda.synchronize()
+        ctx.reset_kernel_time()
+        step()
+        step()
+        iso_total, iso_n = ctx.kernel_time()
+        iso_ms = iso_total / max(1, iso_n)
+        ctx.set_concurrent_scales(True)
     scale_pixels = []
     for s in range(S):
         st = ctx.stats(s)
@@ -144,6 +157,8 @@ def main():
                 "kernel": "k_pairdist<60>", "launches": pd_launches,
                 "avg_launch_ms": round(pd_ms / max(1, pd_launches), 4),
                 "algorithmic_bytes_per_launch_avg": int(algo_bytes_per_step / S),
+                "isolated_avg_launch_ms": None if iso_ms is None else round(iso_ms, 4),
+                "isolated_frac": None if not iso_ms else round((algo_bytes_per_step / S) / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "note": "compute(VALU)-bound kernel: 85 displacements x 60 bins of IEEE-exact chi-square per pixel; see DESIGN.md"}
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file):

@@ -72,6 +72,9 @@ int  bcd_hip_device_count(void);
 void bcd_hip_default_params(bcd_hip_params *p);
 /* enable per-stage event timing into the stats (adds stream synchronisations) */
 int  bcd_hip_set_profiling(bcd_hip_ctx *ctx, int enabled);
+/* multiscale runs drive the (independent) scales concurrently, one HIP stream + host thread each (default on; also
+ * disabled by BCD_HIP_SERIAL_SCALES=1).  Results are identical either way. */
+int  bcd_hip_set_concurrent_scales(bcd_hip_ctx *ctx, int enabled);
 int  bcd_hip_get_stats(const bcd_hip_ctx *ctx, int scale, bcd_hip_scale_stats *out);
 /* duration (ms, HIP events on the context's stream) and launch count of the pair-distance kernel
  * accumulated since the last reset -- the dominant kernel measured by bench.py's roofline */

@@ -416,3 +416,22 @@ def test_mono_parity_large_search_window(hipctx):
     assert rel_linf(got, want) < TOL
     got0 = hipctx.denoise(*dev(col, ns, hist, cov), 1, bh.default_params(m=0.0, b=12)).cpu().numpy()
     assert rel_linf(got0, ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0, b=12))) < TOL
+
+
+def test_concurrent_and_serial_scales_agree(hipctx):
+    """the per-scale streams/threads of a multiscale run change scheduling only"""
+    import bcd_amd.hip as bh
+    W, H = 120, 88
+    col, ns, hist, cov, _ = inputs(W, H, 16, 0.12, 0.0)
+    d = dev(col, ns, hist, cov)
+    prm = bh.default_params(seed=4)
+    a = hipctx.denoise(*d, 3, prm).cpu().numpy()
+    sa = [(hipctx.stats(s).processed, hipctx.stats(s).fallback) for s in range(3)]
+    hipctx.set_concurrent_scales(False)
+    try:
+        b_ = hipctx.denoise(*d, 3, prm).cpu().numpy()
+        sb = [(hipctx.stats(s).processed, hipctx.stats(s).fallback) for s in range(3)]
+    finally:
+        hipctx.set_concurrent_scales(True)
+    assert sa == sb
+    assert rel_linf(a, b_) < 1e-5
