@@ -516,6 +516,48 @@ int bcd_hip_denoise_band(bcd_hip_ctx *ctx, const float *d_colors, const float *d
     return mono_accumulate(ctx, ctx->main, d_colors, d_ns, d_hist, d_cov, W, H, D, main_row_begin, main_row_end, prm, order_seed, 0, d_sum, d_count);
 }
 
+int bcd_hip_denoise_bands(bcd_hip_ctx *ctx, const bcd_hip_band_job *jobs, int njobs, const bcd_hip_params *prm)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    if (!jobs || njobs < 1 || njobs > MAX_SCALES) return bad(ctx, "bad job list");
+    for (int i = 0; i < njobs; ++i) {
+        const bcd_hip_band_job &j = jobs[i];
+        if (!j.d_colors || !j.d_nsamples || !j.d_histograms || !j.d_covariances || !j.d_sum || !j.d_count) return bad(ctx, "null image pointer");
+        RCCHK(check_params(ctx, j.W, j.H, j.D, prm));
+        if (j.main_row_begin < 0 || j.main_row_end > j.H || j.main_row_begin > j.main_row_end) return bad(ctx, "bad main row range");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->concurrent_scales || njobs == 1) {
+        for (int i = 0; i < njobs; ++i) {
+            const bcd_hip_band_job &j = jobs[i];
+            RCCHK(mono_accumulate(ctx, ctx->main, j.d_colors, j.d_nsamples, j.d_histograms, j.d_covariances, j.W, j.H, j.D, j.main_row_begin,
+                                  j.main_row_end, prm, j.order_seed, i, j.d_sum, j.d_count));
+        }
+        return BCD_HIP_OK;
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_pyramid, ctx->stream)); // inputs were produced on the context's stream
+    int rcs[MAX_SCALES];
+    std::thread threads[MAX_SCALES];
+    for (int i = 1; i < njobs; ++i) RCCHK(work_init(ctx, ctx->extra[i], nullptr));
+    for (int i = njobs - 1; i >= 0; --i) {
+        Work *w = i == 0 ? &ctx->main : &ctx->extra[i];
+        const bcd_hip_band_job j = jobs[i];
+        rcs[i] = BCD_HIP_OK;
+        auto job = [=, &rcs]() {
+            if (hipSetDevice(ctx->device) != hipSuccess) { rcs[i] = BCD_HIP_EDEVICE; return; }
+            if (i != 0 && hipStreamWaitEvent(w->stream, ctx->ev_pyramid, 0) != hipSuccess) { rcs[i] = BCD_HIP_EDEVICE; return; }
+            rcs[i] = mono_accumulate(ctx, *w, j.d_colors, j.d_nsamples, j.d_histograms, j.d_covariances, j.W, j.H, j.D, j.main_row_begin,
+                                     j.main_row_end, prm, j.order_seed, i, j.d_sum, j.d_count);
+            if (rcs[i] == BCD_HIP_OK && i != 0 && hipEventRecord(w->ev_done, w->stream) != hipSuccess) rcs[i] = BCD_HIP_EDEVICE;
+        };
+        if (i == 0) job(); else threads[i] = std::thread(job);
+    }
+    for (int i = 1; i < njobs; ++i) threads[i].join();
+    for (int i = 0; i < njobs; ++i) RCCHK(rcs[i]);
+    for (int i = 1; i < njobs; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->extra[i].ev_done, 0));
+    return BCD_HIP_OK;
+}
+
 int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_ns, const float *h_hist, const float *h_cov,
                          int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out)
 {

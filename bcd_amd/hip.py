@@ -16,6 +16,12 @@ class Params(C.Structure):
                 ("marked_skip_probability", C.c_float), ("order_seed", C.c_uint32)]
 
 
+class BandJob(C.Structure):
+    _fields_ = [("d_colors", C.c_void_p), ("d_nsamples", C.c_void_p), ("d_histograms", C.c_void_p), ("d_covariances", C.c_void_p),
+                ("W", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("main_row_begin", C.c_int32), ("main_row_end", C.c_int32),
+                ("order_seed", C.c_uint32), ("d_sum", C.c_void_p), ("d_count", C.c_void_p)]
+
+
 class ScaleStats(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("main_pixels", C.c_int64), ("processed", C.c_int64),
                 ("fallback", C.c_int64), ("similar_total", C.c_int64), ("active_rounds", C.c_int32),
@@ -26,7 +32,7 @@ class ScaleStats(C.Structure):
 SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
     "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
-    "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_host",
+    "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_zero_bad_values",
@@ -116,6 +122,14 @@ class Context:
         H, W, D = hist.shape
         self._chk(lib().bcd_hip_denoise_band(self.h, _dp(col), _dp(ns), _dp(hist), _dp(cov), W, H, D, row_begin, row_end,
                                              C.byref(prm), C.c_uint32(seed), _dp(sum_), _dp(cnt)))
+
+    def denoise_bands(self, jobs, prm):
+        """jobs: list of (col, ns, hist, cov, row_begin, row_end, seed, sum, cnt) device tensors; run concurrently"""
+        arr = (BandJob * len(jobs))()
+        for i, (col, ns, hist, cov, r0, r1, seed, s, c) in enumerate(jobs):
+            H, W, D = hist.shape
+            arr[i] = BandJob(_dp(col).value, _dp(ns).value, _dp(hist).value, _dp(cov).value, W, H, D, r0, r1, seed, _dp(s).value, _dp(c).value)
+        self._chk(lib().bcd_hip_denoise_bands(self.h, arr, len(jobs), C.byref(prm)))
 
     def denoise_host(self, col, ns, hist, cov, nscales, prm):
         import numpy as np

@@ -6,10 +6,12 @@ The reference is single-process; this is the build's own decom
     (MultiscaleDenoiser.cpp:256-266 of the reference);
   * a rank holds, per scale, its band plus (b+w) halo lines of INPUT on each interior side (more where the
     coarser level needs them) -- no input exchange at run time;
-  * per scale there are three neighbour exchanges (the only communication, point-to-point, <= 1 MB):
-      1. accumulator halos: the (b+w) lines of sum(3)+count(1) written outside the owned band,
-      2. two lines of the finalised (unmerged) output, needed by `hi - up(down(hi))` at the band edge,
-      3. one line of the merged output, needed by `up(lo)` of the next finer scale.
+  * the scales' bands go through the denoiser concurrently, then S neighbour exchanges per frame (the only communication,
+    point-to-point, <= 1 MB each):
+      1. accumulator halos of ALL scales: the (b+w) lines of sum(3)+count(1) written outside the owned band,
+      2. two lines of every finalised (unmerged) finer output, needed by `hi - up(down(hi))` at the band edge, and one line
+         of the coarsest output,
+      3. per intermediate scale, one line of the merged output, needed by `up(lo)` of the next finer scale.
     No collective is involved; with torch.distributed these are batched isend/irecv over RCCL (xGMI).
   * `-m 1` marking runs per band (each rank's fixed point sees only its own pixels): a valid greedy order, but not
     the single-GPU image; `-m 0` is order-free and matches the single-GPU result to fp32 round-off.
@@ -95,47 +97,68 @@ def band_program(eng, geom, rank, col, ns, hist, cov, prm, seed0):
         nss.append(eng.downscale_sum(nss[s - 1][a:b_]))
         hists.append(eng.downscale_sum(hists[s - 1][a:b_]))
         covs.append(eng.downscale_cov(covs[s - 1][a:b_], nss[s - 1][a:b_]))
-    outs = [None] * S
-    for s in range(S - 1, -1, -1):
+    # ---- A. every scale's band through the denoiser (independent of each other: the engine may run them concurrently);
+    # a scale only needs its owned lines +- (b+w), the rest of the local band exists to build the coarser pyramid levels
+    jobs, spans = [], []
+    for s in range(S):
         sb = bands[s]
         o0, o1 = sb.own0 - sb.loc0, sb.own1 - sb.loc0           # owned lines, local indices
-        sum_, cnt = eng.accumulate_band(cols[s], nss[s], hists[s], covs[s], o0, o1, prm, eng.scale_seed(seed0, s), s)
-        # 1. accumulator halos
-        send_up = [sum_[o0 - halo:o0].contiguous(), cnt[o0 - halo:o0].contiguous()] if up else None
-        send_down = [sum_[o1:o1 + halo].contiguous(), cnt[o1:o1 + halo].contiguous()] if down else None
-        got_up, got_down = yield ("acc%d" % s, send_up, send_down)
+        a0 = o0 - halo if up else 0
+        a1 = o1 + halo if down else sb.loc1 - sb.loc0
+        spans.append((o0, o1, a0, a1))
+        jobs.append((cols[s][a0:a1], nss[s][a0:a1], hists[s][a0:a1], covs[s][a0:a1], o0 - a0, o1 - a0, eng.scale_seed(seed0, s), s))
+    accs = eng.accumulate_bands(jobs, prm)                       # [(sum, count)] indexed like [a0, a1)
+    # ---- B. one exchange for the accumulator halos of all scales
+    send_up = [t[:halo].contiguous() for acc in accs for t in acc] if up else None
+    send_down = [t[-halo:].contiguous() for acc in accs for t in acc] if down else None
+    got_up, got_down = yield ("acc", send_up, send_down)
+    outs = [None] * S
+    for s in range(S):
+        sb = bands[s]
+        o0, o1, a0, a1 = spans[s]
+        sum_, cnt = accs[s]
         if up:
-            sum_[o0:o0 + halo] += got_up[0]
-            cnt[o0:o0 + halo] += got_up[1]
+            sum_[o0 - a0:o0 - a0 + halo] += got_up[2 * s]
+            cnt[o0 - a0:o0 - a0 + halo] += got_up[2 * s + 1]
         if down:
-            sum_[o1 - halo:o1] += got_down[0]
-            cnt[o1 - halo:o1] += got_down[1]
-        out = eng.finalize(sum_, cnt)                             # valid on owned lines
-        if s < S - 1:
-            # 2. two lines of the unmerged output each side, then merge on [own0-2, own1+2)
-            send_up = [out[o0:o0 + 2].contiguous()] if up else None
-            send_down = [out[o1 - 2:o1].contiguous()] if down else None
-            got_up, got_down = yield ("out%d" % s, send_up, send_down)
+            sum_[o1 - a0 - halo:o1 - a0] += got_down[2 * s]
+            cnt[o1 - a0 - halo:o1 - a0] += got_down[2 * s + 1]
+        fin = eng.finalize(sum_, cnt)                             # valid on owned lines
+        out = eng.zeros_like_rows(fin, sb.loc1 - sb.loc0)
+        out[o0:o1] = fin[o0 - a0:o1 - a0]
+        outs[s] = out
+    # ---- C. one exchange: two lines of every unmerged finer output (for hi - up(down(hi)) at the band edge) and one line of
+    # the coarsest output (for up(lo) of the scale above it)
+    def edge(s, n, top):
+        o0, o1 = spans[s][0], spans[s][1]
+        return outs[s][o0:o0 + n].contiguous() if top else outs[s][o1 - n:o1].contiguous()
+    lines = [2] * (S - 1) + [1]
+    if S > 1:
+        send_up = [edge(s, lines[s], True) for s in range(S)] if up else None
+        send_down = [edge(s, lines[s], False) for s in range(S)] if down else None
+        got_up, got_down = yield ("out", send_up, send_down)
+        for s in range(S):
+            o0, o1 = spans[s][0], spans[s][1]
             if up:
-                out[o0 - 2:o0] = got_up[0]
+                outs[s][o0 - lines[s]:o0] = got_up[s]
             if down:
-                out[o1:o1 + 2] = got_down[0]
-            m0 = o0 - 2 if up else o0
-            m1 = o1 + 2 if down else o1
-            nb = bands[s + 1]
-            lo = outs[s + 1]
-            g_lo0 = (sb.loc0 + m0) // 2 - nb.loc0                 # local line of the coarser level under local line m0
-            out[m0:m1] = eng.merge(out[m0:m1], lo[g_lo0:g_lo0 + (m1 - m0) // 2])
+                outs[s][o1:o1 + lines[s]] = got_down[s]
+    # ---- D. merges coarse to fine; between two merges one line of the freshly merged output travels
+    for s in range(S - 2, -1, -1):
+        sb, nb = bands[s], bands[s + 1]
+        o0, o1 = spans[s][0], spans[s][1]
+        m0 = o0 - 2 if up else o0
+        m1 = o1 + 2 if down else o1
+        g_lo0 = (sb.loc0 + m0) // 2 - nb.loc0                     # local line of the coarser level under local line m0
+        outs[s][m0:m1] = eng.merge(outs[s][m0:m1], outs[s + 1][g_lo0:g_lo0 + (m1 - m0) // 2])
         if s > 0:
-            # 3. one line of the merged output each side, for up(lo) of the next finer scale
-            send_up = [out[o0:o0 + 1].contiguous()] if up else None
-            send_down = [out[o1 - 1:o1].contiguous()] if down else None
+            send_up = [outs[s][o0:o0 + 1].contiguous()] if up else None
+            send_down = [outs[s][o1 - 1:o1].contiguous()] if down else None
             got_up, got_down = yield ("mrg%d" % s, send_up, send_down)
             if up:
-                out[o0 - 1:o0] = got_up[0]
+                outs[s][o0 - 1:o0] = got_up[0]
             if down:
-                out[o1:o1 + 1] = got_down[0]
-        outs[s] = out
+                outs[s][o1:o1 + 1] = got_down[0]
     sb = bands[0]
     return outs[0][sb.own0 - sb.loc0:sb.own1 - sb.loc0]
 
@@ -220,6 +243,7 @@ class HipEngine:
         return self.ctx.downscale_cov(cov.contiguous(), ns.contiguous())
 
     def accumulate_band(self, col, ns, hist, cov, row0, row1, prm, seed, scale):
+        col, ns, hist, cov = col.contiguous(), ns.contiguous(), hist.contiguous(), cov.contiguous()
         H, W, _ = hist.shape
         key = (scale, H, W)
         if key not in self._acc or not self.reuse_buffers:
@@ -228,6 +252,25 @@ class HipEngine:
         s, c = self._acc[key]
         self.ctx.denoise_band(col, ns, hist, cov, row0, row1, prm, seed, s, c)
         return s, c
+
+    def accumulate_bands(self, jobs, prm):
+        """jobs: (col, ns, hist, cov, row0, row1, seed, scale); all bands through the engine concurrently"""
+        torch, cj, out = self.torch, [], []
+        for (col, ns, hist, cov, r0, r1, seed, scale) in jobs:
+            col, ns, hist, cov = col.contiguous(), ns.contiguous(), hist.contiguous(), cov.contiguous()
+            H, W, _ = hist.shape
+            key = (scale, H, W)
+            if key not in self._acc or not self.reuse_buffers:
+                self._acc[key] = (torch.empty((H, W, 3), dtype=torch.float32, device=hist.device),
+                                  torch.empty((H, W), dtype=torch.int32, device=hist.device))
+            s, c = self._acc[key]
+            cj.append((col, ns, hist, cov, r0, r1, seed, s, c))
+            out.append((s, c))
+        self.ctx.denoise_bands(cj, prm)
+        return out
+
+    def zeros_like_rows(self, t, rows):
+        return self.torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
 
     def finalize(self, s, c):
         return self.ctx.finalize(s, c)

@@ -97,6 +97,17 @@ int bcd_hip_denoise_band(bcd_hip_ctx *ctx, const float *d_colors, const float *d
                          int W, int H, int D, int main_row_begin, int main_row_end,
                          const bcd_hip_params *prm, uint32_t order_seed, float *d_sum, int32_t *d_count);
 
+/* several bands at once -- the per-scale bands of one rank in the multi-GPU path -- run concurrently (job i on its own
+ * stream / host thread / workspace, stats slot i), like the scales of bcd_hip_denoise() */
+typedef struct bcd_hip_band_job {
+    const float *d_colors, *d_nsamples, *d_histograms, *d_covariances;
+    int32_t W, H, D, main_row_begin, main_row_end;
+    uint32_t order_seed;
+    float *d_sum;
+    int32_t *d_count;
+} bcd_hip_band_job;
+int bcd_hip_denoise_bands(bcd_hip_ctx *ctx, const bcd_hip_band_job *jobs, int njobs, const bcd_hip_params *prm);
+
 /* ---- whole path, host buffers (what bcd::Denoiser / bcd_cli call): H2D + denoise + D2H -------- */
 int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_nsamples,
                          const float *h_histograms, const float *h_covariances,

@@ -46,6 +46,12 @@ class OracleEngine:
         assert rc == 0
         return torch.from_numpy(s), torch.from_numpy(c)
 
+    def accumulate_bands(self, jobs, prm):
+        return [self.accumulate_band(col, ns, hist, cov, r0, r1, prm, seed, scale) for (col, ns, hist, cov, r0, r1, seed, scale) in jobs]
+
+    def zeros_like_rows(self, t, rows):
+        return torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype)
+
     def finalize(self, s, c):
         out = np.empty(tuple(s.shape), np.float32)
         with np.errstate(all="ignore"):
