@@ -193,7 +193,7 @@ int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t
             HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), wk.stream));
             for (int i = 0; i < batch; ++i) {
                 if (tiled)
-                    HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, getenv("BCD_INNER") ? atoi(getenv("BCD_INNER")) : 6, (rounds == 0 && i == 0 && skip_prob >= 1.f) ? 1 : 0, d_cnt + i, wk.stream));
+                    HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, 6 /* in-tile iterations per launch */, (rounds == 0 && i == 0 && skip_prob >= 1.f) ? 1 : 0, d_cnt + i, wk.stream));
                 else
                     HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, d_cnt + i, wk.stream));
             }

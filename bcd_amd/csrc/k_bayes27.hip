@@ -17,7 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 
-__device__ long long bcd_dbg_cycles[16];
+// per-phase cycle counters of one wavefront, filled only by the DBG instantiation (BCD_DBG_BAYES=1: printed after the launch)
+__device__ long long bcd_dbg_cycles[24];
 
 namespace {
 
@@ -82,7 +83,6 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
         }
         off = wsum(off);
         dg = wsum(dg);
-        if (blockIdx.x == 100 && lane == 0) { bcd_dbg_cycles[12] = sweep; reinterpret_cast<float *>(bcd_dbg_cycles + 13)[sweep < 6 ? sweep : 5] = off / dg; }
         if (off <= 1e-13f * dg) break;
         for (int round = 0; round < KP - 1; ++round) {
             float *Ac = cur ? A1 : A0, *An = cur ? A0 : A1, *Vc = cur ? V1 : V0, *Vn = cur ? V0 : V1;
@@ -452,14 +452,12 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     if (g.words > 32) return hipErrorInvalidValue;
     if (getenv("BCD_DBG_BAYES")) {
         hipLaunchKernelGGL(k_bayes27<true>, dim3(nlist), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
-        long long h[16];
+        long long h[24];
         hipStreamSynchronize(st);
         hipMemcpyFromSymbol(h, HIP_SYMBOL(bcd_dbg_cycles), sizeof(h));
-        { float *fr = reinterpret_cast<float *>(h + 13); fprintf(stderr, "sweeps %lld ratios %g %g %g %g %g %g\n", h[12], fr[0], fr[1], fr[2], fr[3], fr[4], fr[5]); }
         fprintf(stderr, "bayes27 dbg n=%lld: decode %lld noise %lld mean %lld cov %lld jacobi %lld rebuild %lld inv1 %lld step2mm %lld inv2 %lld final %lld total %lld\n", h[11], h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5], h[7]-h[6], h[8]-h[7], h[9]-h[8], h[10]-h[9], h[10]-h[0]);
         return hipGetLastError();
     }
-    { const char *pad = getenv("BCD_BAYES_LDS_PAD"); if (pad) { size_t lds2 = bcd_bayes27_lds_bytes(b) + (size_t)atoi(pad); hipLaunchKernelGGL(k_bayes27<false>, dim3(nlist), dim3(64), lds2, st, colors, pixcov, mask, list, g, min_eig, sum, cnt); return hipGetLastError(); } }
     hipLaunchKernelGGL(k_bayes27<false>, dim3(nlist), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
     return hipGetLastError();
 }
