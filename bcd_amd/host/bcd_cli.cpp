@@ -3,11 +3,13 @@
 // Real defaults are -r 1 and -p 1 (main.cpp:52-53) although the reference's README says 0.  Missing -h / -c are
 // inferred as <input>_hist.exr / <input>_cov.exr (:344-370).  Extra flags of this build: --seed <n> (visiting
 // order), --device <n>.  --ncores and --use-cuda are accepted and ignored (the loop runs on the HIP device).
+// -a <file.bcd.json> (advertised but never parsed by the reference, main.cpp:107) loads a preset; later flags override it.
 #include "Chronometer.h"
 #include "DeepImage.h"
 #include "Denoiser.h"
 #include "ImageIO.h"
 #include "MultiscaleDenoiser.h"
+#include "ParametersIO.h"
 #include "SpikeRemovalFilter.h"
 #include "Utils.h"
 
@@ -57,6 +59,7 @@ namespace
 		cout << "    -h <hist>            The file path to the input histograms buffer (default: <input>_hist.exr)" << endl;
 		cout << "    -c <cov>             The file path to the input covariance matrices buffer (default: <input>_cov.exr)" << endl;
 		cout << "Optional arguments list:" << endl;
+		cout << "    -a <file>            The file path to the .bcd.json file containing arguments for the program" << endl;
 		cout << "    -d <float>           Histogram patch distance threshold (default: " << d.m_histogramPatchDistanceThreshold << ")" << endl;
 		cout << "    -b <int>             Radius of search windows (default: " << d.m_searchWindowRadius << ")" << endl;
 		cout << "    -w <int>             Radius of patches (default: " << d.m_patchRadius << ")" << endl;
@@ -106,6 +109,43 @@ namespace
 			{
 				if(!ImageIO::loadMultiChannelsEXR(a.m_covarianceImage, value)) { cout << "ERROR in program arguments: couldn't load input covariance matrix image file '" << value << "'" << endl; return false; }
 				missingCov = false;
+			}
+			else if(flag == "-a")
+			{
+				PipelineParameters preset;
+				preset.m_prefilteringParameters.m_performSpikeRemoval = a.m_prefilterSpikes;
+				preset.m_prefilteringParameters.m_spikeRemovalThresholdStDevFactor = a.m_prefilterThresholdStDevFactor;
+				preset.m_denoiserParameters.m_nbOfScales = a.m_nbOfScales;
+				DenoiserParameters& p = preset.m_denoiserParameters.m_monoscaleParameters;
+				p.m_histogramDistanceThreshold = a.m_histogramPatchDistanceThreshold; p.m_patchRadius = a.m_patchRadius;
+				p.m_searchWindowRadius = a.m_searchWindowRadius; p.m_minEigenValue = a.m_minEigenValue;
+				p.m_useRandomPixelOrder = a.m_useRandomPixelOrder; p.m_markedPixelsSkippingProbability = a.m_markedPixelsSkippingProbability;
+				if(!ParametersIO::load(preset, value)) { cout << "ERROR in program arguments: couldn't load the parameters file '" << value << "'" << endl; return false; }
+				a.m_prefilterSpikes = preset.m_prefilteringParameters.m_performSpikeRemoval;
+				a.m_prefilterThresholdStDevFactor = preset.m_prefilteringParameters.m_spikeRemovalThresholdStDevFactor;
+				a.m_nbOfScales = preset.m_denoiserParameters.m_nbOfScales;
+				a.m_histogramPatchDistanceThreshold = p.m_histogramDistanceThreshold; a.m_patchRadius = p.m_patchRadius;
+				a.m_searchWindowRadius = p.m_searchWindowRadius; a.m_minEigenValue = p.m_minEigenValue;
+				a.m_useRandomPixelOrder = p.m_useRandomPixelOrder; a.m_markedPixelsSkippingProbability = p.m_markedPixelsSkippingProbability;
+				const InputFileNames& names = preset.m_inputFileNames;
+				if(!names.m_colors.empty() && missingColor)
+				{
+					inputColorFilePath = names.m_colors;
+					if(!ImageIO::loadEXR(a.m_colorImage, names.m_colors.c_str())) { cout << "ERROR in program arguments: couldn't load input color image file '" << names.m_colors << "'" << endl; return false; }
+					missingColor = false;
+				}
+				if(!names.m_histograms.empty() && missingHist)
+				{
+					Deepimf histAndNbOfSamplesImage;
+					if(!ImageIO::loadMultiChannelsEXR(histAndNbOfSamplesImage, names.m_histograms.c_str())) { cout << "ERROR in program arguments: couldn't load input histogram image file '" << names.m_histograms << "'" << endl; return false; }
+					Utils::separateNbOfSamplesFromHistogram(a.m_histogramImage, a.m_nbOfSamplesImage, histAndNbOfSamplesImage);
+					missingHist = false;
+				}
+				if(!names.m_covariances.empty() && missingCov)
+				{
+					if(!ImageIO::loadMultiChannelsEXR(a.m_covarianceImage, names.m_covariances.c_str())) { cout << "ERROR in program arguments: couldn't load input covariance matrix image file '" << names.m_covariances << "'" << endl; return false; }
+					missingCov = false;
+				}
 			}
 			else if(flag == "-d") { a.m_histogramPatchDistanceThreshold = float(atof(value)); if(a.m_histogramPatchDistanceThreshold <= 0.f) return badValue("-d", "expecting a positive floating number"); }
 			else if(flag == "-b") { a.m_searchWindowRadius = atoi(value); if(a.m_searchWindowRadius < 0) return badValue("-b", "expecting a non-negative integer"); }

@@ -7,6 +7,7 @@
 #include "SyntheticScene.h"
 #include "Utils.h"
 
+#include <cstdio>
 #include <memory>
 
 using namespace bcd;
@@ -130,5 +131,27 @@ int bcdcore_read_exr(const char* path, int multiChannels, int* W, int* H, int* D
 }
 
 const char* bcdcore_exr_last_error() { return ImageIO::lastError().c_str(); }
+
+} // extern "C"
+
+// ---- .bcd.json presets (ParametersIO) ----------------------------------------------------------------------------
+#include "ParametersIO.h"
+
+extern "C" {
+
+// round trip helper for the tests: loads `in` over the defaults, writes everything to `out`, returns a few fields
+int bcdcore_presets_roundtrip(const char* in, const char* out, int* nbOfScales, float* tau, int* b, int* randomOrder, float* m, float* minEig,
+		int* spike, float* spikeFactor, char* colorPath, int colorPathCapacity)
+{
+	PipelineParameters p;
+	if(!ParametersIO::load(p, in)) return -1;
+	if(out && !ParametersIO::write(p, out)) return -2;
+	const DenoiserParameters& d = p.m_denoiserParameters.m_monoscaleParameters;
+	*nbOfScales = p.m_denoiserParameters.m_nbOfScales; *tau = d.m_histogramDistanceThreshold; *b = d.m_searchWindowRadius;
+	*randomOrder = d.m_useRandomPixelOrder ? 1 : 0; *m = d.m_markedPixelsSkippingProbability; *minEig = d.m_minEigenValue;
+	*spike = p.m_prefilteringParameters.m_performSpikeRemoval ? 1 : 0; *spikeFactor = p.m_prefilteringParameters.m_spikeRemovalThresholdStDevFactor;
+	snprintf(colorPath, size_t(colorPathCapacity), "%s", p.m_inputFileNames.m_colors.c_str());
+	return 0;
+}
 
 } // extern "C"

@@ -156,3 +156,33 @@ def test_cli_usage_and_argument_errors():
     assert r.returncode == 1 and "between 0 and 1" in r.stdout
     r = subprocess.run([exe, "-i", "/nonexistent.exr"], capture_output=True, text=True)
     assert r.returncode == 1 and "couldn't load input color image" in r.stdout
+
+
+def test_bcd_json_presets_roundtrip(tmp_path):
+    import ctypes as C
+    import json
+    lib = core.lib()
+    src = tmp_path / "scene.bcd.json"
+    src.write_text(json.dumps({"inputColorFile": "img/frame.exr", "inputHistoFile": "img/frame_hist.exr", "inputCovarFile": "img/frame_cov.exr",
+                               "nbOfScales": 2, "histoDistanceThreshold": 0.75, "searchWindowRadius": 9, "randomPixelOrder": False,
+                               "markedPixelsSkippingProbability": 0.5, "minEigenValue": 1e-6, "useCuda": True, "nbOfCores": 4,
+                               "performSpikeRemovalPrefiltering": False, "spikeRemovalThresholdStDevFactor": 2.5,
+                               "someFutureKey": {"nested": [1, 2, {"x": "}"}]}}, indent=2))
+    out = tmp_path / "copy.bcd.json"
+    S, tau, b, r, m, e, sp, sf = C.c_int(), C.c_float(), C.c_int(), C.c_int(), C.c_float(), C.c_float(), C.c_int(), C.c_float()
+    path = C.create_string_buffer(512)
+    rc = lib.bcdcore_presets_roundtrip(str(src).encode(), str(out).encode(), C.byref(S), C.byref(tau), C.byref(b), C.byref(r), C.byref(m),
+                                       C.byref(e), C.byref(sp), C.byref(sf), path, 512)
+    assert rc == 0
+    assert (S.value, b.value, r.value, sp.value) == (2, 9, 0, 0)
+    assert abs(tau.value - 0.75) < 1e-7 and abs(m.value - 0.5) < 1e-7 and abs(e.value - 1e-6) < 1e-12 and abs(sf.value - 2.5) < 1e-6
+    assert path.value.decode() == str(tmp_path) + "/img/frame.exr"       # relative to the folder of the .bcd.json file
+    back = json.loads(out.read_text())                                    # what we write is plain JSON with the reference's keys
+    assert back["nbOfScales"] == 2 and back["randomPixelOrder"] is False and back["inputColorFile"] == "img/frame.exr"
+    assert set(back) == {"inputColorFile", "inputHistoFile", "inputCovarFile", "performSpikeRemovalPrefiltering",
+                         "spikeRemovalThresholdStDevFactor", "nbOfScales", "histoDistanceThreshold", "useCuda", "nbOfCores", "patchRadius",
+                         "searchWindowRadius", "randomPixelOrder", "markedPixelsSkippingProbability", "minEigenValue"}
+    bad = tmp_path / "bad.bcd.json"
+    bad.write_text("{ \"nbOfScales\": }")
+    assert lib.bcdcore_presets_roundtrip(str(bad).encode(), None, C.byref(S), C.byref(tau), C.byref(b), C.byref(r), C.byref(m), C.byref(e),
+                                         C.byref(sp), C.byref(sf), path, 512) == -1

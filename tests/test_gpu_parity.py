@@ -435,3 +435,29 @@ def test_concurrent_and_serial_scales_agree(hipctx):
         hipctx.set_concurrent_scales(True)
     assert sa == sb
     assert rel_linf(a, b_) < 1e-5
+
+
+def test_bcd_cli_preset_file(hipctx, tmp_path):
+    """-a <file.bcd.json>: inputs and parameters come from the preset, later flags override it"""
+    import json
+    import subprocess
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H = 64, 48
+    col, ns, hist, cov = core.synthetic_scene(W, H, 8, 3, 0.2, 0.0)
+    (tmp_path / "in").mkdir()
+    core.write_exr(str(tmp_path / "in" / "f.exr"), col, False)
+    core.write_exr(str(tmp_path / "in" / "h.exr"), core.merge_hist_ns(hist, ns), True)
+    core.write_exr(str(tmp_path / "in" / "c.exr"), cov, True)
+    (tmp_path / "p.bcd.json").write_text(json.dumps({"inputColorFile": "in/f.exr", "inputHistoFile": "in/h.exr", "inputCovarFile": "in/c.exr",
+                                                       "nbOfScales": 1, "searchWindowRadius": 3, "markedPixelsSkippingProbability": 0.0,
+                                                       "performSpikeRemovalPrefiltering": False, "histoDistanceThreshold": 1.25}))
+    exe = _os.path.join(_os.path.dirname(core.LIB_PATH), "bcd_cli")
+    out_path = str(tmp_path / "o.exr")
+    r = subprocess.run([exe, "-a", str(tmp_path / "p.bcd.json"), "-o", out_path, "-b", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = core.read_exr(out_path, False)
+    col_h = core.read_exr(str(tmp_path / "in" / "f.exr"), False)
+    want = hipctx.denoise(*dev(col_h, ns, hist, cov), 1, bh.default_params(b=4, m=0.0, tau=1.25))
+    want = hipctx.zero_bad_values(want).cpu().numpy()
+    assert np.max(np.abs(got - want.astype(np.float16).astype(np.float32))) <= 2e-3 * np.max(want)
