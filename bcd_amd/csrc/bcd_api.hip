@@ -29,6 +29,7 @@ hipError_t bcd_launch_downscale_cov(const float *, const float *, int, int, floa
 hipError_t bcd_launch_interpolate(int, const float *, int, int, int, float *, int, int, hipStream_t);
 hipError_t bcd_launch_spike(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *,
                             float *, float *, hipStream_t);
+hipError_t bcd_launch_accumulate_samples(const float *, const float *, int64_t, int, int, float, float, float *, float *, float *, float *, hipStream_t);
 hipError_t bcd_launch_active_init(const int32_t *, int, int, int, int, int, float, uint32_t, uint8_t *, hipStream_t);
 hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int *, hipStream_t);
 hipError_t bcd_launch_active_tile(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int *, hipStream_t);
@@ -686,6 +687,16 @@ int bcd_hip_spike_filter(bcd_hip_ctx *ctx, const float *d_col, const float *d_ns
     if (!ctx || !d_col || !d_ns || !d_hist || !d_cov || !o_col || !o_ns || !o_hist || !o_cov) return bad(ctx, "bad argument");
     if (W < 3 || H < 3 || D <= 0) return bad(ctx, "image smaller than 3x3");
     HIPCHK(ctx, bcd_launch_spike(d_col, d_ns, d_hist, d_cov, W, H, D, factor, o_col, o_ns, o_hist, o_cov, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_accumulate_samples(bcd_hip_ctx *ctx, const float *d_samples, const float *d_weights, int W, int H, int spp, int nb_bins,
+                               float gamma, float max_value, float *d_nsamples, float *d_mean, float *d_cov, float *d_hist)
+{
+    if (!ctx || !d_samples || !d_nsamples || !d_mean || !d_cov || !d_hist) return bad(ctx, "null pointer");
+    if (W <= 0 || H <= 0 || spp <= 0 || nb_bins < 3) return bad(ctx, "bad size");
+    if ((size_t)3 * nb_bins * 64 * sizeof(float) > 160 * 1024) { set_err(ctx, "more than 213 bins per channel are not supported"); return BCD_HIP_EUNSUPPORTED; }
+    HIPCHK(ctx, bcd_launch_accumulate_samples(d_samples, d_weights, (int64_t)W * H, spp, nb_bins, gamma, max_value, d_nsamples, d_mean, d_cov, d_hist, ctx->stream));
     return BCD_HIP_OK;
 }
 

@@ -147,6 +147,60 @@ __global__ void k_spike(const float *__restrict__ col, const float *__restrict__
     for (int j = 0; j < 6; ++j) ocov[dst * 6 + j] = cov[src * 6 + j];
 }
 
+// SamplesAccumulator::addSample + computeSampleStatistics on the device (src/core/SamplesAccumulator.cpp:44-141):
+// one thread per pixel walks its samples in order (same operations and order as the host class, so nSamples, mean and
+// covariance are bit-identical; the histogram goes through the device powf and agrees to float round-off).
+// The per-thread histogram lives in LDS, bin-major ([bin][thread]) to stay bank-conflict free.
+__global__ __launch_bounds__(64) void k_accumulate_samples(const float *__restrict__ samples, const float *__restrict__ weights,
+                                                           int64_t npix, int spp, int nbins, float gamma, float maxval,
+                                                           float *__restrict__ ons, float *__restrict__ omean, float *__restrict__ ocov,
+                                                           float *__restrict__ ohist)
+{
+    extern __shared__ float lds_h[];
+    const int t = threadIdx.x, D = 3 * nbins;
+    const int64_t p = (int64_t)blockIdx.x * 64 + t;
+    for (int k = 0; k < D; ++k) lds_h[k * 64 + t] = 0.f;
+    if (p >= npix) return;
+    const float sat = 2.f;
+    float wsum = 0.f, w2sum = 0.f, m[3] = { 0.f, 0.f, 0.f }, c[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    const float *sp = samples + p * spp * 3;
+    for (int i = 0; i < spp; ++i) {
+        const float R = sp[3 * i], G = sp[3 * i + 1], B = sp[3 * i + 2];
+        const float w = weights ? weights[p * spp + i] : 1.f;
+        wsum += w;
+        w2sum += w * w;
+        m[0] += w * R; m[1] += w * G; m[2] += w * B;
+        c[0] += w * R * R; c[1] += w * G * G; c[2] += w * B * B;
+        c[3] += w * G * B; c[4] += w * R * B; c[5] += w * R * G;
+        const float rgb[3] = { R, G, B };
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = rgb[ch] > 0 ? rgb[ch] : 0;
+            if (gamma > 1) v = powf(v, 1.f / gamma);
+            if (maxval > 0) v = v / maxval;
+            v = v > sat ? sat : v;
+            const float fi = v * (nbins - 2);
+            int lo = (int)fi;
+            float hw;
+            if (lo < nbins - 2) hw = fi - lo;
+            else { lo = nbins - 2; hw = (v - 1.0f) / (sat - 1.f); }
+            const float lw = 1.0f - hw;
+            lds_h[(ch * nbins + lo) * 64 + t] += w * lw;
+            lds_h[(ch * nbins + lo + 1) * 64 + t] += w * hw;
+        }
+    }
+    const float inv = 1.f / wsum;
+    float mean[3];
+    for (int i = 0; i < 3; ++i) { mean[i] = inv * m[i]; omean[p * 3 + i] = mean[i]; }
+    float cv[6];
+    for (int i = 0; i < 6; ++i) cv[i] = c[i] * inv;
+    cv[0] -= mean[0] * mean[0]; cv[1] -= mean[1] * mean[1]; cv[2] -= mean[2] * mean[2];
+    cv[3] -= mean[1] * mean[2]; cv[4] -= mean[0] * mean[2]; cv[5] -= mean[0] * mean[1];
+    const float bias = 1.f / (1 - w2sum / (wsum * wsum));
+    for (int i = 0; i < 6; ++i) ocov[p * 6 + i] = cv[i] * bias;
+    ons[p] = wsum;
+    for (int k = 0; k < D; ++k) ohist[p * D + k] = lds_h[k * 64 + t];
+}
+
 inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 } // namespace
@@ -193,5 +247,17 @@ hipError_t bcd_launch_spike(const float *col, const float *ns, const float *hist
                             float factor, float *ocol, float *ons, float *ohist, float *ocov, hipStream_t st)
 {
     hipLaunchKernelGGL(k_spike, dim3((W + 63) / 64, H), dim3(64), 0, st, col, ns, hist, cov, W, H, D, factor, ocol, ons, ohist, ocov);
+    return hipGetLastError();
+}
+
+hipError_t bcd_launch_accumulate_samples(const float *samples, const float *weights, int64_t npix, int spp, int nbins, float gamma,
+                                         float maxval, float *ons, float *omean, float *ocov, float *ohist, hipStream_t st)
+{
+    size_t lds = (size_t)3 * nbins * 64 * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate_samples), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_accumulate_samples, dim3(nblk(npix, 64)), dim3(64), lds, st, samples, weights, npix, spp, nbins, gamma, maxval, ons, omean, ocov, ohist);
     return hipGetLastError();
 }

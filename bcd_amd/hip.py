@@ -35,7 +35,7 @@ SYMBOLS = [
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
-    "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_zero_bad_values",
+    "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
     "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_selftest_division",
 ]
 
@@ -221,6 +221,16 @@ class Context:
         self._chk(lib().bcd_hip_spike_filter(self.h, _dp(col), _dp(ns), _dp(hist), _dp(cov), W, H, D, C.c_float(factor),
                                              _dp(o[0]), _dp(o[1]), _dp(o[2]), _dp(o[3])))
         return o
+
+    def accumulate_samples(self, samples, weights=None, nbins=20, gamma=2.2, maxval=2.5):
+        """samples: (H, W, spp, 3) device tensor; weights: (H, W, spp) or None"""
+        torch = self.torch
+        H, W, spp, _ = samples.shape
+        mk = lambda d: torch.empty((H, W, d), dtype=torch.float32, device=samples.device)
+        ns, mean, cov, hist = mk(1), mk(3), mk(6), mk(3 * nbins)
+        self._chk(lib().bcd_hip_accumulate_samples(self.h, _dp(samples), _dp(weights) if weights is not None else None, W, H, spp, nbins,
+                                                   C.c_float(gamma), C.c_float(maxval), _dp(ns), _dp(mean), _dp(cov), _dp(hist)))
+        return ns, mean, cov, hist
 
     def zero_bad_values(self, img):
         self._chk(lib().bcd_hip_zero_bad_values(self.h, _dp(img), C.c_int64(img.numel())))

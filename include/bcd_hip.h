@@ -151,6 +151,11 @@ int bcd_hip_merge(bcd_hip_ctx *ctx, float *d_hi, int W, int H, const float *d_lo
 int bcd_hip_spike_filter(bcd_hip_ctx *ctx, const float *d_colors, const float *d_nsamples,
                          const float *d_histograms, const float *d_covariances, int W, int H, int D, float factor,
                          float *d_colors_out, float *d_nsamples_out, float *d_histograms_out, float *d_covariances_out);
+/* SamplesAccumulator::addSample + getSamplesStatistics for a whole frame   src/core/SamplesAccumulator.cpp:44-141
+ * (lets a GPU renderer keep the statistics in HBM).  d_samples: W*H*spp*3 floats, the spp samples of a pixel contiguous
+ * and in accumulation order; d_weights: W*H*spp floats or NULL (all 1).  Outputs in DeepImage layout, hist depth 3*nb_bins. */
+int bcd_hip_accumulate_samples(bcd_hip_ctx *ctx, const float *d_samples, const float *d_weights, int W, int H, int spp, int nb_bins,
+                               float gamma, float max_value, float *d_nsamples, float *d_mean, float *d_cov, float *d_hist);
 /* checkAndPutToZeroNegativeInfNaNValues   src/cli/main.cpp:389-420 */
 int bcd_hip_zero_bad_values(bcd_hip_ctx *ctx, float *d_img, int64_t n);
 

@@ -461,3 +461,23 @@ def test_bcd_cli_preset_file(hipctx, tmp_path):
     want = hipctx.denoise(*dev(col_h, ns, hist, cov), 1, bh.default_params(b=4, m=0.0, tau=1.25))
     want = hipctx.zero_bad_values(want).cpu().numpy()
     assert np.max(np.abs(got - want.astype(np.float16).astype(np.float32))) <= 2e-3 * np.max(want)
+
+
+@pytest.mark.parametrize("weighted,nbins", [(False, 20), (True, 20), (True, 12)])
+def test_gpu_samples_accumulator(hipctx, weighted, nbins):
+    """device SamplesAccumulator: nSamples / mean / covariance bit-identical to the host class (same order and operations),
+    histograms to float round-off (device powf)"""
+    import torch
+    W, H, spp = 37, 22, 9
+    samples, _ = ol.synth_samples(W, H, spp, seed=4, sigma=0.5, spike_prob=0.1)
+    if weighted:
+        samples[::3, 5] = 0.25
+        samples[::7, 5] = 3.0
+    want = ol.oracle_ops()["accumulate"](samples, W, H, nbins)
+    s4 = samples.reshape(H, W, spp, 6)
+    d_s = torch.from_numpy(np.ascontiguousarray(s4[..., 2:5])).cuda()
+    d_w = torch.from_numpy(np.ascontiguousarray(s4[..., 5])).cuda() if weighted else None
+    ns, mean, cov, hist = [t.cpu().numpy() for t in hipctx.accumulate_samples(d_s, d_w, nbins)]
+    assert bits_equal(ns, want[0]) and bits_equal(mean, want[1]) and bits_equal(cov, want[2])
+    assert np.max(np.abs(hist - want[3])) < 2e-5 * max(1.0, float(np.max(want[3])))
+    assert np.allclose(hist.sum(-1), 3 * ns[..., 0], rtol=1e-5)
