@@ -43,6 +43,24 @@ __device__ inline float pd_div(float a, float b)
     return fmaf(r, y, q);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// two divisions at once on packed operands (same eight operations per component)
+template <bool FAST>
+__device__ inline v2f pd_div2(v2f a, v2f b)
+{
+    if (!FAST) return v2f{ a.x / b.x, a.y / b.y };
+    v2f y = { __builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y) };
+    const v2f one = { 1.f, 1.f };
+    v2f e = __builtin_elementwise_fma(-b, y, one);
+    y = __builtin_elementwise_fma(e, y, y);
+    v2f q = a * y;
+    v2f r = __builtin_elementwise_fma(-b, q, a);
+    q = __builtin_elementwise_fma(r, y, q);
+    r = __builtin_elementwise_fma(-b, q, a);
+    return __builtin_elementwise_fma(r, y, q);
+}
+
 __device__ inline bool pd_bin_bad(float v) { return !(v >= 0.f && v <= PD_BIN_MAX); }
 __device__ inline bool pd_n_bad(float v) { return !(v >= PD_N_MIN && v <= PD_N_MAX); }
 
@@ -140,32 +158,27 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
         auto evaluate = [&](const float4 *buf, int dc, int di) __attribute__((always_inline)) {
             const float n2 = lds_n[ty * ncols + tx + dc + b];
             const float n12 = n1 * n2;
+            const v2f n1v = { n1, n1 }, n2v = { n2, n2 }, n12v = { n12, n12 };
             float sum = 0.f;
             int cnt = 0;
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const float b2[4] = { buf[q].x, buf[q].y, buf[q].z, buf[q].w };
-                float s[4];
-                bool use[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s[j] = h1[4 * q + j] + b2[j];
-                    use[j] = s[j] > 1.f; // reference skips bins with b1 + b2 <= 1 (DenoisingUnit.cpp:379)
-                }
-                // wave-uniform skip of a group of 4 bins that is empty for all 64 pixels of the tile row (exact:
-                // skipped bins contribute nothing); inside an active group the 4 divisions are independent
-                if (__builtin_amdgcn_ballot_w64(use[0] || use[1] || use[2] || use[3]) != 0) {
-                    float t[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float diff = n2 * h1[4 * q + j] - n1 * b2[j];
-                        t[j] = pd_div<FAST>(diff * diff, n12 * s[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { // bins in order: the reference's sequential sum
-                        sum = use[j] ? sum + t[j] : sum;
-                        cnt += use[j] ? 1 : 0;
-                    }
+                // bins 4q..4q+3 as two packed pairs: every operation below is IEEE per component (v_pk_*_f32), i.e. the same
+                // roundings as the scalar code, two bins per instruction
+                const v2f b2lo = { buf[q].x, buf[q].y }, b2hi = { buf[q].z, buf[q].w };
+                const v2f b1lo = { h1[4 * q], h1[4 * q + 1] }, b1hi = { h1[4 * q + 2], h1[4 * q + 3] };
+                const v2f slo = b1lo + b2lo, shi = b1hi + b2hi;
+                const bool u0 = slo.x > 1.f, u1 = slo.y > 1.f, u2 = shi.x > 1.f, u3 = shi.y > 1.f; // DenoisingUnit.cpp:379
+                // wave-uniform skip of a group of 4 bins that is empty for all 64 pixels of the wavefront (exact: skipped
+                // bins contribute nothing); inside an active group the divisions are independent
+                if (__builtin_amdgcn_ballot_w64(u0 || u1 || u2 || u3) != 0) {
+                    const v2f dlo = n2v * b1lo - n1v * b2lo, dhi = n2v * b1hi - n1v * b2hi;
+                    const v2f tlo = pd_div2<FAST>(dlo * dlo, n12v * slo), thi = pd_div2<FAST>(dhi * dhi, n12v * shi);
+                    sum = u0 ? sum + tlo.x : sum; // bins in order: the reference's sequential sum
+                    sum = u1 ? sum + tlo.y : sum;
+                    sum = u2 ? sum + thi.x : sum;
+                    sum = u3 ? sum + thi.y : sum;
+                    cnt += (u0 ? 1 : 0) + (u1 ? 1 : 0) + (u2 ? 1 : 0) + (u3 ? 1 : 0);
                 }
             }
             const int nc = c + dc, nr = r + dl;
