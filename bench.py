@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--skip-prob", type=float, default=1.0, help="-m of bcd_cli")
     ap.add_argument("--random-order", type=int, default=1, help="-r of bcd_cli")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--isolated", action="store_true", help="also time the pair-distance kernel with the scales serialised (3 extra untimed steps)")
     ap.add_argument("--band-path", action="store_true", help="use the multi-GPU row-band code path even with one rank (debug)")
     ap.add_argument("--cpu-sample", default="960x540", help="frame size of the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -136,7 +137,7 @@ def main():
     # the three scales run concurrently on separate streams, so a launch's event-to-event time includes the kernels it
     # overlaps with; the same kernel timed in isolation (scales one after the other, two extra untimed steps):
     iso_ms = None
-    if world == 1 and not args.band_path:
+    if args.isolated and world == 1 and not args.band_path:
         ctx.set_concurrent_scales(False)
         step()
         torch.cuda.synchronize()
@@ -159,7 +160,7 @@ def main():
                 "algorithmic_bytes_per_launch_avg": int(algo_bytes_per_step / S),
                 "isolated_avg_launch_ms": None if iso_ms is None else round(iso_ms, 4),
                 "isolated_frac": None if not iso_ms else round((algo_bytes_per_step / S) / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "compute(VALU)-bound kernel: 85 displacements x 60 bins of IEEE-exact chi-square per pixel; see DESIGN.md"}
+                "note": "VALU-bound kernel (85 displacements x 60 bins of exact chi-square per pixel); the 3 scales run concurrently on separate streams, so launch durations include overlap -- isolated timing: --isolated / profiles/; see DESIGN.md"}
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file):
         try:
