@@ -30,9 +30,9 @@ hipError_t bcd_launch_interpolate(int, const float *, int, int, int, float *, in
 hipError_t bcd_launch_spike(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *,
                             float *, float *, hipStream_t);
 hipError_t bcd_launch_accumulate_samples(const float *, const float *, int64_t, int, int, float, float, float *, float *, float *, float *, hipStream_t);
-hipError_t bcd_launch_active_init(const int32_t *, int, int, int, int, int, float, uint32_t, uint8_t *, hipStream_t);
-hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int *, hipStream_t);
-hipError_t bcd_launch_active_tile(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int *, hipStream_t);
+hipError_t bcd_launch_active_init(const int32_t *, int, int, int, int, int, float, uint32_t, int, uint8_t *, hipStream_t);
+hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int, int *, hipStream_t);
+hipError_t bcd_launch_active_tile(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t bcd_bayes_lds_bytes(int w, int b);
 hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, int, int, int, int, int, float,
@@ -175,37 +175,50 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     return BCD_HIP_OK;
 }
 
+// one batch of marking launches on lines [row_begin, row_end); *undecided_out = pixels of those lines still undecided
+int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
+                int row_end, int random_order, uint32_t seed, int row_offset, bool first_pass, uint8_t *d_state, int *undecided_out,
+                int *launches_out)
+{
+    const int K = 3 * (2 * w + 1) * (2 * w + 1);
+    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+    int *d_cnt = (int *)wk.counters.p;
+    const bool tiled = (b == 6 || b == 12);
+    const int batch = tiled ? 2 : ROUND_BATCH;
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), wk.stream));
+    for (int i = 0; i < batch; ++i) {
+        if (tiled)
+            HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, 6 /* in-tile iterations per launch */,
+                                               (first_pass && i == 0) ? 1 : 0, row_begin, row_end, row_offset, d_cnt + i, wk.stream));
+        else
+            HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, row_begin, row_end, row_offset,
+                                                d_cnt + i, wk.stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(wk.h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, wk.stream));
+    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    int n = batch;
+    for (int i = 0; i < batch; ++i)
+        if (wk.h_counters[i] == 0) { n = i + 1; break; }
+    *undecided_out = wk.h_counters[n - 1];
+    if (launches_out) *launches_out = n;
+    return BCD_HIP_OK;
+}
+
 int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
                int row_end, float skip_prob, int random_order, uint32_t seed, uint8_t *d_state, int32_t *rounds_out)
 {
-    const int K = 3 * (2 * w + 1) * (2 * w + 1);
-    HIPCHK(ctx, bcd_launch_active_init(d_nsim, W, H, w, row_begin, row_end, skip_prob, seed, d_state, wk.stream));
+    HIPCHK(ctx, bcd_launch_active_init(d_nsim, W, H, w, row_begin, row_end, skip_prob, seed, 0, d_state, wk.stream));
     int rounds = 0;
     if (skip_prob > 0.f) {
-        RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
-        int *d_cnt = (int *)wk.counters.p;
         const int max_rounds = 4 * (W + H) + 64;
-        bool done = false;
-        const int side = 2 * b + 1, words = (side * side + 31) / 32;
-        const bool tiled = (b == 6 || b == 12);
-        (void)words;
-        const int batch = tiled ? 2 : ROUND_BATCH;
-        while (!done && rounds < max_rounds) {
-            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), wk.stream));
-            for (int i = 0; i < batch; ++i) {
-                if (tiled)
-                    HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, 6 /* in-tile iterations per launch */, (rounds == 0 && i == 0 && skip_prob >= 1.f) ? 1 : 0, d_cnt + i, wk.stream));
-                else
-                    HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, d_cnt + i, wk.stream));
-            }
-            HIPCHK(ctx, hipMemcpyAsync(wk.h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, wk.stream));
-            HIPCHK(ctx, hipStreamSynchronize(wk.stream));
-            for (int i = 0; i < batch; ++i) {
-                ++rounds;
-                if (wk.h_counters[i] == 0) { done = true; break; }
-            }
+        int undecided = 1;
+        while (undecided != 0 && rounds < max_rounds) {
+            int n = 0;
+            RCCHK(active_step(ctx, wk, d_mask, d_nsim, W, H, w, b, row_begin, row_end, random_order, seed, 0, rounds == 0 && skip_prob >= 1.f,
+                              d_state, &undecided, &n));
+            rounds += n;
         }
-        if (!done) { set_err(ctx, "marking fixed point did not converge"); return BCD_HIP_EDEVICE; }
+        if (undecided != 0) { set_err(ctx, "marking fixed point did not converge"); return BCD_HIP_EDEVICE; }
     }
     if (rounds_out) *rounds_out = rounds;
     return BCD_HIP_OK;
@@ -624,6 +637,25 @@ int bcd_hip_active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *
 {
     if (!ctx || !d_mask || !d_count || !d_state) return bad(ctx, "bad argument");
     return active_set(ctx, ctx->main, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, skip_probability, random_order, seed, d_state, rounds);
+}
+
+int bcd_hip_active_init(bcd_hip_ctx *ctx, const int32_t *d_count, int W, int H, int w, int main_row_begin, int main_row_end,
+                        float skip_probability, uint32_t seed, int row_offset, uint8_t *d_state)
+{
+    if (!ctx || !d_count || !d_state || W <= 0 || H <= 0) return bad(ctx, "bad argument");
+    HIPCHK(ctx, bcd_launch_active_init(d_count, W, H, w, main_row_begin, main_row_end, skip_probability, seed, row_offset, d_state, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_active_step(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_count, int W, int H, int w, int b, int main_row_begin,
+                        int main_row_end, int random_order, uint32_t seed, int row_offset, int first_pass, uint8_t *d_state, int32_t *undecided)
+{
+    if (!ctx || !d_mask || !d_count || !d_state || !undecided) return bad(ctx, "bad argument");
+    int u = 0;
+    RCCHK(active_step(ctx, ctx->main, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, random_order, seed, row_offset, first_pass != 0,
+                      d_state, &u, nullptr));
+    *undecided = u;
+    return BCD_HIP_OK;
 }
 
 int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask,

@@ -12,8 +12,10 @@
 
 namespace {
 
+// row_offset: line of the full frame that local line 0 corresponds to (multi-GPU bands): hashes and visiting keys are
+// functions of the GLOBAL pixel index, so that a band decomposition follows the same order as the whole frame
 __global__ void k_active_init(const int32_t *__restrict__ nsim, int W, int H, int w, int row_begin, int row_end,
-                              float skip_prob, uint32_t seed, uint8_t *__restrict__ state)
+                              float skip_prob, uint32_t seed, int row_offset, uint8_t *__restrict__ state)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     if (c >= W) return;
@@ -22,21 +24,23 @@ __global__ void k_active_init(const int32_t *__restrict__ nsim, int W, int H, in
     if (r >= w && r <= H - 1 - w && c >= w && c <= W - 1 - w && r >= row_begin && r < row_end) {
         if (skip_prob <= 0.f) s = BCD_ST_IN;
         else if (skip_prob >= 1.f) s = BCD_ST_UNDECIDED;
-        else s = (bcd_unit_hash((uint32_t)p, seed) < skip_prob) ? BCD_ST_UNDECIDED : BCD_ST_IN; // never skipped when marked
+        else s = (bcd_unit_hash((uint32_t)(p + (size_t)row_offset * W), seed) < skip_prob) ? BCD_ST_UNDECIDED : BCD_ST_IN; // never skipped when marked
     }
     state[p] = s;
 }
 
 __global__ __launch_bounds__(256) void k_active_round(const uint32_t *__restrict__ mask, const int32_t *__restrict__ nsim,
                                                       uint8_t *state, int W, int H, int b, int words, int min_strong,
-                                                      int random_order, uint32_t seed, int *__restrict__ undecided)
+                                                      int random_order, uint32_t seed, int row_begin, int row_end, int row_offset,
+                                                      int *__restrict__ undecided)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     bool still = false;
-    if (c < W) {
+    const size_t goff = (size_t)row_offset * W;
+    if (c < W && r >= row_begin && r < row_end) {
         size_t p = (size_t)r * W + c;
         if (state[p] == BCD_ST_UNDECIDED) {
-            const uint64_t keyp = bcd_order_key((uint32_t)p, random_order, seed);
+            const uint64_t keyp = bcd_order_key((uint32_t)(p + goff), random_order, seed);
             const int side = 2 * b + 1;
             bool any_in = false, all_decided = true;
             for (int j = 0; j < words && !any_in; ++j) {
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256) void k_active_round(const uint32_t *__restrict
                     size_t q = (size_t)(r + dl) * W + (c + dc);
                     if (q == p) continue;
                     if (nsim[q] < min_strong) continue;                 // fallback pixels mark nobody
-                    if (bcd_order_key((uint32_t)q, random_order, seed) > keyp) continue; // visited later
+                    if (bcd_order_key((uint32_t)(q + goff), random_order, seed) > keyp) continue; // visited later
                     uint8_t sq = state[q];
                     if (sq == BCD_ST_IN) { any_in = true; break; }
                     if (sq == BCD_ST_UNDECIDED) all_decided = false;
@@ -73,7 +77,8 @@ __global__ __launch_bounds__(256) void k_active_round(const uint32_t *__restrict
 template <int B>
 __global__ __launch_bounds__(256) void k_active_tile(const uint32_t *__restrict__ mask, const int32_t *__restrict__ nsim,
                                                      uint8_t *state, int W, int H, int min_strong, int random_order,
-                                                     uint32_t seed, int inner_iters, int first_launch, int *__restrict__ undecided)
+                                                     uint32_t seed, int inner_iters, int first_launch, int row_begin, int row_end,
+                                                     int row_offset, int *__restrict__ undecided)
 {
     constexpr int b = B, WORDS = ((2 * B + 1) * (2 * B + 1) + 31) / 32; // compile-time window: k / side is a multiply-shift
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void k_active_tile(const uint32_t *__restrict_
         uint8_t st = 0, sv = BCD_ST_NONE;
         if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
             size_t q = (size_t)gr * W + gc;
-            h = (uint32_t)(bcd_order_key((uint32_t)q, random_order, seed) >> 32);
+            h = (uint32_t)(bcd_order_key((uint32_t)(q + (size_t)row_offset * W), random_order, seed) >> 32);
             st = nsim[q] >= min_strong;
             sv = state[q];
         }
@@ -104,7 +109,8 @@ __global__ __launch_bounds__(256) void k_active_tile(const uint32_t *__restrict_
     __syncthreads();
     const bool inside = c < W && r < H;
     const size_t p = inside ? (size_t)r * W + c : 0;
-    bool pending = inside && state[p] == BCD_ST_UNDECIDED;
+    // only lines [row_begin, row_end) are decided here; undecided pixels outside (the halo of a band) belong to a neighbour
+    bool pending = inside && r >= row_begin && r < row_end && state[p] == BCD_ST_UNDECIDED;
     uint32_t dep[WORDS];
     if (pending) {
         const int lp = ((threadIdx.x >> 4) + b) * tw + (threadIdx.x & 15) + b;
@@ -209,18 +215,19 @@ __global__ __launch_bounds__(1024) void k_active_lists(const uint8_t *__restrict
 } // namespace
 
 hipError_t bcd_launch_active_init(const int32_t *nsim, int W, int H, int w, int row_begin, int row_end, float skip_prob,
-                                  uint32_t seed, uint8_t *state, hipStream_t st)
+                                  uint32_t seed, int row_offset, uint8_t *state, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_active_init, dim3((W + 255) / 256, H), dim3(256), 0, st, nsim, W, H, w, row_begin, row_end, skip_prob, seed, state);
+    hipLaunchKernelGGL(k_active_init, dim3((W + 255) / 256, H), dim3(256), 0, st, nsim, W, H, w, row_begin, row_end, skip_prob, seed, row_offset, state);
     return hipGetLastError();
 }
 
 hipError_t bcd_launch_active_round(const uint32_t *mask, const int32_t *nsim, uint8_t *state, int W, int H, int b,
-                                   int min_strong, int random_order, uint32_t seed, int *undecided, hipStream_t st)
+                                   int min_strong, int random_order, uint32_t seed, int row_begin, int row_end, int row_offset,
+                                   int *undecided, hipStream_t st)
 {
     int side = 2 * b + 1, words = (side * side + 31) / 32;
     hipLaunchKernelGGL(k_active_round, dim3((W + 255) / 256, H), dim3(256), 0, st, mask, nsim, state, W, H, b, words, min_strong,
-                       random_order, seed, undecided);
+                       random_order, seed, row_begin, row_end, row_offset, undecided);
     return hipGetLastError();
 }
 
@@ -233,8 +240,8 @@ hipError_t bcd_launch_active_lists(const uint8_t *state, const int32_t *nsim, in
 }
 
 hipError_t bcd_launch_active_tile(const uint32_t *mask, const int32_t *nsim, uint8_t *state, int W, int H, int b,
-                                  int min_strong, int random_order, uint32_t seed, int inner_iters, int first_launch, int *undecided,
-                                  hipStream_t st)
+                                  int min_strong, int random_order, uint32_t seed, int inner_iters, int first_launch, int row_begin,
+                                  int row_end, int row_offset, int *undecided, hipStream_t st)
 {
     int side = 2 * b + 1, words = (side * side + 31) / 32;
     dim3 grid((W + 15) / 16, (H + 15) / 16), block(256);
@@ -242,9 +249,9 @@ hipError_t bcd_launch_active_tile(const uint32_t *mask, const int32_t *nsim, uin
     const size_t lds = (size_t)tw * tw * 4 + 2 * (((size_t)tw * tw + 3) & ~(size_t)3);
     (void)words;
     if (b == 6)
-        hipLaunchKernelGGL(k_active_tile<6>, grid, block, lds, st, mask, nsim, state, W, H, min_strong, random_order, seed, inner_iters, first_launch, undecided);
+        hipLaunchKernelGGL(k_active_tile<6>, grid, block, lds, st, mask, nsim, state, W, H, min_strong, random_order, seed, inner_iters, first_launch, row_begin, row_end, row_offset, undecided);
     else if (b == 12)
-        hipLaunchKernelGGL(k_active_tile<12>, grid, block, lds, st, mask, nsim, state, W, H, min_strong, random_order, seed, inner_iters, first_launch, undecided);
+        hipLaunchKernelGGL(k_active_tile<12>, grid, block, lds, st, mask, nsim, state, W, H, min_strong, random_order, seed, inner_iters, first_launch, row_begin, row_end, row_offset, undecided);
     else
         return hipErrorNotSupported;
     return hipGetLastError();

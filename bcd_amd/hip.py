@@ -33,7 +33,7 @@ SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
     "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host",
-    "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set",
+    "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
     "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_selftest_division",
@@ -170,6 +170,20 @@ class Context:
         self._chk(lib().bcd_hip_active_set(self.h, _dp(mask), _dp(cnt), W, H, w, b, row_begin, H if row_end is None else row_end,
                                            C.c_float(m), int(random_order), C.c_uint32(seed), _dp(state), C.byref(rounds)))
         return state, rounds.value
+
+    def active_init(self, cnt, w, row_begin, row_end, m, seed, row_offset, state=None):
+        H, W = cnt.shape
+        if state is None:
+            state = self.torch.zeros((H, W), dtype=self.torch.uint8, device=cnt.device)
+        self._chk(lib().bcd_hip_active_init(self.h, _dp(cnt), W, H, w, row_begin, row_end, C.c_float(m), C.c_uint32(seed), row_offset, _dp(state)))
+        return state
+
+    def active_step(self, mask, cnt, state, w, b, row_begin, row_end, random_order, seed, row_offset, first_pass):
+        H, W = cnt.shape
+        u = C.c_int32(0)
+        self._chk(lib().bcd_hip_active_step(self.h, _dp(mask), _dp(cnt), W, H, w, b, row_begin, row_end, int(random_order), C.c_uint32(seed),
+                                            row_offset, 1 if first_pass else 0, _dp(state), C.byref(u)))
+        return u.value
 
     def bayes_accumulate(self, col, pixcov, mask, nsim, state, w, b, min_eig):
         torch = self.torch

@@ -132,6 +132,14 @@ int bcd_hip_active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *
                        int main_row_begin, int main_row_end,
                        float skip_probability, int random_order, uint32_t seed,
                        uint8_t *d_state, int32_t *rounds);
+/* the two halves of bcd_hip_active_set, for the multi-GPU band path: between two steps neighbouring bands exchange the states
+ * of their boundary lines.  Only lines [main_row_begin, main_row_end) are initialised / decided; row_offset = line of the full
+ * frame under local line 0 (keys and hashes are functions of the global pixel index). */
+int bcd_hip_active_init(bcd_hip_ctx *ctx, const int32_t *d_count, int W, int H, int patch_radius, int main_row_begin, int main_row_end,
+                        float skip_probability, uint32_t seed, int row_offset, uint8_t *d_state);
+int bcd_hip_active_step(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_count, int W, int H, int patch_radius, int search_radius,
+                        int main_row_begin, int main_row_end, int random_order, uint32_t seed, int row_offset, int first_pass,
+                        uint8_t *d_state, int32_t *undecided);
 /* denoiseSelectedPatches / denoiseOnlyMainPatch + aggregateOutputPatches for every processed pixel
  * (DenoisingUnit.cpp:388-481,672-693); d_sum / d_count are accumulated into (zero them first). */
 int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixel_cov,
