@@ -13,8 +13,10 @@ The reference is single-process; this is the build's own decom
          of the coarsest output,
       3. per intermediate scale, one line of the merged output, needed by `up(lo)` of the next finer scale.
     No collective is involved; with torch.distributed these are batched isend/irecv over RCCL (xGMI).
-  * `-m 1` marking runs per band (each rank's fixed point sees only its own pixels): a valid greedy order, but not
-    the single-GPU image; `-m 0` is order-free and matches the single-GPU result to fp32 round-off.
+  * `-m 1` marking: by default per band (each rank's fixed point sees only its own pixels): a valid greedy order, but not
+    the single-GPU image; `exact_marking=True` (band_program_exact) follows the visiting order of the whole frame by
+    exchanging boundary states between marking launches -- the single-GPU image, at the price of a few more exchanges and
+    one small all-reduce per launch batch.  `-m 0` is order-free and matches the single-GPU result either way.
 
 The orchestration is engine-agnostic (torch tensors in, engine does the math): `HipEngine` drives libbcd_hip.so;
 the CPU tests plug an oracle-backed engine in (tests/) and run it with gloo, world_size 2.
@@ -112,6 +114,14 @@ def band_program(eng, geom, rank, col, ns, hist, cov, prm, seed0):
     send_up = [t[:halo].contiguous() for acc in accs for t in acc] if up else None
     send_down = [t[-halo:].contiguous() for acc in accs for t in acc] if down else None
     got_up, got_down = yield ("acc", send_up, send_down)
+    result = yield from _finish_bands(eng, geom, rank, bands, spans, accs, got_up, got_down)
+    return result
+
+
+def _finish_bands(eng, geom, rank, bands, spans, accs, got_up, got_down):
+    """common tail: add the received accumulator halos, finalise, exchange output halos, merge coarse to fine"""
+    S, halo, world = geom.S, geom.halo, geom.world
+    up, down = rank > 0, rank < world - 1
     outs = [None] * S
     for s in range(S):
         sb = bands[s]
@@ -163,24 +173,89 @@ def band_program(eng, geom, rank, col, ns, hist, cov, prm, seed0):
     return outs[0][sb.own0 - sb.loc0:sb.own1 - sb.loc0]
 
 
-def run_virtual(eng, geom, inputs_per_rank, prm, seed0):
+def band_program_exact(eng, geom, rank, col, ns, hist, cov, prm, seed0):
+    """like band_program, but the marking strategy (-m > 0) follows the visiting order of the WHOLE frame: keys are functions of
+    the global pixel index, bands exchange the strong flags and, after every batch of marking launches, the states of their b
+    boundary lines, and a global sum of undecided pixels ends the iteration.  The processed set -- hence the image -- is the
+    single-GPU one.  Extra messages: ("sum", value) is answered with the sum over all ranks.  Scales run one after the other."""
+    S, halo, world, b, w = geom.S, geom.halo, geom.world, geom.b, geom.w
+    bands = geom.scale_bands(rank)
+    up, down = rank > 0, rank < world - 1
+    cols, nss, hists, covs = [col], [ns], [hist], [cov]
+    for s in range(1, S):
+        prev, cur = bands[s - 1], bands[s]
+        a, b_ = 2 * cur.loc0 - prev.loc0, 2 * cur.loc1 - prev.loc0
+        cols.append(eng.downscale_avg(cols[s - 1][a:b_]))
+        nss.append(eng.downscale_sum(nss[s - 1][a:b_]))
+        hists.append(eng.downscale_sum(hists[s - 1][a:b_]))
+        covs.append(eng.downscale_cov(covs[s - 1][a:b_], nss[s - 1][a:b_]))
+    accs, spans = [], []
+    for s in range(S):
+        sb = bands[s]
+        o0, o1 = sb.own0 - sb.loc0, sb.own1 - sb.loc0
+        a0 = o0 - halo if up else 0
+        a1 = o1 + halo if down else sb.loc1 - sb.loc0
+        spans.append((o0, o1, a0, a1))
+        r0, r1 = o0 - a0, o1 - a0                                   # owned lines inside the sub-band [a0, a1)
+        row_offset = sb.loc0 + a0                                   # global line of sub-band line 0
+        seed = eng.scale_seed(seed0, s)
+        c_, n_, h_, v_ = cols[s][a0:a1], nss[s][a0:a1], hists[s][a0:a1], covs[s][a0:a1]
+        mask, nsim = eng.similarity(h_, n_, w, b, prm.hist_dist_threshold)
+        # |S| of the b boundary lines comes from their owner (locally their windows are cut by the band edge)
+        got_up, got_down = yield ("nsim%d" % s, [nsim[r0:r0 + b].contiguous()] if up else None, [nsim[r1 - b:r1].contiguous()] if down else None)
+        if up:
+            nsim[r0 - b:r0] = got_up[0]
+        if down:
+            nsim[r1:r1 + b] = got_down[0]
+        state = eng.active_init(nsim, w, r0, r1, prm.marked_skip_probability, seed, row_offset)
+        if prm.marked_skip_probability > 0:
+            first = prm.marked_skip_probability >= 1.0
+            for _ in range(4 * (sb.W + sb.H) + 64):
+                got_up, got_down = yield ("st%d" % s, [state[r0:r0 + b].contiguous()] if up else None, [state[r1 - b:r1].contiguous()] if down else None)
+                if up:
+                    state[r0 - b:r0] = got_up[0]
+                if down:
+                    state[r1:r1 + b] = got_down[0]
+                left = eng.active_step(mask, nsim, state, w, b, r0, r1, prm.use_random_pixel_order, seed, row_offset, first)
+                first = False
+                total = yield ("sum", left)
+                if total == 0:
+                    break
+            else:
+                raise RuntimeError("marking fixed point did not converge")
+        state[:r0] = 0                                              # halo lines are processed by their owner
+        state[r1:] = 0
+        accs.append(eng.bayes(c_, v_, n_, h_, mask, nsim, state, prm))
+    # ---- from here on identical to band_program: accumulator halos, finalisation, output halos, merges
+    send_up = [t[:halo].contiguous() for acc in accs for t in acc] if up else None
+    send_down = [t[-halo:].contiguous() for acc in accs for t in acc] if down else None
+    got_up, got_down = yield ("acc", send_up, send_down)
+    result = yield from _finish_bands(eng, geom, rank, bands, spans, accs, got_up, got_down)
+    return result
+
+
+def run_virtual(eng, geom, inputs_per_rank, prm, seed0, exact_marking=False):
     """all bands in ONE process, exchanges routed in memory (single-GPU / CPU check of the band path).
     inputs_per_rank[r] = (col, ns, hist, cov) of rank r's local lines.  Returns the owned outputs per rank."""
     def snap(m):  # messages are views into live buffers: copy them like a real send would
-        return None if m is None else (m[0],) + tuple(None if x is None else [t.clone() for t in x] for x in m[1:])
+        if m is None or m[0] == "sum":
+            return m
+        return (m[0],) + tuple(None if x is None else [t.clone() for t in x] for x in m[1:])
 
-    progs = [band_program(eng, geom, r, *inputs_per_rank[r], prm, seed0) for r in range(geom.world)]
+    program = band_program_exact if exact_marking else band_program
+    progs = [program(eng, geom, r, *inputs_per_rank[r], prm, seed0) for r in range(geom.world)]
     msgs = [snap(next(p)) for p in progs]
     results = [None] * geom.world
     while any(m is not None for m in msgs):
         tags = {m[0] for m in msgs if m is not None}
         assert len(tags) == 1, tags
         nxt = []
+        total = sum(m[1] for m in msgs) if "sum" in tags else None
         for r, p in enumerate(progs):
-            from_up = msgs[r - 1][2] if r > 0 else None
-            from_down = msgs[r + 1][1] if r < geom.world - 1 else None
+            from_up = msgs[r - 1][2] if r > 0 and total is None else None
+            from_down = msgs[r + 1][1] if r < geom.world - 1 and total is None else None
             try:
-                nxt.append(snap(p.send((from_up, from_down))))
+                nxt.append(snap(p.send(total if total is not None else (from_up, from_down))))
             except StopIteration as e:
                 results[r] = e.value
                 nxt.append(None)
@@ -188,14 +263,19 @@ def run_virtual(eng, geom, inputs_per_rank, prm, seed0):
     return results
 
 
-def run_distributed(eng, geom, rank, dist, inputs, prm, seed0, device=None):
+def run_distributed(eng, geom, rank, dist, inputs, prm, seed0, device=None, exact_marking=False):
     """one band per rank; exchanges are batched isend/irecv with the two neighbours (RCCL on GPUs, gloo on CPU)"""
     import torch
-    prog = band_program(eng, geom, rank, *inputs, prm, seed0)
+    prog = (band_program_exact if exact_marking else band_program)(eng, geom, rank, *inputs, prm, seed0)
     world = geom.world
     try:
         msg = next(prog)
         while True:
+            if msg[0] == "sum":
+                tsum = torch.tensor([int(msg[1])], dtype=torch.int64, device=device if device is not None else "cpu")
+                dist.all_reduce(tsum)
+                msg = prog.send(int(tsum.item()))
+                continue
             _, send_up, send_down = msg
             ops, got_up, got_down = [], None, None
             if rank > 0:
@@ -272,6 +352,20 @@ class HipEngine:
     def zeros_like_rows(self, t, rows):
         return self.torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
 
+    # ---- stage-level calls used by the exact-marking band program
+    def similarity(self, hist, ns, w, b, tau):
+        return self.ctx.similarity_masks(hist.contiguous(), ns.contiguous(), w, b, tau)
+
+    def active_init(self, nsim, w, row0, row1, m, seed, row_offset):
+        return self.ctx.active_init(nsim, w, row0, row1, m, seed, row_offset)
+
+    def active_step(self, mask, nsim, state, w, b, row0, row1, random_order, seed, row_offset, first):
+        return self.ctx.active_step(mask, nsim, state, w, b, row0, row1, random_order, seed, row_offset, first)
+
+    def bayes(self, col, cov, ns, hist, mask, nsim, state, prm):
+        pixcov = self.ctx.pixel_cov(cov.contiguous(), ns.contiguous())
+        return self.ctx.bayes_accumulate(col.contiguous(), pixcov, mask, nsim, state, prm.patch_radius, prm.search_radius, prm.min_eigen_value)
+
     def finalize(self, s, c):
         return self.ctx.finalize(s, c)
 
@@ -282,8 +376,9 @@ class HipEngine:
 class BandDenoiser:
     """bench.py / library front-end of one rank's band"""
 
-    def __init__(self, ctx, dist, rank, world, W, H, D, nscales, prm):
+    def __init__(self, ctx, dist, rank, world, W, H, D, nscales, prm, exact_marking=False):
         self.ctx, self.dist, self.rank, self.world = ctx, dist, rank, world
+        self.exact_marking = exact_marking
         self.geom = BandGeometry(W, H, nscales, prm.search_radius, prm.patch_radius, world)
         self.eng = HipEngine(ctx)
         self.prm = prm
@@ -306,7 +401,8 @@ class BandDenoiser:
         # the context must be bound to torch's CURRENT stream (bench.py does that): engine kernels, torch slicing/adds
         # and the RCCL point-to-point ops are then ordered by the stream itself.  Otherwise fence explicitly.
         eng = self.eng if self.shared_stream else _SyncedEngine(self.eng)
-        self.out = run_distributed(eng, self.geom, self.rank, self.dist, self.inputs, self.prm, self.prm.order_seed)
+        self.out = run_distributed(eng, self.geom, self.rank, self.dist, self.inputs, self.prm, self.prm.order_seed,
+                                   device=self.inputs[0].device, exact_marking=self.exact_marking)
         return self.out
 
 

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--random-order", type=int, default=1, help="-r of bcd_cli")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--isolated", action="store_true", help="also time the pair-distance kernel with the scales serialised (3 extra untimed steps)")
+    ap.add_argument("--exact-marking", action="store_true", help="N > 1: -m 1 marking follows the whole-frame order (state exchanges between marking launches)")
     ap.add_argument("--band-path", action="store_true", help="use the multi-GPU row-band code path even with one rank (debug)")
     ap.add_argument("--cpu-sample", default="960x540", help="frame size of the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -104,7 +105,7 @@ def main():
             ctx.denoise(*d_in, S, prm, out)
     else:
         from bcd_amd.tiling import BandDenoiser
-        band = BandDenoiser(ctx, dist, rank, world, W, H, 60, S, prm)
+        band = BandDenoiser(ctx, dist, rank, world, W, H, 60, S, prm, exact_marking=args.exact_marking)
         g0, g1 = band.input_lines()
         col, ns, hist, cov = core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes, g0, g1 - g0)
         band.upload(col, ns, hist, cov)
@@ -186,7 +187,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d synthetic frame (%d spp, sigma %.2f, spikes %.2f), %d-scale, b=%d w=1 d=1 e=1e-8, -m %g -r %d (seeded), no prefilter"
                                    % (W, H, args.spp, args.sigma, args.spikes, S, b, args.skip_prob, args.random_order),
-                       "parallelism": "rowband%d" % world if world > 1 else "single", "per_scale": scales},
+                       "parallelism": ("rowband%d%s" % (world, "-exactmark" if args.exact_marking else "")) if world > 1 else "single", "per_scale": scales},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

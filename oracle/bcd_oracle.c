@@ -646,6 +646,27 @@ int bcdo_accumulate_band(const float *colors, const float *nsamp, const float *h
     return 0;
 }
 
+/* processes exactly the listed main pixels (no marking logic at all): the per-band tail of the exact multi-GPU marking
+ * tests, where the processed set has been decided globally beforehand.  sum / cnt are zeroed here. */
+int bcdo_accumulate_pixels(const float *colors, const float *nsamp, const float *hist, const float *cov,
+                           int W, int H, int D, const BcdoParams *prm, const int32_t *pixels, int64_t n, float *sum, int32_t *cnt)
+{
+    int rc = check_inputs(colors, nsamp, hist, cov, W, H, D, prm);
+    if (rc) return rc;
+    size_t npix = (size_t)W * H;
+    float *pixcov = (float *)malloc(sizeof(float) * npix * 6);
+    bcdo_pixel_cov_from_sample_cov(cov, nsamp, W, H, pixcov);
+    uint8_t *marked = (uint8_t *)calloc(npix, 1);
+    memset(sum, 0, sizeof(float) * npix * 3);
+    memset(cnt, 0, sizeof(int32_t) * npix);
+    Unit u;
+    unit_init(&u, W, H, D, prm, colors, nsamp, hist, pixcov, sum, cnt, marked);
+    for (int64_t i = 0; i < n; ++i) denoise_patch_and_similar(&u, pixels[i] / W, pixels[i] % W, 0.f, NULL);
+    unit_free(&u);
+    free(marked); free(pixcov);
+    return 0;
+}
+
 void bcdo_finalize(const float *sum, const int32_t *cnt, int64_t npix, float *out) { final_divide(sum, cnt, (size_t)npix, out); }
 
 /* Reference-style parallel m=1 (racy, NOT reproducible): strip reorder (Denoiser.cpp:382-414),

@@ -83,6 +83,8 @@ int bcdo_denoise_mono(const float *colors, const float *nsamp, const float *hist
 int bcdo_accumulate_band(const float *colors, const float *nsamp, const float *hist, const float *cov,
                          int W, int H, int D, const BcdoParams *prm, int row_begin, int row_end,
                          const int32_t *order, int64_t n_order, float *sum, int32_t *cnt);
+int bcdo_accumulate_pixels(const float *colors, const float *nsamp, const float *hist, const float *cov,
+                           int W, int H, int D, const BcdoParams *prm, const int32_t *pixels, int64_t n, float *sum, int32_t *cnt);
 void bcdo_finalize(const float *sum, const int32_t *cnt, int64_t npix, float *out);
 
 /* reference-style racy OpenMP m=1 run (shared mark image, strip order, dynamic schedule;

@@ -481,3 +481,25 @@ def test_gpu_samples_accumulator(hipctx, weighted, nbins):
     assert bits_equal(ns, want[0]) and bits_equal(mean, want[1]) and bits_equal(cov, want[2])
     assert np.max(np.abs(hist - want[3])) < 2e-5 * max(1.0, float(np.max(want[3])))
     assert np.allclose(hist.sum(-1), 3 * ns[..., 0], rtol=1e-5)
+
+
+@pytest.mark.parametrize("W,H,S,world,random_order,b", [(96, 80, 3, 2, 1, 3), (80, 90, 2, 3, 1, 6), (96, 64, 1, 2, 0, 6)])
+def test_band_path_exact_marking_equals_single_gpu(hipctx, W, H, S, world, random_order, b):
+    """-m 1 over bands with exact_marking: global keys + boundary state exchange => the single-GPU frame"""
+    import torch
+    import bcd_amd.hip as bh
+    from bcd_amd.tiling import BandGeometry, HipEngine, run_virtual
+    col, ns, hist, cov, _ = inputs(W, H, 32, 0.08, 0.0)
+    prm = bh.default_params(m=1.0, random_order=random_order, seed=9, b=b)
+    full = hipctx.denoise(*dev(col, ns, hist, cov), S, prm).cpu().numpy()
+    stats_full = [(hipctx.stats(s).processed, hipctx.stats(s).fallback) for s in range(S)]
+    g = BandGeometry(W, H, S, prm.search_radius, 1, world)
+    ins = []
+    for r in range(world):
+        l0, l1 = g.input_lines(r)
+        ins.append(dev(col[l0:l1], ns[l0:l1], hist[l0:l1], cov[l0:l1]))
+    outs = run_virtual(HipEngine(hipctx, reuse_buffers=False), g, ins, prm, prm.order_seed, exact_marking=True)
+    torch.cuda.synchronize()
+    got = np.concatenate([o.cpu().numpy() for o in outs], 0)
+    assert stats_full[0][0] > 0
+    assert rel_linf(got, full) < 1e-5

@@ -75,15 +75,18 @@ def test_virtual_ranks_match_full_frame_m0(W, H, S, world):
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-6
 
 
-def _gloo_worker(rank, world, port, W, H, S, q):
+def _gloo_worker(rank, world, port, W, H, S, q, exact=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     arrs = _inputs(W, H)
     prm = Prm()
+    if exact:
+        prm.marked_skip_probability = 1.0
+        prm.use_random_pixel_order = 1
     g = BandGeometry(W, H, S, prm.search_radius, 1, world)
-    out = run_distributed(OracleEngine(None), g, rank, dist, _slice(arrs, g, rank), prm, 5)
+    out = run_distributed(OracleEngine(None), g, rank, dist, _slice(arrs, g, rank), prm, 5, exact_marking=exact)
     q.put((rank, out.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -104,4 +107,57 @@ def test_two_processes_gloo_match_full_frame():
         assert p.exitcode == 0
     got = np.concatenate([res[r] for r in range(world)], 0)
     want = ol.denoise_multiscale(*_inputs(W, H), S, ol.params(b=Prm.search_radius, m=0.0, threads=1))
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-6
+
+
+def _visit_order_global(W, H, w, random_order, seed):
+    """main pixels of the full frame sorted by the build's visiting key (python restatement of bcd_hip_visit_order)"""
+    eng = OracleEngine(None)
+    idx = np.array([l * W + c for l in range(w, H - w) for c in range(w, W - w)], np.uint64)
+    return idx[np.argsort(eng._keys(idx, random_order, seed), kind="stable")].astype(np.int32)
+
+
+@pytest.mark.parametrize("W,H,S,world,random_order", [(30, 40, 1, 2, 1), (30, 40, 1, 2, 0), (28, 44, 2, 3, 1)])
+def test_exact_marking_across_bands_matches_full_frame_m1(W, H, S, world, random_order):
+    """-m 1 with the exact band program: boundary states are exchanged between marking rounds and keys are global, so the
+    processed set -- and the image -- are those of the whole frame visited in the same order"""
+    arrs = _inputs(W, H, spp=8)
+    prm = Prm()
+    prm.marked_skip_probability = 1.0
+    prm.use_random_pixel_order = random_order
+    g = BandGeometry(W, H, S, prm.search_radius, 1, world)
+    outs = run_virtual(OracleEngine(None), g, [_slice(arrs, g, r) for r in range(world)], prm, 5, exact_marking=True)
+    got = np.concatenate([o.numpy() for o in outs], 0)
+    orders, w_, h_ = [], W, H
+    for s in range(S):
+        orders.append(_visit_order_global(w_, h_, 1, random_order, 5 + s))
+        w_, h_ = w_ // 2, h_ // 2
+    want = ol.denoise_multiscale(*arrs, S, ol.params(b=prm.search_radius, m=1.0), orders=orders)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-6
+    # the per-band (default) program is a different, valid greedy: it must NOT be required to match
+    Prm.marked_skip_probability = 0.0
+
+
+def test_python_keys_match_the_library_order():
+    import bcd_amd.hip as bh
+    for ro in (0, 1):
+        assert np.array_equal(_visit_order_global(23, 17, 1, ro, 77), bh.visit_order(23, 17, 1, ro, 77))
+
+
+def test_two_processes_gloo_exact_marking():
+    """the exact -m 1 band program over real processes: point-to-point state exchanges + the all-reduce of undecided counts"""
+    import torch.multiprocessing as mp
+    W, H, S, world = 30, 36, 1, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, W, H, S, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got = np.concatenate([res[r] for r in range(world)], 0)
+    want = ol.denoise_mono(*_inputs(W, H), ol.params(b=Prm.search_radius, m=1.0), order=_visit_order_global(W, H, 1, 1, 5))
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-6
