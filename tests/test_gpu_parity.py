@@ -503,3 +503,47 @@ def test_band_path_exact_marking_equals_single_gpu(hipctx, W, H, S, world, rando
     got = np.concatenate([o.cpu().numpy() for o in outs], 0)
     assert stats_full[0][0] > 0
     assert rel_linf(got, full) < 1e-5
+
+
+def _inputs_bins(W, H, spp, nbins, sigma=0.2, seed=5):
+    samples, _ = ol.synth_samples(W, H, spp, seed=seed, sigma=sigma, spike_prob=0.0)
+    ns, mean, cov, hist = ol.oracle_ops()["accumulate"](samples, W, H, nbins)
+    return mean, ns, hist, cov
+
+
+@pytest.mark.parametrize("nbins", [10, 8, 4, 40])
+def test_other_histogram_depths(hipctx, nbins):
+    """D = 3 x bins other than 60: templated kernels for D in {12, 24, 36, 120}, the generic pair-distance kernel otherwise"""
+    import bcd_amd.hip as bh
+    W, H = 70, 40
+    col, ns, hist, cov = _inputs_bins(W, H, 16, nbins)
+    d_col, d_ns, d_hist, d_cov = dev(col, ns, hist, cov)
+    mask, cnt = hipctx.similarity_masks(d_hist, d_ns, 1, 6, 1.0)
+    wmask, wcnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask) and np.array_equal(cnt.cpu().numpy(), wcnt)
+    got = hipctx.denoise(d_col, d_ns, d_hist, d_cov, 1, bh.default_params(m=0.0)).cpu().numpy()
+    assert rel_linf(got, ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0))) < TOL
+
+
+@pytest.mark.parametrize("w,b,m", [(2, 3, 0.0), (2, 3, 1.0), (0, 4, 1.0)])
+def test_other_patch_radii(hipctx, w, b, m):
+    """-w != 1 runs the generic mask / marking / Bayes kernels (K = 3(2w+1)^2 = 75 or 3)"""
+    import bcd_amd.hip as bh
+    W, H = 60, 44
+    col, ns, hist, cov, _ = inputs(W, H, 32, 0.08, 0.0)
+    prm = bh.default_params(m=m, random_order=1, seed=6, w=w, b=b)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), 1, prm).cpu().numpy()
+    order = bh.visit_order(W, H, w, 1, 6) if m else None
+    want = ol.denoise_mono(col, ns, hist, cov, ol.params(m=m, w=w, b=b), order=order)
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+
+
+def test_unsupported_geometry_is_refused(hipctx):
+    import bcd_amd.hip as bh
+    col, ns, hist, cov, _ = inputs(40, 30, 8, 0.2, 0.0)
+    with pytest.raises(bh.BcdHipError, match="LDS|supported"):
+        hipctx.denoise(*dev(col, ns, hist, cov), 1, bh.default_params(w=2, b=6))      # 169 x 75 patch clouds do not fit the LDS
+    with pytest.raises(bh.BcdHipError):
+        hipctx.denoise(*dev(col, ns, hist, cov), 6, bh.default_params())               # too many scales for 40 x 30
