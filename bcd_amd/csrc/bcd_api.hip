@@ -35,8 +35,9 @@ hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *,
 hipError_t bcd_launch_active_tile(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t bcd_bayes_lds_bytes(int w, int b);
+size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
 hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, int, int, int, int, int, float,
-                                   float *, int32_t *, hipStream_t);
+                                   float *, int32_t *, float *, size_t, hipStream_t);
 hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, int, int, int, int, int, float *, int32_t *,
                                  hipStream_t);
 
@@ -58,7 +59,7 @@ struct DevBuf {
 struct Work {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt; // grow-only
+    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, gscratch; // grow-only
     int32_t *h_counters = nullptr; // pinned
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; // pair-distance kernel timing
     int ev_used = 0;
@@ -244,7 +245,10 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     if (n_strong) *n_strong = ns;
     if (n_weak) *n_weak = nw;
     if (sim_total) *sim_total = tot;
-    HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, ns, W, H, w, b, min_eig, d_sum, d_count, wk.stream));
+    const size_t per_block = bcd_bayes_scratch_bytes_per_block(w, b);
+    if (per_block && ns > 0) RCCHK(ensure(ctx, wk.gscratch, per_block * (size_t)std::min(ns, 1024)));
+    HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, ns, W, H, w, b, min_eig, d_sum, d_count,
+                                        (float *)wk.gscratch.p, wk.gscratch.bytes, wk.stream));
     HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, nw, W, H, w, b, d_sum, d_count, wk.stream));
     return BCD_HIP_OK;
 }
@@ -325,7 +329,7 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
 
 void work_destroy(Work &w)
 {
-    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt };
+    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt, &w.gscratch };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (w.h_counters) (void)hipHostFree(w.h_counters);
     for (auto &pr : w.ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

@@ -9,6 +9,7 @@
 // Sums that the reference accumulates sequentially (means, covariances, noise mean) are accumulated in
 // the same order here.  Compiled with -ffp-contract=off; fmaf() is used explicitly where contraction is wanted.
 #include "bcd_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -213,15 +214,17 @@ __device__ int decode_members(const uint32_t *mask, int p, const BayesGeom &g, i
 
 __global__ __launch_bounds__(64) void k_bayes_strong_generic(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                      const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
-                                                     BayesGeom g, float min_eig, float *sum, int32_t *cnt)
+                                                     BayesGeom g, int nlist, float min_eig, float *sum, int32_t *cnt, float *gscratch)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
     const int K = g.K, P = g.P, KP = g.KP, LD = g.LD, pw = 2 * g.w + 1;
     int *mem = reinterpret_cast<int *>(lds);
-    float *X = lds + g.maxS;
+    // the two n x K patch clouds live in LDS when they fit; for large patches (w = 2: K = 75) they go to a per-workgroup slice
+    // of a global scratch buffer and the grid strides over the list
+    float *X = gscratch ? gscratch + (size_t)blockIdx.x * 2 * g.maxS * K : lds + g.maxS;
     float *Xd = X + g.maxS * K;
-    float *A = Xd + g.maxS * K;
+    float *A = gscratch ? lds + g.maxS : Xd + g.maxS * K;
     float *V = A + KP * LD;
     float *Bm = V + KP * LD;
     float *noise = Bm + KP * LD;
@@ -232,7 +235,9 @@ __global__ __launch_bounds__(64) void k_bayes_strong_generic(const float *__rest
     int *rp = reinterpret_cast<int *>(rs + KP / 2);
     int *rq = rp + KP / 2;
 
-    const int p = list[blockIdx.x];
+  for (int item = blockIdx.x; item < nlist; item += gridDim.x) {
+    __syncthreads();
+    const int p = list[item];
     const int n = decode_members(mask, p, g, mem, lane);
     const float n_inv = 1.f / (float)n;
 
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(64) void k_bayes_strong_generic(const float *__rest
     spectral_rebuild(Bm, A, V, fl, K, LD, lane, true, min_eig);
     // aggregateOutputPatches (:672-693)
     apply_estimate<true>(X, Bm, mean, noise, mem, n, g, lane, nullptr, sum, cnt);
+  }
 }
 
 // denoiseOnlyMainPatch (:455-481): average of the similar colour patches added to the main patch only
@@ -313,31 +319,55 @@ BayesGeom make_geom(int W, int H, int w, int b)
 
 size_t bcd_bayes27_lds_bytes(int b);
 
+// LDS of the generic kernel; with_clouds = false: patch clouds in global scratch
+static size_t generic_lds_bytes(int w, int b, bool with_clouds)
+{
+    BayesGeom g = make_geom(0, 0, w, b);
+    size_t f = (size_t)g.maxS + (with_clouds ? 2 * (size_t)g.maxS * g.K : 0) + 3 * (size_t)g.KP * g.LD + g.P * 6 + 2 * g.K + 4 * (g.KP / 2);
+    return f * sizeof(float);
+}
+
+// smallest LDS footprint with which (w, b) can run (check_params)
 size_t bcd_bayes_lds_bytes(int w, int b)
 {
     if (w == 1) return bcd_bayes27_lds_bytes(b);
+    size_t full = generic_lds_bytes(w, b, true);
+    return full <= 160 * 1024 ? full : generic_lds_bytes(w, b, false);
+}
+
+// bytes of global scratch one workgroup needs when the clouds do not fit the LDS (0 otherwise)
+size_t bcd_bayes_scratch_bytes_per_block(int w, int b)
+{
+    if (w == 1 || generic_lds_bytes(w, b, true) <= 160 * 1024) return 0;
     BayesGeom g = make_geom(0, 0, w, b);
-    size_t f = (size_t)g.maxS + 2 * (size_t)g.maxS * g.K + 3 * (size_t)g.KP * g.LD + g.P * 6 + 2 * g.K + 4 * (g.KP / 2);
-    return f * sizeof(float);
+    return 2 * (size_t)g.maxS * g.K * sizeof(float);
 }
 
 hipError_t bcd_launch_bayes27(const float *, const float *, const uint32_t *, const int32_t *, int, int, int, int, float, float *, int32_t *,
                               hipStream_t);
 
 hipError_t bcd_launch_bayes_strong(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int nlist,
-                                   int W, int H, int w, int b, float min_eig, float *sum, int32_t *cnt, hipStream_t st)
+                                   int W, int H, int w, int b, float min_eig, float *sum, int32_t *cnt, float *gscratch,
+                                   size_t gscratch_bytes, hipStream_t st)
 {
     if (nlist <= 0) return hipSuccess;
     if (w == 1) return bcd_launch_bayes27(colors, pixcov, mask, list, nlist, W, H, b, min_eig, sum, cnt, st);
     BayesGeom g = make_geom(W, H, w, b);
     if (g.words > 32) return hipErrorInvalidValue;
-    size_t lds = bcd_bayes_lds_bytes(w, b);
+    const size_t per_block = bcd_bayes_scratch_bytes_per_block(w, b);
+    const size_t lds = generic_lds_bytes(w, b, per_block == 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    int blocks = nlist;
+    if (per_block) {
+        if (!gscratch || gscratch_bytes < per_block) return hipErrorInvalidValue;
+        blocks = (int)std::min<size_t>((size_t)nlist, gscratch_bytes / per_block);
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bayes_strong_generic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_bayes_strong_generic, dim3(nlist), dim3(64), lds, st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
+    hipLaunchKernelGGL(k_bayes_strong_generic, dim3(blocks), dim3(64), lds, st, colors, pixcov, mask, list, g, nlist, min_eig, sum, cnt,
+                       per_block ? gscratch : nullptr);
     return hipGetLastError();
 }
 

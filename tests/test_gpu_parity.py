@@ -525,7 +525,7 @@ def test_other_histogram_depths(hipctx, nbins):
     assert rel_linf(got, ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0))) < TOL
 
 
-@pytest.mark.parametrize("w,b,m", [(2, 3, 0.0), (2, 3, 1.0), (0, 4, 1.0)])
+@pytest.mark.parametrize("w,b,m", [(2, 3, 0.0), (2, 3, 1.0), (0, 4, 1.0), (2, 6, 1.0)])
 def test_other_patch_radii(hipctx, w, b, m):
     """-w != 1 runs the generic mask / marking / Bayes kernels (K = 3(2w+1)^2 = 75 or 3)"""
     import bcd_amd.hip as bh
@@ -544,6 +544,6 @@ def test_unsupported_geometry_is_refused(hipctx):
     import bcd_amd.hip as bh
     col, ns, hist, cov, _ = inputs(40, 30, 8, 0.2, 0.0)
     with pytest.raises(bh.BcdHipError, match="LDS|supported"):
-        hipctx.denoise(*dev(col, ns, hist, cov), 1, bh.default_params(w=2, b=6))      # 169 x 75 patch clouds do not fit the LDS
+        hipctx.denoise(*dev(col, ns, hist, cov), 1, bh.default_params(w=3, b=6))      # three 148 x 149 matrices do not fit the LDS
     with pytest.raises(bh.BcdHipError):
         hipctx.denoise(*dev(col, ns, hist, cov), 6, bh.default_params())               # too many scales for 40 x 30
