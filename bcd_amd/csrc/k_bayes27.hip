@@ -1,5 +1,5 @@
 // k_bayes27.hip -- Bayesian patch estimate for the default patch radius w = 1 (K = 27), one wavefront per
-// processed pixel, 18 KB of LDS per wavefront (8 wavefronts per CU).
+// processed pixel, 17.8 KB of LDS per wavefront (9 wavefronts per CU).
 //
 // Same mathematics as DenoisingUnit::denoiseSelectedPatches (src/core/DenoisingUnit.cpp:388-453) and
 // aggregateOutputPatches (:672-693), reorganised for the GPU:
@@ -24,7 +24,7 @@ namespace {
 
 #define DBG_T(i) do { if (DBG && blockIdx.x == 100 && lane == 0) bcd_dbg_cycles[i] = __builtin_readcyclecounter(); } while (0)
 
-constexpr int K = 27, KP = 28, LD = 29, P = 9, MSZ = KP * LD, CHUNK = 32;
+constexpr int K = 27, KP = 28, LD = 29, P = 9, MSZ = KP * LD, CHUNK = MSZ / K; // 30 members per staging chunk
 
 struct Geom27 {
     int W, H, b, side, words, maxS;
@@ -225,13 +225,86 @@ __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
     return ok && isfinite(fro) && sqrtf(fro) * min_eig <= 1.f;
 }
 
-// M <- inverseSymmetricMatrix(M) (DenoisingUnit.cpp:578-604), in place.  scratch: S0..S3 (each >= KP*JLD floats), cs
-__device__ void inverse27(float *M, float *S0, float *S1, float *S2, float *S3, float *fl, float *cs, int lane, float min_eig)
+// compact in-place two-sided Jacobi on LD-layout matrices (round-robin pairs, everything through LDS): only used by the rare
+// spectral fallback of inverse27, where the register-row solver's ping-pong buffers are not available
+__device__ void jacobi27_inplace(float *A, float *V, float *prm /* 4 * KP/2 floats */, int lane)
 {
-    to_jacobi_layout(S0, M, lane); // backup for the spectral path, taken before the sweep destroys M
+    float *rc = prm, *rs = prm + KP / 2;
+    int *rp = reinterpret_cast<int *>(prm + KP), *rq = rp + KP / 2;
+    for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; V[r * LD + c] = (r == c) ? 1.f : 0.f; }
+    __syncthreads();
+    constexpr int N1 = KP - 1, NP = KP / 2;
+    for (int sweep = 0; sweep < 14; ++sweep) {
+        float off = 0.f, dg = 0.f;
+        for (int e = lane; e < K * K; e += 64) {
+            int r = e / K, c = e - r * K;
+            float v = A[r * LD + c];
+            if (r == c) dg = fmaf(v, v, dg); else off = fmaf(v, v, off);
+        }
+        off = wsum(off);
+        dg = wsum(dg);
+        if (off <= 1e-13f * dg) break;
+        for (int round = 0; round < N1; ++round) {
+            if (lane < NP) {
+                int a = (lane == 0) ? N1 : (round + lane) % N1, bb = (lane == 0) ? round : (round - lane + N1) % N1;
+                int p = min(a, bb), q = max(a, bb);
+                float c = 1.f, s = 0.f;
+                if (q < K) {
+                    float apq = A[p * LD + q];
+                    if (apq != 0.f) {
+                        float theta = (A[q * LD + q] - A[p * LD + p]) / (2.f * apq);
+                        float t = 1.f / (fabsf(theta) + sqrtf(fmaf(theta, theta, 1.f)));
+                        t = theta < 0.f ? -t : t;
+                        c = 1.f / sqrtf(fmaf(t, t, 1.f));
+                        s = t * c;
+                        if (!(fabsf(theta) < 1e18f)) { c = 1.f; s = 0.f; }
+                    }
+                } else { p = 0; q = 0; }
+                rc[lane] = c; rs[lane] = s; rp[lane] = p; rq[lane] = q;
+            }
+            __syncthreads();
+            for (int t = lane; t < NP * K; t += 64) { // A <- A J, V <- V J
+                int k = t / K, row = t - k * K;
+                float c = rc[k], s = rs[k];
+                if (s != 0.f) {
+                    int p = rp[k], q = rq[k];
+                    float ap = A[row * LD + p], aq = A[row * LD + q], vp = V[row * LD + p], vq = V[row * LD + q];
+                    A[row * LD + p] = fmaf(c, ap, -s * aq); A[row * LD + q] = fmaf(s, ap, c * aq);
+                    V[row * LD + p] = fmaf(c, vp, -s * vq); V[row * LD + q] = fmaf(s, vp, c * vq);
+                }
+            }
+            __syncthreads();
+            for (int t = lane; t < NP * K; t += 64) { // A <- J^T A
+                int k = t / K, col = t - k * K;
+                float c = rc[k], s = rs[k];
+                if (s != 0.f) {
+                    int p = rp[k], q = rq[k];
+                    float ap = A[p * LD + col], aq = A[q * LD + col];
+                    A[p * LD + col] = fmaf(c, ap, -s * aq); A[q * LD + col] = fmaf(s, ap, c * aq);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// M <- inverseSymmetricMatrix(M) (DenoisingUnit.cpp:578-604), in place.  scratch: S0, S1 (matrix sized), fl, prm (2*KP floats)
+__device__ void inverse27(float *M, float *S0, float *S1, float *fl, float *prm, int lane, float min_eig)
+{
+    // backup for the spectral path, taken before the sweep destroys M: lower triangle mirrored, like Eigen's solver reads it
+    for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; S0[r * LD + c] = M[(r >= c ? r : c) * LD + (r >= c ? c : r)]; }
+    __syncthreads();
     if (sweep_inverse27(M, lane, min_eig)) return;
-    int w = jacobi27(S0, S1, S2, S3, cs, lane);
-    rebuild27(M, w ? S1 : S0, w ? S3 : S2, fl, lane, true, min_eig);
+    jacobi27_inplace(S0, S1, prm, lane);
+    if (lane < K) fl[lane] = 1.f / fmaxf(min_eig, S0[lane * LD + lane]);
+    __syncthreads();
+    for (int e = lane; e < K * K; e += 64) {
+        int r = e / K, c = e - r * K;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s = fmaf(S1[r * LD + k], fl[k] * S1[c * LD + k], s);
+        M[r * LD + c] = s;
+    }
+    __syncthreads();
 }
 
 // out[3o+i][c] = delta*(r==c) - sign * sum_j N_o[i][j] * in[3o+j][c]   (block-diagonal noise covariance times a dense matrix)
@@ -302,10 +375,10 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
     float *A = lds, *V = A + MSZ, *Cm = V + MSZ, *Bm = Cm + MSZ;
-    float *X2 = Bm + MSZ;                      // fifth matrix-sized scratch (Jacobi ping-pong)
-    float *chunk = X2 + MSZ;
-    float *cs = chunk + CHUNK * K;             // 28 floats read as float4: every offset so far is a multiple of 16 bytes
-    float *noise = cs + KP;
+    float *X2 = Bm + MSZ;                      // fifth matrix-sized buffer: Jacobi ping-pong partner ...
+    float *chunk = X2;                         // ... and member-staging chunk (never live at the same time)
+    float *cs = X2 + MSZ;                      // 2 x 28 floats (rotation parameters), read as float4: offsets are multiples of 16 bytes
+    float *noise = cs + 2 * KP;
     float *mean = noise + P * 6;
     float *fl = mean + K + 1;
     int *mem = reinterpret_cast<int *>(fl + KP);
@@ -389,7 +462,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     }
     add_noise27(Bm, noise, lane, +1.f);
     DBG_T(6);
-    inverse27(Bm, A, V, X2, chunk, fl, cs, lane, min_eig);
+    inverse27(Bm, A, V, fl, cs, lane, min_eig);
     DBG_T(7);
     // ---- Step 2 (:438-453): the Step-1 estimates are xhat = x - G (x - m) with G = N Cinv1, hence their empirical
     // mean is m and their empirical covariance is F C F^T, F = I - G
@@ -405,7 +478,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     __syncthreads();
     add_noise27(Bm, noise, lane, +1.f);
     DBG_T(8);
-    inverse27(Bm, A, V, X2, chunk, fl, cs, lane, min_eig);
+    inverse27(Bm, A, V, fl, cs, lane, min_eig);
     noise_times27(Cm, noise, Bm, lane, false);
     DBG_T(9);     // Cm = G2 = N Cinv2
 
@@ -440,7 +513,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 size_t bcd_bayes27_lds_bytes(int b)
 {
     int side = 2 * b + 1;
-    return (size_t)(5 * MSZ + CHUNK * K + P * 6 + (K + 1) + KP + KP + side * side) * sizeof(float);
+    return (size_t)(5 * MSZ + 2 * KP + P * 6 + (K + 1) + KP + side * side) * sizeof(float);
 }
 
 hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int nlist,
