@@ -51,10 +51,11 @@ __device__ inline int noise_idx(int i, int j)
 // has met once (one sweep).  Eigenvalues = diagonal of A (in slot order), eigenvectors = columns of V (same order):
 // V f(diag) V^T needs no bookkeeping of the permutation.  Matrices here use a leading dimension of 28 floats.
 constexpr int JLD = 28;
+static_assert(MSZ >= (KP + 1) * JLD, "the Jacobi layout needs one spare row per matrix buffer");
 
 __device__ inline float dpp_xor1(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
 }
 
 __device__ inline int sigma_slot(int s)
@@ -72,6 +73,13 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
     __syncthreads();
     const bool isA = lane < KP, isV = lane >= 32 && lane < 32 + K;
     const int vrow = lane - 32;
+    // per-lane row addresses in both buffer pairs, hoisted out of the round loop: source row, and destination row at
+    // the Brent-Luk permuted position (A) / the same position (V); idle lanes read row 0 of A
+    const float *src0 = isA ? A0 + lane * JLD : (isV ? V0 + vrow * JLD : A0), *src1 = isA ? A1 + lane * JLD : (isV ? V1 + vrow * JLD : A1);
+    // (idle lanes dump into the spare row 28 of the A buffers -- MSZ = 29 rows of 28 floats -- so that the stores need no branch)
+    float *dst0 = isA ? A1 + sigma_slot(lane) * JLD : (isV ? V1 + vrow * JLD : A1 + KP * JLD);
+    float *dst1 = isA ? A0 + sigma_slot(lane) * JLD : (isV ? V0 + vrow * JLD : A0 + KP * JLD);
+    const int mypair = isA ? (lane >> 1) : 0;
     int cur = 0;
     for (int sweep = 0; sweep < 12; ++sweep) {
         float *A = cur ? A1 : A0;
@@ -85,7 +93,7 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
         dg = wsum(dg);
         if (off <= 1e-13f * dg) break;
         for (int round = 0; round < KP - 1; ++round) {
-            float *Ac = cur ? A1 : A0, *An = cur ? A0 : A1, *Vc = cur ? V1 : V0, *Vn = cur ? V0 : V1;
+            const float *Ac = cur ? A1 : A0;
             if (lane < KP / 2) {
                 int p = 2 * lane, q = p + 1;
                 float apq = Ac[p * JLD + q], c = 1.f, s = 0.f;
@@ -103,7 +111,7 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
                 cs[2 * lane] = c; cs[2 * lane + 1] = s;
             }
             __syncthreads();
-            const float *src = isA ? Ac + lane * JLD : (isV ? Vc + vrow * JLD : Ac);
+            const float *src = cur ? src1 : src0;
             float row[JLD], rot[JLD];
 #pragma unroll
             for (int q4 = 0; q4 < JLD / 4; ++q4) {
@@ -119,22 +127,18 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
                 row[2 * j] = fmaf(c, x, -s * y);
                 row[2 * j + 1] = fmaf(s, x, c * y);
             }
-            // row rotations of A: rows (2i, 2i+1) live in lanes (2i, 2i+1)
-            const float2 mine = reinterpret_cast<const float2 *>(cs)[isA ? (lane >> 1) : 0];
-            const float sg = (lane & 1) ? mine.y : -mine.y;
+            // row rotations of A: rows (2i, 2i+1) live in lanes (2i, 2i+1); the V lanes apply the identity (1, 0), exact
+            // because every entry of V is finite
+            const float2 mine = reinterpret_cast<const float2 *>(cs)[mypair];
+            const float mc = isA ? mine.x : 1.f, ms = isA ? ((lane & 1) ? mine.y : -mine.y) : 0.f;
             float out[JLD];
 #pragma unroll
-            for (int k = 0; k < JLD; ++k) {
-                float partner = dpp_xor1(row[k]);
-                float v = isA ? fmaf(mine.x, row[k], sg * partner) : row[k];
-                out[sigma_slot(k)] = v;          // Brent-Luk column move (static register renaming)
-            }
-            float *dst = isA ? An + sigma_slot(lane) * JLD : Vn + vrow * JLD;
-            if (isA || isV) {
+            for (int k = 0; k < JLD; ++k)
+                out[sigma_slot(k)] = fmaf(mc, row[k], dpp_xor1(row[k]) * ms); // + Brent-Luk column move (register renaming)
+            float *dst = cur ? dst1 : dst0;
 #pragma unroll
-                for (int q4 = 0; q4 < JLD / 4; ++q4)
-                    reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
-            }
+            for (int q4 = 0; q4 < JLD / 4; ++q4)
+                reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
             cur ^= 1;
             __syncthreads();
         }
