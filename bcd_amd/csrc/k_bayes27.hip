@@ -64,6 +64,7 @@ __device__ inline int sigma_slot(int s)
 }
 
 // A0 holds the symmetric input (JLD layout, row/col 27 zero); returns 0/1: index of the buffer pair holding the result
+template <bool DBG>
 __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, int lane)
 {
     for (int e = lane; e < K * JLD; e += 64) {
@@ -91,6 +92,7 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
         }
         off = wsum(off);
         dg = wsum(dg);
+        if (DBG && blockIdx.x == 100 && lane == 0) bcd_dbg_cycles[12 + sweep] = (long long)(1e18f * off / dg);
         if (off <= 1e-13f * dg) break;
         for (int round = 0; round < KP - 1; ++round) {
             const float *Ac = cur ? A1 : A0;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
-    float *A = lds, *V = A + MSZ, *Cm = V + MSZ, *Bm = Cm + MSZ;
+    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ; // A, V, Bm contiguous: reused as the aggregation window
     float *X2 = Bm + MSZ;                      // fifth matrix-sized buffer: Jacobi ping-pong partner ...
     float *chunk = X2;                         // ... and member-staging chunk (never live at the same time)
     float *cs = X2 + MSZ;                      // 2 x 28 floats (rotation parameters), read as float4: offsets are multiples of 16 bytes
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     add_noise27(A, noise, lane, -1.f);
     to_jacobi_layout(Bm, A, lane);
     {
-        int w = jacobi27(Bm, A, V, X2, cs, lane);   // ping-pong pairs (Bm, V) <-> (A, X2)
+        int w = jacobi27<DBG>(Bm, A, V, X2, cs, lane);   // ping-pong pairs (Bm, V) <-> (A, X2)
         DBG_T(5);
         float *EA = w ? A : Bm, *EV = w ? X2 : V, *OUT = w ? Bm : A;
         rebuild27(OUT, EA, EV, fl, lane, false, 0.f);
@@ -486,7 +488,19 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     noise_times27(Cm, noise, Bm, lane, false);
     DBG_T(9);     // Cm = G2 = N Cinv2
 
-    // ---- finalDenoisingMatrixMultiplication (:656-670) on the noisy patches centred on m, aggregateOutputPatches (:672-693)
+    // ---- finalDenoisingMatrixMultiplication (:656-670) on the noisy patches centred on m, aggregateOutputPatches (:672-693).
+    // Every patch of every member lies in the (side+2)^2 window around p: the contributions are first summed there in LDS
+    // (A, V, Bm are dead by now) and flushed with one global atomic per touched value, rows contiguous; windows that do not
+    // fit (b > 10) or images narrower than the search window go straight to global atomics.
+    const int AW = g.side + 2, b1 = g.b + 1;
+    const bool in_lds = AW * AW * 4 <= 3 * MSZ && W > g.side;
+    float *accS = A;
+    int *accC = reinterpret_cast<int *>(A + AW * AW * 3);
+    if (in_lds) {
+        for (int e = lane; e < AW * AW * 4; e += 64) A[e] = 0.f;
+        __syncthreads();
+    }
+    const float invW = 1.f / (float)W;
     for (int i0 = 0; i0 < n; i0 += CHUNK) {
         int cn = min(CHUNK, n - i0);
         stage_chunk(chunk, colors, mem, i0, cn, W, lane);
@@ -500,13 +514,36 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
                 float xc = x[c] - mean[c];
                 y0 = fmaf(g0[c], xc, y0); y1 = fmaf(g1[c], xc, y1); y2 = fmaf(g2[c], xc, y2);
             }
-            int q = mem[i0 + i] + (o / 3 - 1) * W + (o % 3 - 1);
-            unsafeAtomicAdd(sum + (size_t)q * 3 + 0, x[3 * o] - y0);
-            unsafeAtomicAdd(sum + (size_t)q * 3 + 1, x[3 * o + 1] - y1);
-            unsafeAtomicAdd(sum + (size_t)q * 3 + 2, x[3 * o + 2] - y2);
-            atomicAdd(cnt + q, 1);
+            const int oy = o / 3 - 1, ox = o % 3 - 1;
+            if (in_lds) {
+                int d = mem[i0 + i] - p;                    // = dy * W + dx with |dx| <= b < W / 2
+                int dy = (int)rintf((float)d * invW), dx = d - dy * W;
+                int wq = (dy + b1 + oy) * AW + dx + b1 + ox;
+                unsafeAtomicAdd(accS + wq * 3 + 0, x[3 * o] - y0);
+                unsafeAtomicAdd(accS + wq * 3 + 1, x[3 * o + 1] - y1);
+                unsafeAtomicAdd(accS + wq * 3 + 2, x[3 * o + 2] - y2);
+                atomicAdd(accC + wq, 1);
+            } else {
+                int q = mem[i0 + i] + oy * W + ox;
+                unsafeAtomicAdd(sum + (size_t)q * 3 + 0, x[3 * o] - y0);
+                unsafeAtomicAdd(sum + (size_t)q * 3 + 1, x[3 * o + 1] - y1);
+                unsafeAtomicAdd(sum + (size_t)q * 3 + 2, x[3 * o + 2] - y2);
+                atomicAdd(cnt + q, 1);
+            }
         }
         __syncthreads();
+    }
+    if (in_lds) {
+        const int row3 = AW * 3;
+        const long long base = (long long)p - (long long)b1 * W - b1; // window origin; untouched cells may lie outside the image
+        for (int e = lane; e < AW * row3; e += 64) {
+            int wy = e / row3, r = e - wy * row3, wx = r / 3;
+            if (accC[wy * AW + wx] != 0) unsafeAtomicAdd(sum + (base + (long long)wy * W) * 3 + r, accS[e]);
+        }
+        for (int e = lane; e < AW * AW; e += 64) {
+            int wy = e / AW, wx = e - wy * AW, c = accC[e];
+            if (c != 0) atomicAdd(cnt + (base + (long long)wy * W + wx), c);
+        }
     }
     DBG_T(10);
     if (DBG && blockIdx.x == 100 && lane == 0) bcd_dbg_cycles[11] = n;
@@ -532,6 +569,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         long long h[24];
         hipStreamSynchronize(st);
         hipMemcpyFromSymbol(h, HIP_SYMBOL(bcd_dbg_cycles), sizeof(h));
+        fprintf(stderr, "sweeps off2/dg2 x1e18:"); for (int i = 12; i < 24; ++i) fprintf(stderr, " %lld", h[i]); fprintf(stderr, "\n");
         fprintf(stderr, "bayes27 dbg n=%lld: decode %lld noise %lld mean %lld cov %lld jacobi %lld rebuild %lld inv1 %lld step2mm %lld inv2 %lld final %lld total %lld\n", h[11], h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5], h[7]-h[6], h[8]-h[7], h[9]-h[8], h[10]-h[9], h[10]-h[0]);
         return hipGetLastError();
     }
