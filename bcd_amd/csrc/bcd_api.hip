@@ -32,7 +32,8 @@ hipError_t bcd_launch_spike(const float *, const float *, const float *, const f
 hipError_t bcd_launch_accumulate_samples(const float *, const float *, int64_t, int, int, float, float, float *, float *, float *, float *, hipStream_t);
 hipError_t bcd_launch_active_init(const int32_t *, int, int, int, int, int, float, uint32_t, int, uint8_t *, hipStream_t);
 hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int, int *, hipStream_t);
-hipError_t bcd_launch_active_tile(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int, int, int, int *, hipStream_t);
+hipError_t bcd_launch_mark_deps(const uint32_t *, const int32_t *, uint8_t *, uint32_t *, int, int, int, int, int, uint32_t, int, int, int, int *, hipStream_t);
+hipError_t bcd_launch_mark_round(const uint32_t *, uint8_t *, int, int, int, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t bcd_bayes_lds_bytes(int w, int b);
 size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
@@ -44,7 +45,7 @@ hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t 
 namespace {
 
 constexpr int MAX_SCALES = 16;
-constexpr int ROUND_BATCH = 4;
+constexpr int ROUND_BATCH = 8;
 constexpr int MAX_EVENT_PAIRS = 4096;
 
 struct DevBuf {
@@ -59,7 +60,8 @@ struct DevBuf {
 struct Work {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, gscratch; // grow-only
+    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, gscratch, dep; // grow-only
+    bool dep_ready = false;        // dependency lists of the current marking problem are in `dep` (reset by active_init)
     int32_t *h_counters = nullptr; // pinned
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; // pair-distance kernel timing
     int ev_used = 0;
@@ -181,17 +183,32 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
                 int row_end, int random_order, uint32_t seed, int row_offset, bool first_pass, uint8_t *d_state, int *undecided_out,
                 int *launches_out)
 {
+    (void)first_pass; // a hint of the C ABI ("every pixel is still undecided"); the dependency-list kernels do not need it
     const int K = 3 * (2 * w + 1) * (2 * w + 1);
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int *d_cnt = (int *)wk.counters.p;
-    const bool tiled = (b == 6 || b == 12);
-    const int batch = tiled ? 2 : ROUND_BATCH;
+    // b = 6 / 12: dependency lists extracted once per marking problem, then cheap tile rounds (in-tile chains are resolved
+    // inside a launch: few launches for a random order, more for the long chains of the scanline order);
+    // other radii: the generic one-level-per-launch kernel
+    const bool listed = (b == 6 || b == 12);
+    int batch = 4;
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), wk.stream));
-    for (int i = 0; i < batch; ++i) {
-        if (tiled)
-            HIPCHK(ctx, bcd_launch_active_tile(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, 6 /* in-tile iterations per launch */,
-                                               (first_pass && i == 0) ? 1 : 0, row_begin, row_end, row_offset, d_cnt + i, wk.stream));
-        else
+    if (listed) {
+        const int side = 2 * b + 1, words = (side * side + 31) / 32;
+        const int iters = 8; // in-tile iterations per launch
+        int i = 0;
+        batch = random_order ? 2 : ROUND_BATCH;
+        if (!wk.dep_ready) {
+            RCCHK(ensure(ctx, wk.dep, (size_t)W * H * words * sizeof(uint32_t)));
+            HIPCHK(ctx, bcd_launch_mark_deps(d_mask, d_nsim, d_state, (uint32_t *)wk.dep.p, W, H, b, K + 1, random_order, seed,
+                                             row_begin, row_end, row_offset, d_cnt + i++, wk.stream));
+            wk.dep_ready = true;
+            if (random_order) batch = 5;
+        }
+        for (; i < batch; ++i)
+            HIPCHK(ctx, bcd_launch_mark_round((const uint32_t *)wk.dep.p, d_state, W, H, b, row_begin, row_end, iters, d_cnt + i, wk.stream));
+    } else {
+        for (int i = 0; i < batch; ++i)
             HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, row_begin, row_end, row_offset,
                                                 d_cnt + i, wk.stream));
     }
@@ -209,6 +226,7 @@ int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t
                int row_end, float skip_prob, int random_order, uint32_t seed, uint8_t *d_state, int32_t *rounds_out)
 {
     HIPCHK(ctx, bcd_launch_active_init(d_nsim, W, H, w, row_begin, row_end, skip_prob, seed, 0, d_state, wk.stream));
+    wk.dep_ready = false;
     int rounds = 0;
     if (skip_prob > 0.f) {
         const int max_rounds = 4 * (W + H) + 64;
@@ -329,7 +347,7 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
 
 void work_destroy(Work &w)
 {
-    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt, &w.gscratch };
+    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (w.h_counters) (void)hipHostFree(w.h_counters);
     for (auto &pr : w.ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -648,6 +666,7 @@ int bcd_hip_active_init(bcd_hip_ctx *ctx, const int32_t *d_count, int W, int H, 
 {
     if (!ctx || !d_count || !d_state || W <= 0 || H <= 0) return bad(ctx, "bad argument");
     HIPCHK(ctx, bcd_launch_active_init(d_count, W, H, w, main_row_begin, main_row_end, skip_probability, seed, row_offset, d_state, ctx->stream));
+    ctx->main.dep_ready = false;
     return BCD_HIP_OK;
 }
 
@@ -656,6 +675,7 @@ int bcd_hip_active_step(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t 
 {
     if (!ctx || !d_mask || !d_count || !d_state || !undecided) return bad(ctx, "bad argument");
     int u = 0;
+    ctx->main.dep_ready = false; // stateless entry point: the dependency lists are rebuilt from (mask, count, state) on every call
     RCCHK(active_step(ctx, ctx->main, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, random_order, seed, row_offset, first_pass != 0,
                       d_state, &u, nullptr));
     *undecided = u;

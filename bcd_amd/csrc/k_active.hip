@@ -69,110 +69,147 @@ __global__ __launch_bounds__(256) void k_active_round(const uint32_t *__restrict
     if (bal && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)bal) - 1)) atomicAdd(undecided, __popcll(bal));
 }
 
-// Tile-iterated round: a 16x16 tile of pixels per workgroup.  On entry every undecided pixel extracts its dependency
-// bits (similar AND visited earlier AND strong) into registers; the tile then iterates in place -- updates made by the
-// same workgroup are visible through the CU's write-through L1 (volatile loads), updates of other workgroups may be
-// seen late, which only delays a decision (the iteration is monotone and its fixed point unique).  One launch
-// resolves every dependency chain that stays inside a tile, so a frame needs 2-3 launches instead of one per level.
-template <int B>
-__global__ __launch_bounds__(256) void k_active_tile(const uint32_t *__restrict__ mask, const int32_t *__restrict__ nsim,
-                                                     uint8_t *state, int W, int H, int min_strong, int random_order,
-                                                     uint32_t seed, int inner_iters, int first_launch, int row_begin, int row_end,
-                                                     int row_offset, int *__restrict__ undecided)
+// ---- dependency lists + probe rounds (search radius 6 or 12) ------------------------------------------------------------
+// k_mark_deps, once per marking problem: every undecided pixel extracts dep(p) = similar AND strong AND visited earlier
+// into global memory.  The "strong" test is word-parallel: the strong flags of the tile and its halo are bit-packed per
+// row in LDS, the window's strong bitmap is 2b+1 shifted row fields, and only the (few) strong similar neighbours are
+// walked bit by bit for the key comparison.  Pixels with dep = 0 are local minima of the order: processed.
+// k_mark_round, one dependency level per launch: a still undecided pixel probes the states of its dep bits (IN -> p is
+// marked; decided and not processed -> bit dropped; undecided -> wait).  A state byte only ever changes from UNDECIDED to its
+// final value, so a stale read delays a decision and never changes it.
+// the (2B+1)^2 window bitmap of a pixel at tile position (lx, ly) from per-row bitmaps of the tile + halo (bit lc of
+// rows[lr] = cell (lr, lc)): window line j is the field of 2B+1 bits starting at column lx of row ly + j
+template <int B, class RowPtr>
+__device__ inline void window_bits(uint32_t (&w)[((2 * B + 1) * (2 * B + 1) + 31) / 32], RowPtr rows, int lx, int ly)
 {
-    constexpr int b = B, WORDS = ((2 * B + 1) * (2 * B + 1) + 31) / 32; // compile-time window: k / side is a multiply-shift
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = blockIdx.y * 16 + (threadIdx.x >> 4);
-    constexpr int side = 2 * b + 1;
-    volatile uint8_t *vstate = state;
-    // stage, for the tile and its b-pixel halo, the high word of the visiting key and the "strong" flag (|S| >= 3P+1):
-    // the dependency extraction below then probes LDS instead of chasing dependent global loads
-    extern __shared__ uint32_t lds_u[];
-    constexpr int tw = 16 + 2 * b;
-    uint32_t *s_hash = lds_u;
-    uint8_t *s_strong = reinterpret_cast<uint8_t *>(lds_u + tw * tw);
-    volatile uint8_t *s_state = s_strong + tw * tw; // states of the tile + halo, refreshed from global every iteration
-    const int r0 = blockIdx.y * 16 - b, c0 = blockIdx.x * 16 - b;
+    constexpr int side = 2 * B + 1, WORDS = (side * side + 31) / 32;
+#pragma unroll
+    for (int j = 0; j < WORDS; ++j) w[j] = 0;
+#pragma unroll
+    for (int j = 0; j < side; ++j) {
+        const unsigned long long field = (rows[ly + j] >> lx) & ((1ull << side) - 1);
+        const int pos = j * side, word = pos >> 5, sh = pos & 31;
+        const unsigned long long v = field << sh;
+        w[word] |= (uint32_t)v;
+        if (word + 1 < WORDS) w[word + 1] |= (uint32_t)(v >> 32);
+    }
+}
+
+template <int B>
+__global__ __launch_bounds__(256) void k_mark_deps(const uint32_t *__restrict__ mask, const int32_t *__restrict__ nsim,
+                                                   uint8_t *state, uint32_t *__restrict__ dep, int W, int H, int min_strong,
+                                                   int random_order, uint32_t seed, int row_begin, int row_end, int row_offset,
+                                                   int *__restrict__ undecided)
+{
+    constexpr int side = 2 * B + 1, WORDS = (side * side + 31) / 32, tw = 16 + 2 * B;
+    static_assert(tw <= 64 && side <= 32, "row bitmaps are 64-bit");
+    __shared__ uint32_t s_hash[tw * tw];
+    __shared__ unsigned long long s_rowbits[tw];
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + lx, r = blockIdx.y * 16 + ly;
+    const int r0 = blockIdx.y * 16 - B, c0 = blockIdx.x * 16 - B;
+    if (threadIdx.x < tw) s_rowbits[threadIdx.x] = 0ull;
+    __syncthreads();
     for (int i = threadIdx.x; i < tw * tw; i += 256) {
         int lr = i / tw, lc = i - lr * tw, gr = r0 + lr, gc = c0 + lc;
         uint32_t h = 0;
-        uint8_t st = 0, sv = BCD_ST_NONE;
         if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
             size_t q = (size_t)gr * W + gc;
             h = (uint32_t)(bcd_order_key((uint32_t)(q + (size_t)row_offset * W), random_order, seed) >> 32);
-            st = nsim[q] >= min_strong;
-            sv = state[q];
+            if (nsim[q] >= min_strong) atomicOr(&s_rowbits[lr], 1ull << lc);
         }
         s_hash[i] = h;
-        s_strong[i] = st;
-        s_state[i] = sv;
     }
     __syncthreads();
     const bool inside = c < W && r < H;
     const size_t p = inside ? (size_t)r * W + c : 0;
-    // only lines [row_begin, row_end) are decided here; undecided pixels outside (the halo of a band) belong to a neighbour
     bool pending = inside && r >= row_begin && r < row_end && state[p] == BCD_ST_UNDECIDED;
-    uint32_t dep[WORDS];
     if (pending) {
-        const int lp = ((threadIdx.x >> 4) + b) * tw + (threadIdx.x & 15) + b;
+        uint32_t sw[WORDS];
+        window_bits<B>(sw, s_rowbits, lx, ly);
+        const int lp = (ly + B) * tw + lx + B;
         const uint32_t hp = s_hash[lp];
+        uint32_t d[WORDS];
+        bool none = true;
 #pragma unroll
         for (int j = 0; j < WORDS; ++j) {
-            uint32_t m = mask[p * WORDS + j], keep = 0;
+            uint32_t m = mask[p * WORDS + j] & sw[j], keep = 0;
             while (m) {
                 int bit = __ffs(m) - 1;
                 m &= m - 1;
                 int k = j * 32 + bit;
-                int dl = k / side - b, dc = k - (k / side) * side - b;
-                int lq = lp + dl * tw + dc;
-                uint32_t hq = s_hash[lq];
-                // strong, and visited earlier: key = (hash, index), index order == (dl, dc) lexicographic order
+                int dl = k / side - B, dc = k - (k / side) * side - B;
+                uint32_t hq = s_hash[lp + dl * tw + dc];
+                // visited earlier: key = (hash, index), index order == (dl, dc) lexicographic order
                 bool earlier = hq < hp || (hq == hp && (dl < 0 || (dl == 0 && dc < 0)));
-                if (s_strong[lq] && earlier) keep |= 1u << bit;
+                if (earlier) keep |= 1u << bit;
             }
-            dep[j] = keep;
+            d[j] = keep;
+            none = none && keep == 0;
         }
-    } else {
+        if (none) { state[p] = BCD_ST_IN; pending = false; }
+        else {
 #pragma unroll
-        for (int j = 0; j < WORDS; ++j) dep[j] = 0;
+            for (int j = 0; j < WORDS; ++j) dep[p * WORDS + j] = d[j];
+        }
     }
-    const int lp_own = ((threadIdx.x >> 4) + b) * tw + (threadIdx.x & 15) + b;
-    for (int it = 0; it < inner_iters; ++it) {
-        bool changed = false;
-        if (pending) {
-            bool any_in = false, wait = false;
-            // very first pass of a scale: every neighbour is still undecided, so only pixels without any earlier strong
-            // similar neighbour (local minima of the visiting order) can be decided -- no need to probe states
-            const bool skip_probe = first_launch && it == 0;
-#pragma unroll
-            for (int j = 0; j < WORDS; ++j) {
-                uint32_t m = dep[j];
-                if (skip_probe) { wait = wait || m != 0; continue; }
-                while (m && !any_in) {
-                    int bit = __ffs(m) - 1;
-                    m &= m - 1;
-                    int k = j * 32 + bit;
-                    int dl = k / side - b, dc = k - (k / side) * side - b;
-                    uint8_t sq = s_state[lp_own + dl * tw + dc];
-                    if (sq == BCD_ST_IN) any_in = true;
-                    else if (sq == BCD_ST_UNDECIDED) wait = true;
-                    else dep[j] &= ~(1u << bit); // decided and not processed: can never mark p
-                }
-            }
-            if (any_in) { state[p] = BCD_ST_OUT; s_state[lp_own] = BCD_ST_OUT; pending = false; changed = true; }
-            else if (!wait) { state[p] = BCD_ST_IN; s_state[lp_own] = BCD_ST_IN; pending = false; changed = true; }
+    int left = __syncthreads_count(pending);
+    if (threadIdx.x == 0 && left) atomicAdd(undecided, left);
+}
+
+template <int B>
+__global__ __launch_bounds__(256) void k_mark_round(const uint32_t *__restrict__ dep, uint8_t *state, int W, int H, int row_begin,
+                                                    int row_end, int iters, int *__restrict__ undecided)
+{
+    constexpr int side = 2 * B + 1, WORDS = (side * side + 31) / 32, tw = 16 + 2 * B;
+    static_assert(tw <= 64, "row bitmaps are 64-bit");
+    // states of the tile + halo as two bitmaps per row: processed (IN) and undecided
+    __shared__ unsigned long long s_in_[tw], s_und_[tw];
+    volatile unsigned long long *s_in = s_in_, *s_und = s_und_;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + lx, r = blockIdx.y * 16 + ly;
+    const bool inside = c < W && r < H;
+    const size_t p = inside ? (size_t)r * W + c : 0;
+    bool pending = inside && r >= row_begin && r < row_end && state[p] == BCD_ST_UNDECIDED;
+    if (!__syncthreads_or(pending)) return; // nothing left to decide in this tile
+    if (threadIdx.x < tw) { s_in_[threadIdx.x] = 0ull; s_und_[threadIdx.x] = 0ull; }
+    __syncthreads();
+    const int r0 = blockIdx.y * 16 - B, c0 = blockIdx.x * 16 - B;
+    for (int i = threadIdx.x; i < tw * tw; i += 256) {
+        int lr = i / tw, lc = i - lr * tw, gr = r0 + lr, gc = c0 + lc;
+        if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
+            uint8_t v = state[(size_t)gr * W + gc];
+            if (v == BCD_ST_IN) atomicOr(&s_in_[lr], 1ull << lc);
+            else if (v == BCD_ST_UNDECIDED) atomicOr(&s_und_[lr], 1ull << lc);
         }
-        // halo cells are owned by other workgroups running concurrently: re-read them (late values only delay decisions)
-        for (int i = threadIdx.x; i < tw * tw; i += 256) {
-            int lr = i / tw, lc = i - lr * tw;
-            if (lr >= b && lr < b + 16 && lc >= b && lc < b + 16) continue;
-            int gr = r0 + lr, gc = c0 + lc;
-            if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
-                uint8_t old = s_state[i];
-                if (old == BCD_ST_UNDECIDED) {
-                    uint8_t nv = vstate[(size_t)gr * W + gc];
-                    if (nv != old) { s_state[i] = nv; changed = true; }
-                }
-            }
+    }
+    uint32_t d[WORDS];
+#pragma unroll
+    for (int j = 0; j < WORDS; ++j) d[j] = pending ? dep[p * WORDS + j] : 0u;
+    __syncthreads();
+    // decisions made inside the tile are visible to the tile at once (LDS), the halo is as of the launch: one launch resolves
+    // the chains that stay inside a tile, the next one sees the neighbours' results.  Word-parallel probe: p is marked iff
+    // dep & IN-window != 0, and waits iff dep & undecided-window != 0.
+    for (int it = 0; it < iters; ++it) {
+        uint8_t v = BCD_ST_UNDECIDED;
+        if (pending) {
+            uint32_t win[WORDS];
+            bool any_in = false, wait = false;
+            window_bits<B>(win, s_in, lx, ly);
+#pragma unroll
+            for (int j = 0; j < WORDS; ++j) any_in = any_in || (d[j] & win[j]) != 0;
+            window_bits<B>(win, s_und, lx, ly);
+#pragma unroll
+            for (int j = 0; j < WORDS; ++j) wait = wait || (d[j] & win[j]) != 0;
+            v = any_in ? BCD_ST_OUT : (wait ? BCD_ST_UNDECIDED : BCD_ST_IN);
+        }
+        __syncthreads(); // every probe of this iteration has read the bitmaps
+        const bool changed = pending && v != BCD_ST_UNDECIDED;
+        if (changed) {
+            state[p] = v;
+            atomicAnd(&s_und_[ly + B], ~(1ull << (lx + B)));
+            if (v == BCD_ST_IN) atomicOr(&s_in_[ly + B], 1ull << (lx + B));
+            pending = false;
         }
         if (!__syncthreads_or(changed)) break;
     }
@@ -239,19 +276,30 @@ hipError_t bcd_launch_active_lists(const uint8_t *state, const int32_t *nsim, in
     return hipGetLastError();
 }
 
-hipError_t bcd_launch_active_tile(const uint32_t *mask, const int32_t *nsim, uint8_t *state, int W, int H, int b,
-                                  int min_strong, int random_order, uint32_t seed, int inner_iters, int first_launch, int row_begin,
-                                  int row_end, int row_offset, int *undecided, hipStream_t st)
+// marking with stored dependency lists (b = 6 or 12): dependency extraction ...
+hipError_t bcd_launch_mark_deps(const uint32_t *mask, const int32_t *nsim, uint8_t *state, uint32_t *dep, int W, int H, int b,
+                                int min_strong, int random_order, uint32_t seed, int row_begin, int row_end, int row_offset,
+                                int *undecided, hipStream_t st)
 {
-    int side = 2 * b + 1, words = (side * side + 31) / 32;
     dim3 grid((W + 15) / 16, (H + 15) / 16), block(256);
-    const int tw = 16 + 2 * b;
-    const size_t lds = (size_t)tw * tw * 4 + 2 * (((size_t)tw * tw + 3) & ~(size_t)3);
-    (void)words;
     if (b == 6)
-        hipLaunchKernelGGL(k_active_tile<6>, grid, block, lds, st, mask, nsim, state, W, H, min_strong, random_order, seed, inner_iters, first_launch, row_begin, row_end, row_offset, undecided);
+        hipLaunchKernelGGL(k_mark_deps<6>, grid, block, 0, st, mask, nsim, state, dep, W, H, min_strong, random_order, seed, row_begin, row_end, row_offset, undecided);
     else if (b == 12)
-        hipLaunchKernelGGL(k_active_tile<12>, grid, block, lds, st, mask, nsim, state, W, H, min_strong, random_order, seed, inner_iters, first_launch, row_begin, row_end, row_offset, undecided);
+        hipLaunchKernelGGL(k_mark_deps<12>, grid, block, 0, st, mask, nsim, state, dep, W, H, min_strong, random_order, seed, row_begin, row_end, row_offset, undecided);
+    else
+        return hipErrorNotSupported;
+    return hipGetLastError();
+}
+
+// ... and one round: in-tile fixed point against the halo states of the launch
+hipError_t bcd_launch_mark_round(const uint32_t *dep, uint8_t *state, int W, int H, int b, int row_begin, int row_end, int iters, int *undecided,
+                                 hipStream_t st)
+{
+    dim3 grid((W + 15) / 16, (H + 15) / 16), block(256);
+    if (b == 6)
+        hipLaunchKernelGGL(k_mark_round<6>, grid, block, 0, st, dep, state, W, H, row_begin, row_end, iters, undecided);
+    else if (b == 12)
+        hipLaunchKernelGGL(k_mark_round<12>, grid, block, 0, st, dep, state, W, H, row_begin, row_end, iters, undecided);
     else
         return hipErrorNotSupported;
     return hipGetLastError();
