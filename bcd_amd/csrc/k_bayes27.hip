@@ -1,9 +1,9 @@
 // k_bayes27.hip -- Bayesian patch estimate for the default patch radius w = 1 (K = 27), one wavefront per
-// processed pixel, 17.8 KB of LDS per wavefront (9 wavefronts per CU).
+// processed pixel, 14.3 KB of LDS per wavefront (11 wavefronts per CU).
 //
 // Same mathematics as DenoisingUnit::denoiseSelectedPatches (src/core/DenoisingUnit.cpp:388-453) and
 // aggregateOutputPatches (:672-693), reorganised for the GPU:
-//   * the similar patches are streamed through a 32-member LDS chunk three times (mean, covariance,
+//   * the similar patches are streamed through a 30-member LDS chunk three times (mean, covariance,
 //     final estimate) instead of being held as n x 27 clouds; sums keep the reference's sequential order;
 //   * Step 2's covariance of the Step-1 estimates (:441-443) is obtained without touching the members
 //     again: the Step-1 estimate is affine, xhat = x - G (x - m), G = N Cinv1, so its empirical mean is m
@@ -63,9 +63,10 @@ __device__ inline int sigma_slot(int s)
     return s == 0 ? 0 : (s == 1 ? 2 : (s == 26 ? 27 : ((s & 1) ? s - 2 : s + 2)));
 }
 
-// A0 holds the symmetric input (JLD layout, row/col 27 zero); returns 0/1: index of the buffer pair holding the result
+// A0 holds the symmetric input (JLD layout, row/col 27 zero).  In place: the workgroup is a single wavefront, so every row is
+// in registers (ds_read, program order) before the first permuted row is written back (ds_write) -- no ping-pong buffers.
 template <bool DBG>
-__device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, int lane)
+__device__ void jacobi27(float *A0, float *V0, float *cs, int lane)
 {
     for (int e = lane; e < K * JLD; e += 64) {
         int r = e / JLD, c = e - r * JLD;
@@ -74,20 +75,17 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
     __syncthreads();
     const bool isA = lane < KP, isV = lane >= 32 && lane < 32 + K;
     const int vrow = lane - 32;
-    // per-lane row addresses in both buffer pairs, hoisted out of the round loop: source row, and destination row at
-    // the Brent-Luk permuted position (A) / the same position (V); idle lanes read row 0 of A
-    const float *src0 = isA ? A0 + lane * JLD : (isV ? V0 + vrow * JLD : A0), *src1 = isA ? A1 + lane * JLD : (isV ? V1 + vrow * JLD : A1);
-    // (idle lanes dump into the spare row 28 of the A buffers -- MSZ = 29 rows of 28 floats -- so that the stores need no branch)
-    float *dst0 = isA ? A1 + sigma_slot(lane) * JLD : (isV ? V1 + vrow * JLD : A1 + KP * JLD);
-    float *dst1 = isA ? A0 + sigma_slot(lane) * JLD : (isV ? V0 + vrow * JLD : A0 + KP * JLD);
+    // per-lane row addresses, hoisted out of the round loop: source row, and destination row at the Brent-Luk permuted
+    // position (A) / the same position (V); idle lanes read row 0 of A and dump into the spare row 28 of A (MSZ = 29 rows of
+    // 28 floats), so that the stores need no branch
+    const float *src = isA ? A0 + lane * JLD : (isV ? V0 + vrow * JLD : A0);
+    float *dst = isA ? A0 + sigma_slot(lane) * JLD : (isV ? V0 + vrow * JLD : A0 + KP * JLD);
     const int mypair = isA ? (lane >> 1) : 0;
-    int cur = 0;
     for (int sweep = 0; sweep < 12; ++sweep) {
-        float *A = cur ? A1 : A0;
         float off = 0.f, dg = 0.f;
         for (int e = lane; e < KP * JLD; e += 64) {
             int r = e / JLD, c = e - r * JLD;
-            float v = A[e];
+            float v = A0[e];
             if (r == c) dg = fmaf(v, v, dg); else off = fmaf(v, v, off);
         }
         off = wsum(off);
@@ -95,11 +93,10 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
         if (DBG && blockIdx.x == 100 && lane == 0) bcd_dbg_cycles[12 + sweep] = (long long)(1e18f * off / dg);
         if (off <= 1e-13f * dg) break;
         for (int round = 0; round < KP - 1; ++round) {
-            const float *Ac = cur ? A1 : A0;
             if (lane < KP / 2) {
                 int p = 2 * lane, q = p + 1;
-                float apq = Ac[p * JLD + q], c = 1.f, s = 0.f;
-                float app = Ac[p * JLD + p], aqq = Ac[q * JLD + q];
+                float apq = A0[p * JLD + q], c = 1.f, s = 0.f;
+                float app = A0[p * JLD + p], aqq = A0[q * JLD + q];
                 if (apq != 0.f) {
                     // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working
                     // precision (c^2 + s^2 = 1 +- 1e-7), not the exact minimiser
@@ -113,7 +110,6 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
                 cs[2 * lane] = c; cs[2 * lane + 1] = s;
             }
             __syncthreads();
-            const float *src = cur ? src1 : src0;
             float row[JLD], rot[JLD];
 #pragma unroll
             for (int q4 = 0; q4 < JLD / 4; ++q4) {
@@ -137,15 +133,12 @@ __device__ int jacobi27(float *A0, float *A1, float *V0, float *V1, float *cs, i
 #pragma unroll
             for (int k = 0; k < JLD; ++k)
                 out[sigma_slot(k)] = fmaf(mc, row[k], dpp_xor1(row[k]) * ms); // + Brent-Luk column move (register renaming)
-            float *dst = cur ? dst1 : dst0;
 #pragma unroll
             for (int q4 = 0; q4 < JLD / 4; ++q4)
                 reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
-            cur ^= 1;
             __syncthreads();
         }
     }
-    return cur;
 }
 
 // out (LD layout) = V f(lambda) V^T ; f = max(0,.) (clamp) or 1/max(minEig,.) (inverse); A, V in the Jacobi (JLD) layout
@@ -380,10 +373,9 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
-    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ; // A, V, Bm contiguous: reused as the aggregation window
-    float *X2 = Bm + MSZ;                      // fifth matrix-sized buffer: Jacobi ping-pong partner ...
-    float *chunk = X2;                         // ... and member-staging chunk (never live at the same time)
-    float *cs = X2 + MSZ;                      // 2 x 28 floats (rotation parameters), read as float4: offsets are multiples of 16 bytes
+    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ; // A, V contiguous: reused as the aggregation window
+    float *chunk = Bm;                         // member-staging chunk: Bm is free while the clouds are streamed (mean/covariance, output)
+    float *cs = Bm + MSZ;                      // 2 x 28 floats (rotation parameters), read as float4: offsets are multiples of 16 bytes
     float *noise = cs + 2 * KP;
     float *mean = noise + P * 6;
     float *fl = mean + K + 1;
@@ -457,14 +449,9 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     add_noise27(A, noise, lane, -1.f);
     to_jacobi_layout(Bm, A, lane);
     {
-        int w = jacobi27<DBG>(Bm, A, V, X2, cs, lane);   // ping-pong pairs (Bm, V) <-> (A, X2)
+        jacobi27<DBG>(Bm, V, cs, lane);
         DBG_T(5);
-        float *EA = w ? A : Bm, *EV = w ? X2 : V, *OUT = w ? Bm : A;
-        rebuild27(OUT, EA, EV, fl, lane, false, 0.f);
-        if (OUT != Bm) { // keep the convention "M1 lives in Bm"
-            for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; Bm[r * LD + c] = OUT[r * LD + c]; }
-            __syncthreads();
-        }
+        rebuild27(Bm, Bm, V, fl, lane, false, 0.f); // reads the eigenvalues (diagonal) before it overwrites Bm: M1 lives in Bm
     }
     add_noise27(Bm, noise, lane, +1.f);
     DBG_T(6);
@@ -490,10 +477,10 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 
     // ---- finalDenoisingMatrixMultiplication (:656-670) on the noisy patches centred on m, aggregateOutputPatches (:672-693).
     // Every patch of every member lies in the (side+2)^2 window around p: the contributions are first summed there in LDS
-    // (A, V, Bm are dead by now) and flushed with one global atomic per touched value, rows contiguous; windows that do not
-    // fit (b > 10) or images narrower than the search window go straight to global atomics.
+    // (A and V are dead by now) and flushed with one global atomic per touched value, rows contiguous; windows that do not
+    // fit (b > 8) or images narrower than the search window go straight to global atomics.
     const int AW = g.side + 2, b1 = g.b + 1;
-    const bool in_lds = AW * AW * 4 <= 3 * MSZ && W > g.side;
+    const bool in_lds = AW * AW * 4 <= 2 * MSZ && W > g.side; // A and V; Bm holds the chunk
     float *accS = A;
     int *accC = reinterpret_cast<int *>(A + AW * AW * 3);
     if (in_lds) {
@@ -554,7 +541,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 size_t bcd_bayes27_lds_bytes(int b)
 {
     int side = 2 * b + 1;
-    return (size_t)(5 * MSZ + 2 * KP + P * 6 + (K + 1) + KP + side * side) * sizeof(float);
+    return (size_t)(4 * MSZ + 2 * KP + P * 6 + (K + 1) + KP + side * side) * sizeof(float);
 }
 
 hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int nlist,
