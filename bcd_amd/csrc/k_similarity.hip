@@ -287,44 +287,61 @@ __device__ inline float lane_down(float v) { return __shfl_down(v, 1); } // valu
 __device__ inline int lane_up(int v)       { return __shfl_up(v, 1); }
 __device__ inline int lane_down(int v)     { return __shfl_down(v, 1); }
 
+// One wavefront: 62 columns x FWD_RB lines of one 32-displacement word.  Per displacement the FWD_RB + 2 lines of the T / C
+// planes are loaded once and shared by the lines of the strip (1.5 loads per output instead of 3); the nine T values are
+// summed in the reference's order (patch line by line, left to right), the counts are integers.
+constexpr int FWD_RB = 4;
 __global__ __launch_bounds__(64) void k_fwd_masks_w1(const float *__restrict__ T, const uint8_t *__restrict__ Cn,
-                                                     int W, int H, int b, float tau, int fwords,
+                                                     int W, int H, int b, float tau, int fwords, int nd,
                                                      uint32_t *__restrict__ fwd)
 {
     const int lane = threadIdx.x;
     const int c = blockIdx.x * 62 + lane - 1; // lanes 1..62 produce output
-    const int r = blockIdx.y;
-    const bool col_ok = c >= 0 && c < W;
-    const bool is_main = (r >= 1 && r <= H - 2 && c >= 1 && c <= W - 2);
+    const int rb = blockIdx.y * FWD_RB;
+    const int wi = blockIdx.z;
     const bool writer = lane >= 1 && lane <= 62 && c < W;
+    const bool c_main = c >= 1 && c <= W - 2;
     const size_t plane = (size_t)W * H;
-    // rows r-1, r, r+1 clamped for the loads (values of non-main pixels are never used)
-    const int r0 = max(r - 1, 0), r2 = min(r + 1, H - 1), cc = min(max(c, 0), W - 1);
-    const size_t o0 = (size_t)r0 * W + cc, o1 = (size_t)r * W + cc, o2 = (size_t)r2 * W + cc;
-    uint32_t word = 0;
-    int didx = 0, wi = 0;
-    for (int dl = 0; dl <= b; ++dl)
-        for (int dc = (dl == 0 ? 0 : -b); dc <= b; ++dc, ++didx) {
-            const float *Tp = T + (size_t)didx * plane;
-            const uint8_t *Cp = Cn + (size_t)didx * plane;
-            float t0 = Tp[o0], t1 = Tp[o1], t2 = Tp[o2];
-            int n0 = Cp[o0], n1 = Cp[o1], n2 = Cp[o2];
-            float s = lane_up(t0);
-            s += t0; s += lane_down(t0);
-            s += lane_up(t1); s += t1; s += lane_down(t1);
-            s += lane_up(t2); s += t2; s += lane_down(t2);
-            int n = lane_up(n0) + n0 + lane_down(n0) + lane_up(n1) + n1 + lane_down(n1) + lane_up(n2) + n2 + lane_down(n2);
-            const int qr = r + dl, qc = c + dc;
-            const bool q_main = qr <= H - 2 && qc >= 1 && qc <= W - 2;
-            float d = s / (float)n; // 0/0 = NaN -> not similar
-            if (is_main && q_main && d <= tau) word |= 1u << (didx & 31);
-            if ((didx & 31) == 31) {
-                if (writer) fwd[((size_t)r * W + c) * fwords + wi] = word;
-                word = 0; ++wi;
-            }
+    const int cc = min(max(c, 0), W - 1), side = 2 * b + 1;
+    // lines rb-1 .. rb+FWD_RB clamped for the loads (values of non-main pixels are never used)
+    size_t off[FWD_RB + 2];
+#pragma unroll
+    for (int i = 0; i < FWD_RB + 2; ++i) off[i] = (size_t)min(max(rb - 1 + i, 0), H - 1) * W + cc;
+    uint32_t word[FWD_RB];
+#pragma unroll
+    for (int i = 0; i < FWD_RB; ++i) word[i] = 0;
+    const int d_end = min(nd, 32 * wi + 32);
+    for (int didx = 32 * wi; didx < d_end; ++didx) {
+        int dl = 0, dc = didx;
+        if (didx > b) { int e = didx - (b + 1); dl = 1 + e / side; dc = e - (dl - 1) * side - b; }
+        const float *Tp = T + (size_t)didx * plane;
+        const uint8_t *Cp = Cn + (size_t)didx * plane;
+        float tc[FWD_RB + 2], tl[FWD_RB + 2], tr[FWD_RB + 2];
+        int nh[FWD_RB + 2];
+#pragma unroll
+        for (int i = 0; i < FWD_RB + 2; ++i) { tc[i] = Tp[off[i]]; nh[i] = Cp[off[i]]; }
+#pragma unroll
+        for (int i = 0; i < FWD_RB + 2; ++i) {
+            tl[i] = lane_up(tc[i]); tr[i] = lane_down(tc[i]);
+            nh[i] = lane_up(nh[i]) + nh[i] + lane_down(nh[i]);
         }
-    if ((didx & 31) != 0 && writer) fwd[((size_t)r * W + c) * fwords + wi] = word;
-    (void)col_ok;
+        const int qc = c + dc;
+        const bool cols_ok = c_main && qc >= 1 && qc <= W - 2;
+#pragma unroll
+        for (int i = 0; i < FWD_RB; ++i) {
+            float s = tl[i];
+            s += tc[i]; s += tr[i];
+            s += tl[i + 1]; s += tc[i + 1]; s += tr[i + 1];
+            s += tl[i + 2]; s += tc[i + 2]; s += tr[i + 2];
+            const int n = nh[i] + nh[i + 1] + nh[i + 2];
+            const int r = rb + i;
+            const float d = s / (float)n; // 0/0 = NaN -> not similar
+            if (cols_ok && r >= 1 && r <= H - 2 && r + dl <= H - 2 && d <= tau) word[i] |= 1u << (didx & 31);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FWD_RB; ++i)
+        if (writer && rb + i < H) fwd[((size_t)(rb + i) * W + c) * fwords + wi] = word[i];
 }
 
 // kernel 3: full (2b+1)^2-bit masks and |S| from the forward bits: bit(p, -delta) = bit(p - delta, +delta)
@@ -353,6 +370,55 @@ __global__ __launch_bounds__(256) void k_sym_masks(const uint32_t *__restrict__ 
             }
         }
     for (int j = 0; j < words; ++j) mask[pix * words + j] = out[j];
+    count[pix] = n;
+}
+
+// kernel 3, compile-time search radius: the forward words of the tile's pixels and of the B lines above / B columns either
+// side are staged in LDS once; in mask order the forward half-plane is the pixel's own bits moved up by KC = ((2B+1)^2-1)/2
+// (bit KC + i <- forward bit i, a funnel shift of the words), and the backward half is bit KC - i <- forward bit i of p - delta_i.
+template <int B>
+__global__ __launch_bounds__(256) void k_sym_masks_t(const uint32_t *__restrict__ fwd, int W, int H,
+                                                     uint32_t *__restrict__ mask, int32_t *__restrict__ count)
+{
+    constexpr int side = 2 * B + 1, ND = (B + 1) + B * side, FW = (ND + 31) / 32, WORDS = (side * side + 31) / 32, KC = ND - 1;
+    constexpr int TC = 64 + 2 * B, TR = 4 + B;
+    extern __shared__ uint32_t s_fwd[]; // [TR][TC][FW]
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 4;
+    for (int i = threadIdx.x; i < TR * TC * FW; i += 256) {
+        int cell = i / FW, j = i - cell * FW;
+        int lr = cell / TC, lc = cell - lr * TC, gr = r0 - B + lr, gc = c0 - B + lc;
+        s_fwd[i] = (gr >= 0 && gr < H && gc >= 0 && gc < W) ? fwd[((size_t)gr * W + gc) * FW + j] : 0u;
+    }
+    __syncthreads();
+    const int c = c0 + lx, r = r0 + ly;
+    if (c >= W || r >= H) return;
+    uint32_t out[WORDS];
+#pragma unroll
+    for (int j = 0; j < WORDS; ++j) out[j] = 0;
+    const uint32_t *own = s_fwd + ((ly + B) * TC + lx + B) * FW;
+#pragma unroll
+    for (int j = 0; j < FW; ++j) {
+        const uint32_t v = own[j];
+        const int pos = KC + 32 * j, wd = pos >> 5, sh = pos & 31;
+        out[wd] |= v << sh;
+        if (sh != 0 && wd + 1 < WORDS) out[wd + 1] |= v >> (32 - sh);
+    }
+#pragma unroll
+    for (int dl = 0; dl <= B; ++dl) {
+#pragma unroll
+        for (int dc = -B; dc <= B; ++dc) {
+            if (dl == 0 && dc <= 0) continue;
+            const int di = dl == 0 ? dc : (B + 1) + (dl - 1) * side + (dc + B);
+            const uint32_t wv = s_fwd[((ly + B - dl) * TC + (lx + B - dc)) * FW + (di >> 5)];
+            const int k = KC - di;
+            out[k >> 5] |= ((wv >> (di & 31)) & 1u) << (k & 31);
+        }
+    }
+    const size_t pix = (size_t)r * W + c;
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < WORDS; ++j) { mask[pix * WORDS + j] = out[j]; n += __popc(out[j]); }
     count[pix] = n;
 }
 
@@ -472,8 +538,17 @@ hipError_t bcd_launch_masks(const float *T, const uint8_t *Cn, int W, int H, int
     int64_t npix = (int64_t)W * H;
     if (w == 1 && fwd_scratch) {
         const int fwords = (bcd_delta_count(b) + 31) / 32;
-        hipLaunchKernelGGL(k_fwd_masks_w1, dim3((W + 61) / 62, H), dim3(64), 0, st, T, Cn, W, H, b, tau, fwords, fwd_scratch);
-        hipLaunchKernelGGL(k_sym_masks, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, st, fwd_scratch, W, H, b, fwords, words, mask, count);
+        hipLaunchKernelGGL(k_fwd_masks_w1, dim3((W + 61) / 62, (H + FWD_RB - 1) / FWD_RB, fwords), dim3(64), 0, st, T, Cn, W, H, b, tau, fwords,
+                           bcd_delta_count(b), fwd_scratch);
+        dim3 grid((W + 63) / 64, (H + 3) / 4);
+        if (b == 6 || b == 12) {
+            const size_t lds = (size_t)(4 + b) * (64 + 2 * b) * fwords * sizeof(uint32_t);
+            if (b == 6)
+                hipLaunchKernelGGL(k_sym_masks_t<6>, grid, dim3(256), lds, st, fwd_scratch, W, H, mask, count);
+            else
+                hipLaunchKernelGGL(k_sym_masks_t<12>, grid, dim3(256), lds, st, fwd_scratch, W, H, mask, count);
+        } else
+            hipLaunchKernelGGL(k_sym_masks, grid, dim3(256), 0, st, fwd_scratch, W, H, b, fwords, words, mask, count);
         return hipGetLastError();
     }
     dim3 block(64, 4);

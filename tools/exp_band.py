@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""estimate the per-rank compute time of the band path on ONE GPU: an interior rank of an N-way split runs its band program,
+every neighbour exchange is answered with a copy of what it sent (right shapes, no communication)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bcd_amd.core as core
+import bcd_amd.hip as bh
+from bcd_amd.tiling import BandGeometry, HipEngine, band_program, band_program_exact
+
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1280, 720)
+exact = len(sys.argv) > 3 and sys.argv[3] == "exact"
+S, b, w = 3, 6, 1
+prm = bh.default_params(b=b, w=w, m=1.0, random_order=1, seed=1234)
+stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
+ctx = bh.Context(0, stream)
+eng = HipEngine(ctx)
+base = None
+for world in (1, 2, 4, 8):
+    geom = BandGeometry(W, H, S, b, w, world)
+    rank = world // 2
+    g0, g1 = geom.input_lines(rank)
+    col, ns, hist, cov = core.synthetic_scene(W, H, 32, 1234, 0.35, 0.01, g0, g1 - g0)
+    inputs = [torch.from_numpy(a).cuda() for a in (col, ns, hist, cov)]
+
+    def step():
+        prog = (band_program_exact if exact else band_program)(eng, geom, rank, *inputs, prm, prm.order_seed)
+        try:
+            msg = next(prog)
+            while True:
+                if msg[0] == "sum":
+                    msg = prog.send(int(msg[1]))
+                    continue
+                _, up, down = msg
+                msg = prog.send((None if up is None else [t.clone() for t in up], None if down is None else [t.clone() for t in down]))
+        except StopIteration as e:
+            return e.value
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / n
+    if base is None:
+        base = ms
+    print("%dx%d world %d rank %d lines %d: %.3f ms/step  -> compute-only efficiency %.2f" % (W, H, world, rank, g1 - g0, ms, base / (world * ms)))
