@@ -37,15 +37,23 @@ hipError_t bcd_launch_mark_round(const uint32_t *, uint8_t *, int, int, int, int
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t bcd_bayes_lds_bytes(int w, int b);
 size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
-hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, int, int, int, int, int, float,
-                                   float *, int32_t *, float *, size_t, hipStream_t);
-hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, int, int, int, int, int, float *, int32_t *,
-                                 hipStream_t);
+hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, const int32_t *, int *, int, int, int, int,
+                                   int, float, float *, int32_t *, float *, size_t, hipStream_t);
+hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, const int32_t *, int, int, int, int, int, float *,
+                                 int32_t *, hipStream_t);
 
 namespace {
 
 constexpr int MAX_SCALES = 16;
 constexpr int ROUND_BATCH = 8;
+constexpr int SPEC_ROUNDS = 6; // marking launches of a speculative chain (dependency extraction + 5 rounds)
+// BCD_HIP_SPEC_ROUNDS=n (2..8) overrides it: the parity tests use a batch that is too short to exercise the redo path
+int spec_rounds()
+{
+    const char *e = getenv("BCD_HIP_SPEC_ROUNDS");
+    int n = e ? atoi(e) : SPEC_ROUNDS;
+    return n < 2 ? 2 : (n > ROUND_BATCH ? ROUND_BATCH : n);
+}
 constexpr int MAX_EVENT_PAIRS = 4096;
 
 struct DevBuf {
@@ -75,6 +83,7 @@ struct bcd_hip_ctx {
     bool owns_stream = false;
     bool profiling = false;
     bool concurrent_scales = true;
+    int num_cus = 256;
     std::mutex err_mutex;
     std::string err;
     bcd_hip_scale_stats stats[MAX_SCALES];
@@ -143,8 +152,10 @@ int check_params(bcd_hip_ctx *ctx, int W, int H, int D, const bcd_hip_params *pr
     return BCD_HIP_OK;
 }
 
+// exact_mode: 0 = fast division, range flag checked here (one stream synchronisation); 1 = the compiler's division;
+// 2 = fast division, flag copied to wk.h_counters[40] but NOT checked: the caller validates after its own synchronisation
 int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
-               uint32_t *d_mask, int32_t *d_count)
+               uint32_t *d_mask, int32_t *d_count, int exact_mode = 0)
 {
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(b);
@@ -167,13 +178,15 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int *d_flag = (int *)wk.counters.p + 40;
     HIPCHK(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), wk.stream));
-    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, 1, d_flag, wk.stream));
+    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, exact_mode == 1 ? 0 : 1, d_flag, wk.stream));
     if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
     // the fast kernel flags inputs outside the range where its division is proven exact: redo with the compiler's division
-    HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
-    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
-    if (wk.h_counters[40] != 0)
-        HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, 0, d_flag, wk.stream));
+    if (exact_mode != 1) HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
+    if (exact_mode == 0) {
+        HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+        if (wk.h_counters[40] != 0)
+            HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, 0, d_flag, wk.stream));
+    }
     HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream));
     return BCD_HIP_OK;
 }
@@ -222,12 +235,33 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
     return BCD_HIP_OK;
 }
 
+// speculative = true: one fixed batch of marking launches without reading the counters back; the per-launch undecided counts
+// are copied to wk.h_counters[0..ROUND_BATCH) and the caller checks, after its own synchronisation, that the last one is 0
+// (active_set_outcome).  Only offered where the batch normally suffices: list kernels and a random order.
+bool can_speculate_marking(int b, int random_order) { return (b == 6 || b == 12) && random_order; }
+
 int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
-               int row_end, float skip_prob, int random_order, uint32_t seed, uint8_t *d_state, int32_t *rounds_out)
+               int row_end, float skip_prob, int random_order, uint32_t seed, uint8_t *d_state, int32_t *rounds_out, bool speculative = false)
 {
     HIPCHK(ctx, bcd_launch_active_init(d_nsim, W, H, w, row_begin, row_end, skip_prob, seed, 0, d_state, wk.stream));
     wk.dep_ready = false;
     int rounds = 0;
+    if (speculative && skip_prob > 0.f) {
+        const int K = 3 * (2 * w + 1) * (2 * w + 1), side = 2 * b + 1, words = (side * side + 31) / 32;
+        RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+        RCCHK(ensure(ctx, wk.dep, (size_t)W * H * words * sizeof(uint32_t)));
+        int *d_cnt = (int *)wk.counters.p;
+        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), wk.stream));
+        HIPCHK(ctx, bcd_launch_mark_deps(d_mask, d_nsim, d_state, (uint32_t *)wk.dep.p, W, H, b, K + 1, random_order, seed, row_begin, row_end, 0,
+                                         d_cnt, wk.stream));
+        wk.dep_ready = true;
+        const int nspec = spec_rounds();
+        for (int i = 1; i < nspec; ++i)
+            HIPCHK(ctx, bcd_launch_mark_round((const uint32_t *)wk.dep.p, d_state, W, H, b, row_begin, row_end, 8, d_cnt + i, wk.stream));
+        HIPCHK(ctx, hipMemcpyAsync(wk.h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, wk.stream));
+        if (rounds_out) *rounds_out = nspec;
+        return BCD_HIP_OK;
+    }
     if (skip_prob > 0.f) {
         const int max_rounds = 4 * (W + H) + 64;
         int undecided = 1;
@@ -243,32 +277,38 @@ int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t
     return BCD_HIP_OK;
 }
 
+// lists of processed pixels + both estimate kernels, without any host round trip: the list lengths stay in device memory
+// and persistent workgroups share the lists.  The lengths and the sum of |S| are copied to wk.h_counters[16..20): read them
+// with bayes_counts() after the stream has been synchronised.
 int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask, const int32_t *d_nsim,
-          const uint8_t *d_state, int W, int H, int w, int b, float min_eig, float *d_sum, int32_t *d_count,
-          int64_t *n_strong, int64_t *n_weak, int64_t *sim_total)
+          const uint8_t *d_state, int W, int H, int w, int b, float min_eig, float *d_sum, int32_t *d_count)
 {
     const int64_t npix = (int64_t)W * H;
     const int K = 3 * (2 * w + 1) * (2 * w + 1);
     RCCHK(ensure(ctx, wk.strong, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.weak, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
-    int32_t *d_c = (int32_t *)wk.counters.p + 16;
-    HIPCHK(ctx, hipMemsetAsync(d_c, 0, 4 * sizeof(int32_t), wk.stream));
+    int32_t *d_c = (int32_t *)wk.counters.p + 16; // [0] strong, [1] weak, [2..3] sum |S|, [4] work counter of the strong kernel
+    HIPCHK(ctx, hipMemsetAsync(d_c, 0, 8 * sizeof(int32_t), wk.stream));
     HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)wk.strong.p, (int32_t *)wk.weak.p, d_c, wk.stream));
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream));
-    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
-    int ns = wk.h_counters[16], nw = wk.h_counters[17];
-    int64_t tot;
-    memcpy(&tot, wk.h_counters + 18, sizeof(tot));
-    if (n_strong) *n_strong = ns;
-    if (n_weak) *n_weak = nw;
-    if (sim_total) *sim_total = tot;
     const size_t per_block = bcd_bayes_scratch_bytes_per_block(w, b);
-    if (per_block && ns > 0) RCCHK(ensure(ctx, wk.gscratch, per_block * (size_t)std::min(ns, 1024)));
-    HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, ns, W, H, w, b, min_eig, d_sum, d_count,
-                                        (float *)wk.gscratch.p, wk.gscratch.bytes, wk.stream));
-    HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, nw, W, H, w, b, d_sum, d_count, wk.stream));
+    const int64_t cap = std::max<int64_t>(1, npix);
+    // persistent grids: as many workgroups as the CUs hold at once (w = 1: LDS-bound, 11 per CU; generic: 1024 scratch slices)
+    const int strong_blocks = (int)std::min<int64_t>(cap, w == 1 ? (int64_t)ctx->num_cus * 11 : 1024);
+    const int weak_blocks = (int)std::min<int64_t>(cap, (int64_t)ctx->num_cus * 32);
+    if (per_block) RCCHK(ensure(ctx, wk.gscratch, per_block * (size_t)strong_blocks));
+    HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, d_c, d_c + 4, strong_blocks, W, H, w, b, min_eig,
+                                        d_sum, d_count, (float *)wk.gscratch.p, wk.gscratch.bytes, wk.stream));
+    HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, d_c + 1, weak_blocks, W, H, w, b, d_sum, d_count, wk.stream));
     return BCD_HIP_OK;
+}
+
+void bayes_counts(const Work &wk, int64_t *n_strong, int64_t *n_weak, int64_t *sim_total)
+{
+    *n_strong = wk.h_counters[16];
+    *n_weak = wk.h_counters[17];
+    memcpy(sim_total, wk.h_counters + 18, sizeof(*sim_total));
 }
 
 float stage_ms(Work &wk, int a, int b)
@@ -281,7 +321,7 @@ float stage_ms(Work &wk, int a, int b)
 // one scale: accumulators only (d_sum / d_count are zeroed here)
 int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov,
                     int W, int H, int D, int row_begin, int row_end, const bcd_hip_params *prm, uint32_t seed, int scale,
-                    float *d_sum, int32_t *d_count)
+                    float *d_sum, int32_t *d_count, float *d_out = nullptr /* finalised image, optional */)
 {
     const int w = prm->patch_radius, b = prm->search_radius;
     const size_t npix = (size_t)W * H;
@@ -295,22 +335,44 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     st.width = W; st.height = H;
     st.main_pixels = (int64_t)std::max(0, W - 2 * w) * std::max(0, std::min(row_end, H - w) - std::max(row_begin, w));
     const bool prof = ctx->profiling;
-    if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[0], wk.stream));
-    HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, wk.stream));
-    RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p));
-    if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
-    RCCHK(active_set(ctx, wk, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, W, H, w, b, row_begin, row_end,
-                     prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)wk.state.p, &st.active_rounds));
-    if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
-    HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.stream));
-    HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), wk.stream));
+    // First attempt: the whole chain is enqueued without a host round trip -- fast division with its range flag unchecked, one
+    // fixed batch of marking launches, list lengths in device memory -- then ONE synchronisation validates the speculation
+    // (flag clear, marking converged).  If it fails (inputs outside the guarded range, unusually deep dependency chains) the
+    // scale is redone step by step with the checks in line.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool spec = attempt == 0 && !getenv("BCD_HIP_NO_SPECULATION");
+        const bool spec_marking = spec && can_speculate_marking(b, prm->use_random_pixel_order);
+        if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[0], wk.stream));
+        HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, wk.stream));
+        RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, spec ? 2 : 0));
+        if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
+        RCCHK(active_set(ctx, wk, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, W, H, w, b, row_begin, row_end,
+                         prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)wk.state.p, &st.active_rounds, spec_marking));
+        if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
+        HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.stream));
+        HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), wk.stream));
+        RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p,
+                    (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count));
+        if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[3], wk.stream));
+        if (d_out) HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, (int64_t)npix, d_out, wk.stream));
+        HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+        bool ok = true;
+        if (spec && wk.h_counters[40] != 0) ok = false;                       // range flag of the fast division
+        if (spec_marking && prm->marked_skip_probability > 0.f) {
+            const int nspec = spec_rounds();
+            int n = nspec;
+            for (int i = 0; i < nspec; ++i)
+                if (wk.h_counters[i] == 0) { n = i + 1; break; }
+            if (wk.h_counters[n - 1] != 0) ok = false;                         // marking not converged within the batch
+            st.active_rounds = n;
+        }
+        if (ok) break;
+        if (!spec) { set_err(ctx, "internal: non-speculative chain failed validation"); return BCD_HIP_EDEVICE; }
+    }
     int64_t ns = 0, nw = 0, tot = 0;
-    RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p,
-                (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count, &ns, &nw, &tot));
+    bayes_counts(wk, &ns, &nw, &tot);
     st.processed = ns + nw; st.fallback = nw; st.similar_total = tot;
     if (prof) {
-        HIPCHK(ctx, hipEventRecord(wk.ev_stage[3], wk.stream));
-        HIPCHK(ctx, hipStreamSynchronize(wk.stream));
         st.ms_similarity = stage_ms(wk, 0, 1);
         st.ms_active = stage_ms(wk, 1, 2);
         st.ms_bayes = stage_ms(wk, 2, 3);
@@ -325,9 +387,7 @@ int mono(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_ns, c
     const size_t npix = (size_t)W * H;
     RCCHK(ensure(ctx, wk.sum, npix * 3 * sizeof(float)));
     RCCHK(ensure(ctx, wk.cnt, npix * sizeof(int32_t)));
-    RCCHK(mono_accumulate(ctx, wk, d_colors, d_ns, d_hist, d_cov, W, H, D, 0, H, prm, seed, scale, (float *)wk.sum.p, (int32_t *)wk.cnt.p));
-    HIPCHK(ctx, bcd_launch_finalize((const float *)wk.sum.p, (const int32_t *)wk.cnt.p, (int64_t)npix, d_out, wk.stream));
-    return BCD_HIP_OK;
+    return mono_accumulate(ctx, wk, d_colors, d_ns, d_hist, d_cov, W, H, D, 0, H, prm, seed, scale, (float *)wk.sum.p, (int32_t *)wk.cnt.p, d_out);
 }
 
 
@@ -399,6 +459,10 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
     if (work_init(ctx, ctx->main, ctx->stream) != BCD_HIP_OK || hipEventCreateWithFlags(&ctx->ev_pyramid, hipEventDisableTiming) != hipSuccess) {
         bcd_hip_ctx_destroy(ctx);
         return BCD_HIP_EDEVICE;
+    }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) ctx->num_cus = cus;
     }
     const char *env = getenv("BCD_HIP_SERIAL_SCALES");
     ctx->concurrent_scales = !(env && env[0] == '1');
@@ -687,7 +751,7 @@ int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const floa
                              float *d_sum, int32_t *d_count)
 {
     if (!ctx || !d_colors || !d_pixcov || !d_mask || !d_nsim || !d_state || !d_sum || !d_count) return bad(ctx, "bad argument");
-    return bayes(ctx, ctx->main, d_colors, d_pixcov, d_mask, d_nsim, d_state, W, H, w, b, min_eig, d_sum, d_count, nullptr, nullptr, nullptr);
+    return bayes(ctx, ctx->main, d_colors, d_pixcov, d_mask, d_nsim, d_state, W, H, w, b, min_eig, d_sum, d_count);
 }
 
 int bcd_hip_finalize(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int64_t npix, float *d_out)

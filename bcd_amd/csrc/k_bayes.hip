@@ -214,7 +214,8 @@ __device__ int decode_members(const uint32_t *mask, int p, const BayesGeom &g, i
 
 __global__ __launch_bounds__(64) void k_bayes_strong_generic(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                      const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
-                                                     BayesGeom g, int nlist, float min_eig, float *sum, int32_t *cnt, float *gscratch)
+                                                     BayesGeom g, const int32_t *__restrict__ d_nlist, float min_eig, float *sum, int32_t *cnt,
+                                                     float *gscratch)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(64) void k_bayes_strong_generic(const float *__rest
     int *rp = reinterpret_cast<int *>(rs + KP / 2);
     int *rq = rp + KP / 2;
 
+  const int nlist = *d_nlist; // list length in device memory: no host round trip before the launch
   for (int item = blockIdx.x; item < nlist; item += gridDim.x) {
     __syncthreads();
     const int p = list[item];
@@ -283,12 +285,16 @@ __global__ __launch_bounds__(64) void k_bayes_strong_generic(const float *__rest
 
 // denoiseOnlyMainPatch (:455-481): average of the similar colour patches added to the main patch only
 __global__ __launch_bounds__(64) void k_bayes_weak(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
-                                                   const int32_t *__restrict__ list, BayesGeom g, float *sum, int32_t *cnt)
+                                                   const int32_t *__restrict__ list, const int32_t *__restrict__ d_nlist, BayesGeom g,
+                                                   float *sum, int32_t *cnt)
 {
     extern __shared__ float lds[];
     int *mem = reinterpret_cast<int *>(lds);
     const int lane = threadIdx.x, pw = 2 * g.w + 1;
-    const int p = list[blockIdx.x];
+    const int nlist = *d_nlist;
+  for (int item = blockIdx.x; item < nlist; item += gridDim.x) {
+    __syncthreads(); // mem[] of the previous item is no longer read
+    const int p = list[item];
     const int n = decode_members(mask, p, g, mem, lane);
     const float n_inv = 1.f / (float)n; // inf when n == 0, like the reference (assert compiled out, :212-213)
     for (int k = lane; k < g.K; k += 64) {
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(64) void k_bayes_weak(const float *__restrict__ col
         unsafeAtomicAdd(sum + (size_t)(p + offp) * 3 + ch, n_inv * acc);
         if (ch == 0) atomicAdd(cnt + p + offp, 1);
     }
+  }
 }
 
 BayesGeom make_geom(int W, int H, int w, int b)
@@ -343,40 +350,40 @@ size_t bcd_bayes_scratch_bytes_per_block(int w, int b)
     return 2 * (size_t)g.maxS * g.K * sizeof(float);
 }
 
-hipError_t bcd_launch_bayes27(const float *, const float *, const uint32_t *, const int32_t *, int, int, int, int, float, float *, int32_t *,
-                              hipStream_t);
+hipError_t bcd_launch_bayes27(const float *, const float *, const uint32_t *, const int32_t *, const int32_t *, int *, int, int, int, int, float,
+                              float *, int32_t *, hipStream_t);
 
-hipError_t bcd_launch_bayes_strong(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int nlist,
-                                   int W, int H, int w, int b, float min_eig, float *sum, int32_t *cnt, float *gscratch,
-                                   size_t gscratch_bytes, hipStream_t st)
+// the list lengths stay in device memory (d_nlist, written by k_active_lists); `blocks` persistent workgroups share the lists
+hipError_t bcd_launch_bayes_strong(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list,
+                                   const int32_t *d_nlist, int *d_work, int blocks, int W, int H, int w, int b, float min_eig, float *sum,
+                                   int32_t *cnt, float *gscratch, size_t gscratch_bytes, hipStream_t st)
 {
-    if (nlist <= 0) return hipSuccess;
-    if (w == 1) return bcd_launch_bayes27(colors, pixcov, mask, list, nlist, W, H, b, min_eig, sum, cnt, st);
+    if (blocks <= 0) return hipSuccess;
+    if (w == 1) return bcd_launch_bayes27(colors, pixcov, mask, list, d_nlist, d_work, blocks, W, H, b, min_eig, sum, cnt, st);
     BayesGeom g = make_geom(W, H, w, b);
     if (g.words > 32) return hipErrorInvalidValue;
     const size_t per_block = bcd_bayes_scratch_bytes_per_block(w, b);
     const size_t lds = generic_lds_bytes(w, b, per_block == 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    int blocks = nlist;
     if (per_block) {
         if (!gscratch || gscratch_bytes < per_block) return hipErrorInvalidValue;
-        blocks = (int)std::min<size_t>((size_t)nlist, gscratch_bytes / per_block);
+        blocks = (int)std::min<size_t>((size_t)blocks, gscratch_bytes / per_block);
     }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bayes_strong_generic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_bayes_strong_generic, dim3(blocks), dim3(64), lds, st, colors, pixcov, mask, list, g, nlist, min_eig, sum, cnt,
+    hipLaunchKernelGGL(k_bayes_strong_generic, dim3(blocks), dim3(64), lds, st, colors, pixcov, mask, list, g, d_nlist, min_eig, sum, cnt,
                        per_block ? gscratch : nullptr);
     return hipGetLastError();
 }
 
-hipError_t bcd_launch_bayes_weak(const float *colors, const uint32_t *mask, const int32_t *list, int nlist,
+hipError_t bcd_launch_bayes_weak(const float *colors, const uint32_t *mask, const int32_t *list, const int32_t *d_nlist, int blocks,
                                  int W, int H, int w, int b, float *sum, int32_t *cnt, hipStream_t st)
 {
-    if (nlist <= 0) return hipSuccess;
+    if (blocks <= 0) return hipSuccess;
     BayesGeom g = make_geom(W, H, w, b);
     if (g.words > 32) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_bayes_weak, dim3(nlist), dim3(64), (size_t)g.maxS * sizeof(int), st, colors, mask, list, g, sum, cnt);
+    hipLaunchKernelGGL(k_bayes_weak, dim3(blocks), dim3(64), (size_t)g.maxS * sizeof(int), st, colors, mask, list, d_nlist, g, sum, cnt);
     return hipGetLastError();
 }

@@ -22,7 +22,7 @@ __device__ long long bcd_dbg_cycles[24];
 
 namespace {
 
-#define DBG_T(i) do { if (DBG && blockIdx.x == 100 && lane == 0) bcd_dbg_cycles[i] = __builtin_readcyclecounter(); } while (0)
+#define DBG_T(i) do { if (DBG && item == 100 && lane == 0) bcd_dbg_cycles[i] = __builtin_readcyclecounter(); } while (0)
 
 constexpr int K = 27, KP = 28, LD = 29, P = 9, MSZ = KP * LD, CHUNK = MSZ / K; // 30 members per staging chunk
 
@@ -66,7 +66,7 @@ __device__ inline int sigma_slot(int s)
 // A0 holds the symmetric input (JLD layout, row/col 27 zero).  In place: the workgroup is a single wavefront, so every row is
 // in registers (ds_read, program order) before the first permuted row is written back (ds_write) -- no ping-pong buffers.
 template <bool DBG>
-__device__ void jacobi27(float *A0, float *V0, float *cs, int lane)
+__device__ void jacobi27(float *A0, float *V0, float *cs, int lane, int item)
 {
     for (int e = lane; e < K * JLD; e += 64) {
         int r = e / JLD, c = e - r * JLD;
@@ -90,7 +90,7 @@ __device__ void jacobi27(float *A0, float *V0, float *cs, int lane)
         }
         off = wsum(off);
         dg = wsum(dg);
-        if (DBG && blockIdx.x == 100 && lane == 0) bcd_dbg_cycles[12 + sweep] = (long long)(1e18f * off / dg);
+        if (DBG && item == 100 && lane == 0) bcd_dbg_cycles[12 + sweep] = (long long)(1e18f * off / dg);
         if (off <= 1e-13f * dg) break;
         for (int round = 0; round < KP - 1; ++round) {
             if (lane < KP / 2) {
@@ -369,7 +369,8 @@ __device__ inline void stage_chunk(float *chunk, const float *__restrict__ color
 template <bool DBG>
 __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                 const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
-                                                Geom27 g, float min_eig, float *sum, int32_t *cnt)
+                                                const int32_t *__restrict__ d_nlist, int *work, Geom27 g, float min_eig, float *sum,
+                                                int32_t *cnt)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
@@ -381,8 +382,16 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     float *fl = mean + K + 1;
     int *mem = reinterpret_cast<int *>(fl + KP);
 
+    // persistent wavefronts: the list length lives in device memory (no host round trip between the marking and this
+    // launch), items are handed out through an atomic counter
+    const int nlist = *d_nlist;
+  for (;;) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(work, 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= nlist) break;
     DBG_T(0);
-    const int p = list[blockIdx.x];
+    const int p = list[item];
     const int n = decode_members27(mask, p, g, mem, lane);
     DBG_T(1);
     const float n_inv = 1.f / (float)n;
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     add_noise27(A, noise, lane, -1.f);
     to_jacobi_layout(Bm, A, lane);
     {
-        jacobi27<DBG>(Bm, V, cs, lane);
+        jacobi27<DBG>(Bm, V, cs, lane, item);
         DBG_T(5);
         rebuild27(Bm, Bm, V, fl, lane, false, 0.f); // reads the eigenvalues (diagonal) before it overwrites Bm: M1 lives in Bm
     }
@@ -533,7 +542,9 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
         }
     }
     DBG_T(10);
-    if (DBG && blockIdx.x == 100 && lane == 0) bcd_dbg_cycles[11] = n;
+    if (DBG && item == 100 && lane == 0) bcd_dbg_cycles[11] = n;
+    __syncthreads(); // the next item reuses the LDS
+  }
 }
 
 } // namespace
@@ -544,22 +555,22 @@ size_t bcd_bayes27_lds_bytes(int b)
     return (size_t)(4 * MSZ + 2 * KP + P * 6 + (K + 1) + KP + side * side) * sizeof(float);
 }
 
-hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int nlist,
-                              int W, int H, int b, float min_eig, float *sum, int32_t *cnt, hipStream_t st)
+hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, const int32_t *d_nlist,
+                              int *d_work, int blocks, int W, int H, int b, float min_eig, float *sum, int32_t *cnt, hipStream_t st)
 {
-    if (nlist <= 0) return hipSuccess;
+    if (blocks <= 0) return hipSuccess;
     Geom27 g;
     g.W = W; g.H = H; g.b = b; g.side = 2 * b + 1; g.words = (g.side * g.side + 31) / 32; g.maxS = g.side * g.side;
     if (g.words > 32) return hipErrorInvalidValue;
     if (getenv("BCD_DBG_BAYES")) {
-        hipLaunchKernelGGL(k_bayes27<true>, dim3(nlist), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
+        hipLaunchKernelGGL(k_bayes27<true>, dim3(blocks), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, d_nlist, d_work, g, min_eig, sum, cnt);
         long long h[24];
-        hipStreamSynchronize(st);
-        hipMemcpyFromSymbol(h, HIP_SYMBOL(bcd_dbg_cycles), sizeof(h));
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(bcd_dbg_cycles), sizeof(h));
         fprintf(stderr, "sweeps off2/dg2 x1e18:"); for (int i = 12; i < 24; ++i) fprintf(stderr, " %lld", h[i]); fprintf(stderr, "\n");
         fprintf(stderr, "bayes27 dbg n=%lld: decode %lld noise %lld mean %lld cov %lld jacobi %lld rebuild %lld inv1 %lld step2mm %lld inv2 %lld final %lld total %lld\n", h[11], h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5], h[7]-h[6], h[8]-h[7], h[9]-h[8], h[10]-h[9], h[10]-h[0]);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_bayes27<false>, dim3(nlist), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, g, min_eig, sum, cnt);
+    hipLaunchKernelGGL(k_bayes27<false>, dim3(blocks), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, d_nlist, d_work, g, min_eig, sum, cnt);
     return hipGetLastError();
 }
