@@ -45,15 +45,7 @@ hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t 
 namespace {
 
 constexpr int MAX_SCALES = 16;
-constexpr int ROUND_BATCH = 8;
-constexpr int SPEC_ROUNDS = 6; // marking launches of a speculative chain (dependency extraction + 5 rounds)
-// BCD_HIP_SPEC_ROUNDS=n (2..8) overrides it: the parity tests use a batch that is too short to exercise the redo path
-int spec_rounds()
-{
-    const char *e = getenv("BCD_HIP_SPEC_ROUNDS");
-    int n = e ? atoi(e) : SPEC_ROUNDS;
-    return n < 2 ? 2 : (n > ROUND_BATCH ? ROUND_BATCH : n);
-}
+constexpr int ROUND_BATCH = 16;
 constexpr int MAX_EVENT_PAIRS = 4096;
 
 struct DevBuf {
@@ -69,6 +61,7 @@ struct Work {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, gscratch, dep; // grow-only
+    int rounds_hint = 0;           // marking launches the last problem needed
     bool dep_ready = false;        // dependency lists of the current marking problem are in `dep` (reset by active_init)
     int32_t *h_counters = nullptr; // pinned
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; // pair-distance kernel timing
@@ -210,13 +203,15 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
         const int side = 2 * b + 1, words = (side * side + 31) / 32;
         const int iters = 8; // in-tile iterations per launch
         int i = 0;
-        batch = random_order ? 2 : ROUND_BATCH;
+        batch = random_order ? 3 : ROUND_BATCH;
         if (!wk.dep_ready) {
             RCCHK(ensure(ctx, wk.dep, (size_t)W * H * words * sizeof(uint32_t)));
             HIPCHK(ctx, bcd_launch_mark_deps(d_mask, d_nsim, d_state, (uint32_t *)wk.dep.p, W, H, b, K + 1, random_order, seed,
                                              row_begin, row_end, row_offset, d_cnt + i++, wk.stream));
             wk.dep_ready = true;
-            if (random_order) batch = 5;
+            // first batch: what the previous marking problem of this workspace needed, plus one (frames of a sequence and
+            // the bands of a frame behave alike), so that the usual case costs a single host round trip
+            if (random_order) batch = std::min(ROUND_BATCH, std::max(5, wk.rounds_hint + 1));
         }
         for (; i < batch; ++i)
             HIPCHK(ctx, bcd_launch_mark_round((const uint32_t *)wk.dep.p, d_state, W, H, b, row_begin, row_end, iters, d_cnt + i, wk.stream));
@@ -235,33 +230,12 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
     return BCD_HIP_OK;
 }
 
-// speculative = true: one fixed batch of marking launches without reading the counters back; the per-launch undecided counts
-// are copied to wk.h_counters[0..ROUND_BATCH) and the caller checks, after its own synchronisation, that the last one is 0
-// (active_set_outcome).  Only offered where the batch normally suffices: list kernels and a random order.
-bool can_speculate_marking(int b, int random_order) { return (b == 6 || b == 12) && random_order; }
-
 int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
-               int row_end, float skip_prob, int random_order, uint32_t seed, uint8_t *d_state, int32_t *rounds_out, bool speculative = false)
+               int row_end, float skip_prob, int random_order, uint32_t seed, uint8_t *d_state, int32_t *rounds_out)
 {
     HIPCHK(ctx, bcd_launch_active_init(d_nsim, W, H, w, row_begin, row_end, skip_prob, seed, 0, d_state, wk.stream));
     wk.dep_ready = false;
     int rounds = 0;
-    if (speculative && skip_prob > 0.f) {
-        const int K = 3 * (2 * w + 1) * (2 * w + 1), side = 2 * b + 1, words = (side * side + 31) / 32;
-        RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
-        RCCHK(ensure(ctx, wk.dep, (size_t)W * H * words * sizeof(uint32_t)));
-        int *d_cnt = (int *)wk.counters.p;
-        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), wk.stream));
-        HIPCHK(ctx, bcd_launch_mark_deps(d_mask, d_nsim, d_state, (uint32_t *)wk.dep.p, W, H, b, K + 1, random_order, seed, row_begin, row_end, 0,
-                                         d_cnt, wk.stream));
-        wk.dep_ready = true;
-        const int nspec = spec_rounds();
-        for (int i = 1; i < nspec; ++i)
-            HIPCHK(ctx, bcd_launch_mark_round((const uint32_t *)wk.dep.p, d_state, W, H, b, row_begin, row_end, 8, d_cnt + i, wk.stream));
-        HIPCHK(ctx, hipMemcpyAsync(wk.h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, wk.stream));
-        if (rounds_out) *rounds_out = nspec;
-        return BCD_HIP_OK;
-    }
     if (skip_prob > 0.f) {
         const int max_rounds = 4 * (W + H) + 64;
         int undecided = 1;
@@ -272,6 +246,7 @@ int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t
             rounds += n;
         }
         if (undecided != 0) { set_err(ctx, "marking fixed point did not converge"); return BCD_HIP_EDEVICE; }
+        wk.rounds_hint = rounds;
     }
     if (rounds_out) *rounds_out = rounds;
     return BCD_HIP_OK;
@@ -335,40 +310,28 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     st.width = W; st.height = H;
     st.main_pixels = (int64_t)std::max(0, W - 2 * w) * std::max(0, std::min(row_end, H - w) - std::max(row_begin, w));
     const bool prof = ctx->profiling;
-    // First attempt: the whole chain is enqueued without a host round trip -- fast division with its range flag unchecked, one
-    // fixed batch of marking launches, list lengths in device memory -- then ONE synchronisation validates the speculation
-    // (flag clear, marking converged).  If it fails (inputs outside the guarded range, unusually deep dependency chains) the
-    // scale is redone step by step with the checks in line.
+    // Host round trips of a scale: one per batch of marking launches (normally a single batch; it also brings the range flag of
+    // the fast division back), and one at the end for the counters.  The estimate kernels take their list lengths from device
+    // memory, the finalisation is enqueued before the last synchronisation.
+    if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[0], wk.stream));
+    HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, wk.stream));
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const bool spec = attempt == 0 && !getenv("BCD_HIP_NO_SPECULATION");
-        const bool spec_marking = spec && can_speculate_marking(b, prm->use_random_pixel_order);
-        if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[0], wk.stream));
-        HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, wk.stream));
-        RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, spec ? 2 : 0));
-        if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
+        RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, attempt == 0 ? 2 : 1));
+        if (prof && attempt == 0) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
         RCCHK(active_set(ctx, wk, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, W, H, w, b, row_begin, row_end,
-                         prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)wk.state.p, &st.active_rounds, spec_marking));
-        if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
-        HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.stream));
-        HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), wk.stream));
-        RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p,
-                    (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count));
-        if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[3], wk.stream));
-        if (d_out) HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, (int64_t)npix, d_out, wk.stream));
-        HIPCHK(ctx, hipStreamSynchronize(wk.stream));
-        bool ok = true;
-        if (spec && wk.h_counters[40] != 0) ok = false;                       // range flag of the fast division
-        if (spec_marking && prm->marked_skip_probability > 0.f) {
-            const int nspec = spec_rounds();
-            int n = nspec;
-            for (int i = 0; i < nspec; ++i)
-                if (wk.h_counters[i] == 0) { n = i + 1; break; }
-            if (wk.h_counters[n - 1] != 0) ok = false;                         // marking not converged within the batch
-            st.active_rounds = n;
-        }
-        if (ok) break;
-        if (!spec) { set_err(ctx, "internal: non-speculative chain failed validation"); return BCD_HIP_EDEVICE; }
+                         prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)wk.state.p, &st.active_rounds));
+        if (attempt == 1) break;
+        if (!(prm->marked_skip_probability > 0.f)) HIPCHK(ctx, hipStreamSynchronize(wk.stream)); // no marking batch brought the flag back
+        if (wk.h_counters[40] == 0) break; // every input inside the range where the fast division is proven exact
     }
+    if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
+    HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.stream));
+    HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), wk.stream));
+    RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p,
+                (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count));
+    if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[3], wk.stream));
+    if (d_out) HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, (int64_t)npix, d_out, wk.stream));
+    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
     int64_t ns = 0, nw = 0, tot = 0;
     bayes_counts(wk, &ns, &nw, &tot);
     st.processed = ns + nw; st.fallback = nw; st.similar_total = tot;
