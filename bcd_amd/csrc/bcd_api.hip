@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -60,7 +61,7 @@ struct DevBuf {
 struct Work {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, gscratch, dep; // grow-only
+    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, gscratch, dep, tmp_lo; // grow-only
     int rounds_hint = 0;           // marking launches the last problem needed
     bool dep_ready = false;        // dependency lists of the current marking problem are in `dep` (reset by active_init)
     int32_t *h_counters = nullptr; // pinned
@@ -68,6 +69,7 @@ struct Work {
     int ev_used = 0;
     hipEvent_t ev_stage[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t ev_done = nullptr;
+    hipEvent_t ev_built = nullptr; // this scale's pyramid level is complete
 };
 
 struct bcd_hip_ctx {
@@ -344,6 +346,28 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     return BCD_HIP_OK;
 }
 
+// mergeOutputs (MultiscaleDenoiser.cpp:453-466) on a workspace's stream: hi -= up(down(hi)); hi += up(lo)
+int merge_on(bcd_hip_ctx *ctx, Work &wk, float *d_hi, int W, int H, const float *d_lo, int D)
+{
+    const int w2 = W / 2, h2 = H / 2;
+    RCCHK(ensure(ctx, wk.tmp_lo, (size_t)w2 * h2 * D * sizeof(float)));
+    HIPCHK(ctx, bcd_launch_downscale(1, d_hi, W, H, D, (float *)wk.tmp_lo.p, wk.stream));
+    HIPCHK(ctx, bcd_launch_interpolate(1, (const float *)wk.tmp_lo.p, w2, h2, D, d_hi, W, H, wk.stream));
+    HIPCHK(ctx, bcd_launch_interpolate(2, d_lo, w2, h2, D, d_hi, W, H, wk.stream));
+    return BCD_HIP_OK;
+}
+
+// one pyramid level from the finer one (MultiscaleDenoiser.cpp:41-53) on `st`
+int build_level(bcd_hip_ctx *ctx, const float *col, const float *ns, const float *hs, const float *cv, int W, int H, int D,
+                DevBuf (&lvl)[5], hipStream_t st)
+{
+    HIPCHK(ctx, bcd_launch_downscale(1, col, W, H, 3, (float *)lvl[0].p, st));
+    HIPCHK(ctx, bcd_launch_downscale(0, ns, W, H, 1, (float *)lvl[1].p, st));
+    HIPCHK(ctx, bcd_launch_downscale(0, hs, W, H, D, (float *)lvl[2].p, st));
+    HIPCHK(ctx, bcd_launch_downscale_cov(cv, ns, W, H, (float *)lvl[3].p, st));
+    return BCD_HIP_OK;
+}
+
 int mono(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov, int W, int H, int D,
          const bcd_hip_params *prm, uint32_t seed, int scale, float *d_out)
 {
@@ -365,17 +389,19 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
     HIPCHK(ctx, hipHostMalloc((void **)&w.h_counters, 64 * sizeof(int32_t), hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipEventCreate(&w.ev_stage[i]));
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_built, hipEventDisableTiming));
     return BCD_HIP_OK;
 }
 
 void work_destroy(Work &w)
 {
-    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep };
+    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep, &w.tmp_lo };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (w.h_counters) (void)hipHostFree(w.h_counters);
     for (auto &pr : w.ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (int i = 0; i < 4; ++i) if (w.ev_stage[i]) (void)hipEventDestroy(w.ev_stage[i]);
     if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+    if (w.ev_built) (void)hipEventDestroy(w.ev_built);
     if (w.owns_stream && w.stream) (void)hipStreamDestroy(w.stream);
 }
 
@@ -528,37 +554,65 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
         RCCHK(ensure(ctx, ctx->pyr[s][2], np * D * sizeof(float)));
         RCCHK(ensure(ctx, ctx->pyr[s][3], np * 6 * sizeof(float)));
         RCCHK(ensure(ctx, ctx->pyr[s][4], np * 3 * sizeof(float)));
-        HIPCHK(ctx, bcd_launch_downscale(1, col[s - 1], ws[s - 1], hh[s - 1], 3, (float *)ctx->pyr[s][0].p, ctx->stream));
-        HIPCHK(ctx, bcd_launch_downscale(0, ns[s - 1], ws[s - 1], hh[s - 1], 1, (float *)ctx->pyr[s][1].p, ctx->stream));
-        HIPCHK(ctx, bcd_launch_downscale(0, hs[s - 1], ws[s - 1], hh[s - 1], D, (float *)ctx->pyr[s][2].p, ctx->stream));
-        HIPCHK(ctx, bcd_launch_downscale_cov(cv[s - 1], ns[s - 1], ws[s - 1], hh[s - 1], (float *)ctx->pyr[s][3].p, ctx->stream));
         col[s] = (float *)ctx->pyr[s][0].p; ns[s] = (float *)ctx->pyr[s][1].p; hs[s] = (float *)ctx->pyr[s][2].p;
         cv[s] = (float *)ctx->pyr[s][3].p; out[s] = (float *)ctx->pyr[s][4].p;
     }
     // ---- the scales are independent until the merges (MultiscaleDenoiser.cpp:79-134 runs them coarse to fine, but each
-    // Denoiser only reads its own pyramid level): run them concurrently, one stream + host thread + workspace per scale
+    // Denoiser only reads its own pyramid level): one stream + host thread + workspace per scale.  Scale s > 0 builds its
+    // own pyramid level on its stream (from level s-1, once that is complete), so that the finest scale -- the critical
+    // path -- starts at once; after its own chain scale s merges the (already merged) scale s+1 into its output.
     if (ctx->concurrent_scales) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_pyramid, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pyramid, ctx->stream)); // the caller's inputs are ready
         int rcs[MAX_SCALES];
         std::thread threads[MAX_SCALES];
+        std::atomic<int> built[MAX_SCALES], done[MAX_SCALES]; // 0 = pending, 1 = event recorded, -1 = failed
+        for (int s = 0; s < MAX_SCALES; ++s) { built[s].store(0); done[s].store(0); }
         for (int s = 1; s < nb_scales; ++s) RCCHK(work_init(ctx, ctx->extra[s], nullptr));
+        auto await = [](std::atomic<int> &f) { int v; while ((v = f.load()) == 0) std::this_thread::yield(); return v; };
         for (int s = nb_scales - 1; s >= 0; --s) {
             Work *w = s == 0 ? &ctx->main : &ctx->extra[s];
             rcs[s] = BCD_HIP_OK;
-            auto job = [=, &rcs]() {
-                if (hipSetDevice(ctx->device) != hipSuccess) { rcs[s] = BCD_HIP_EDEVICE; return; }
-                if (s != 0 && hipStreamWaitEvent(w->stream, ctx->ev_pyramid, 0) != hipSuccess) { rcs[s] = BCD_HIP_EDEVICE; return; }
-                rcs[s] = mono(ctx, *w, col[s], ns[s], hs[s], cv[s], ws[s], hh[s], D, prm, bcd_hip_scale_seed(prm->order_seed, s), s, out[s]);
-                if (rcs[s] == BCD_HIP_OK && s != 0 && hipEventRecord(w->ev_done, w->stream) != hipSuccess) rcs[s] = BCD_HIP_EDEVICE;
+            auto job = [&, s, w]() {
+                int rc = BCD_HIP_OK;
+                bool built_set = s == 0, done_set = s == 0;
+                do {
+                    if (hipSetDevice(ctx->device) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+                    if (s != 0) {
+                        if (hipStreamWaitEvent(w->stream, ctx->ev_pyramid, 0) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+                        if (s >= 2) {
+                            if (await(built[s - 1]) < 0) { rc = BCD_HIP_EDEVICE; break; }
+                            if (hipStreamWaitEvent(w->stream, ctx->extra[s - 1].ev_built, 0) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+                        }
+                        rc = build_level(ctx, col[s - 1], ns[s - 1], hs[s - 1], cv[s - 1], ws[s - 1], hh[s - 1], D, ctx->pyr[s], w->stream);
+                        if (rc != BCD_HIP_OK) break;
+                        if (hipEventRecord(w->ev_built, w->stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+                        built[s].store(1); built_set = true;
+                    }
+                    rc = mono(ctx, *w, col[s], ns[s], hs[s], cv[s], ws[s], hh[s], D, prm, bcd_hip_scale_seed(prm->order_seed, s), s, out[s]);
+                    if (rc != BCD_HIP_OK) break;
+                    if (s < nb_scales - 1) {
+                        if (await(done[s + 1]) < 0) { rc = BCD_HIP_EDEVICE; break; }
+                        if (hipStreamWaitEvent(w->stream, ctx->extra[s + 1].ev_done, 0) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+                        rc = merge_on(ctx, *w, out[s], ws[s], hh[s], out[s + 1], 3);
+                        if (rc != BCD_HIP_OK) break;
+                    }
+                    if (s != 0) {
+                        if (hipEventRecord(w->ev_done, w->stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+                        done[s].store(1); done_set = true;
+                    }
+                } while (false);
+                if (!built_set) built[s].store(-1); // never leave a waiter spinning
+                if (!done_set) done[s].store(-1);
+                rcs[s] = rc;
             };
             if (s == 0) job(); else threads[s] = std::thread(job);
         }
         for (int s = 1; s < nb_scales; ++s) threads[s].join();
         for (int s = 0; s < nb_scales; ++s) RCCHK(rcs[s]);
-        for (int s = 1; s < nb_scales; ++s) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->extra[s].ev_done, 0));
-        for (int s = nb_scales - 2; s >= 0; --s) RCCHK(bcd_hip_merge(ctx, out[s], ws[s], hh[s], out[s + 1], 3));
         return BCD_HIP_OK;
     }
+    for (int s = 1; s < nb_scales; ++s)
+        RCCHK(build_level(ctx, col[s - 1], ns[s - 1], hs[s - 1], cv[s - 1], ws[s - 1], hh[s - 1], D, ctx->pyr[s], ctx->stream));
     // ---- coarse to fine, one after the other
     for (int s = nb_scales - 1; s >= 0; --s) {
         RCCHK(mono(ctx, ctx->main, col[s], ns[s], hs[s], cv[s], ws[s], hh[s], D, prm, bcd_hip_scale_seed(prm->order_seed, s), s, out[s]));
@@ -755,13 +809,7 @@ int bcd_hip_interpolate(bcd_hip_ctx *ctx, const float *d_lo, int w, int h, int D
 int bcd_hip_merge(bcd_hip_ctx *ctx, float *d_hi, int W, int H, const float *d_lo, int D)
 {
     if (!ctx || !d_hi || !d_lo || W < 2 || H < 2 || D <= 0) return bad(ctx, "bad argument");
-    const int w2 = W / 2, h2 = H / 2;
-    RCCHK(ensure(ctx, ctx->tmp_lo, (size_t)w2 * h2 * D * sizeof(float)));
-    // mergeOutputs (MultiscaleDenoiser.cpp:453-466): hi -= up(down(hi)); hi += up(lo)
-    HIPCHK(ctx, bcd_launch_downscale(1, d_hi, W, H, D, (float *)ctx->tmp_lo.p, ctx->stream));
-    HIPCHK(ctx, bcd_launch_interpolate(1, (const float *)ctx->tmp_lo.p, w2, h2, D, d_hi, W, H, ctx->stream));
-    HIPCHK(ctx, bcd_launch_interpolate(2, d_lo, w2, h2, D, d_hi, W, H, ctx->stream));
-    return BCD_HIP_OK;
+    return merge_on(ctx, ctx->main, d_hi, W, H, d_lo, D);
 }
 
 int bcd_hip_spike_filter(bcd_hip_ctx *ctx, const float *d_col, const float *d_ns, const float *d_hist, const float *d_cov, int W, int H,
