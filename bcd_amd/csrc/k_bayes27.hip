@@ -63,24 +63,22 @@ __device__ inline int sigma_slot(int s)
     return s == 0 ? 0 : (s == 1 ? 2 : (s == 26 ? 27 : ((s & 1) ? s - 2 : s + 2)));
 }
 
-// A0 holds the symmetric input (JLD layout, row/col 27 zero).  In place: the workgroup is a single wavefront, so every row is
-// in registers (ds_read, program order) before the first permuted row is written back (ds_write) -- no ping-pong buffers.
+// A0 holds the symmetric input (JLD layout, row/col 27 zero).  The kernel is bound by LDS bandwidth (measured: 21 KB per
+// wavefront and round with everything staged through LDS), so only what must change lanes goes through LDS:
+//   * rows of A (lanes 0..27) are stored at their Brent-Luk permuted slot and reloaded -- in place: the workgroup is a single
+//     wavefront, every row is in registers before the first permuted row is written back;
+//   * rows of V (lanes 32..58) never move between lanes and stay in registers for the whole solve;
+//   * the 14 rotations (c, s) are broadcast with v_readlane (wave-uniform SGPR operands of the column rotations).
 template <bool DBG>
-__device__ void jacobi27(float *A0, float *V0, float *cs, int lane, int item)
+__device__ void jacobi27(float *A0, float *V0, int lane, int item)
 {
-    for (int e = lane; e < K * JLD; e += 64) {
-        int r = e / JLD, c = e - r * JLD;
-        V0[e] = (r == c) ? 1.f : 0.f;
-    }
-    __syncthreads();
     const bool isA = lane < KP, isV = lane >= 32 && lane < 32 + K;
     const int vrow = lane - 32;
-    // per-lane row addresses, hoisted out of the round loop: source row, and destination row at the Brent-Luk permuted
-    // position (A) / the same position (V); idle lanes read row 0 of A and dump into the spare row 28 of A (MSZ = 29 rows of
-    // 28 floats), so that the stores need no branch
-    const float *src = isA ? A0 + lane * JLD : (isV ? V0 + vrow * JLD : A0);
-    float *dst = isA ? A0 + sigma_slot(lane) * JLD : (isV ? V0 + vrow * JLD : A0 + KP * JLD);
-    const int mypair = isA ? (lane >> 1) : 0;
+    const float *src = A0 + (isA ? lane : 0) * JLD;
+    float *dst = A0 + (isA ? sigma_slot(lane) : 0) * JLD;
+    float row[JLD];
+#pragma unroll
+    for (int k = 0; k < JLD; ++k) row[k] = (isV && k == vrow) ? 1.f : 0.f; // V = identity
     for (int sweep = 0; sweep < 12; ++sweep) {
         float off = 0.f, dg = 0.f;
         for (int e = lane; e < KP * JLD; e += 64) {
@@ -93,10 +91,11 @@ __device__ void jacobi27(float *A0, float *V0, float *cs, int lane, int item)
         if (DBG && item == 100 && lane == 0) bcd_dbg_cycles[12 + sweep] = (long long)(1e18f * off / dg);
         if (off <= 1e-13f * dg) break;
         for (int round = 0; round < KP - 1; ++round) {
-            if (lane < KP / 2) {
-                int p = 2 * lane, q = p + 1;
-                float apq = A0[p * JLD + q], c = 1.f, s = 0.f;
-                float app = A0[p * JLD + p], aqq = A0[q * JLD + q];
+            // lanes 0..13: rotation of the slot pair (2 lane, 2 lane + 1); the other lanes compute on a harmless copy of pair 0
+            float c = 1.f, s = 0.f;
+            {
+                const int p = lane < KP / 2 ? 2 * lane : 0, q = p + 1;
+                const float apq = A0[p * JLD + q], app = A0[p * JLD + p], aqq = A0[q * JLD + q];
                 if (apq != 0.f) {
                     // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working
                     // precision (c^2 + s^2 = 1 +- 1e-7), not the exact minimiser
@@ -107,38 +106,48 @@ __device__ void jacobi27(float *A0, float *V0, float *cs, int lane, int item)
                     s = t * c;
                     if (!(fabsf(theta) < 1e18f)) { c = 1.f; s = 0.f; } // theta^2 overflows: the rotation is the identity to fp32
                 }
-                cs[2 * lane] = c; cs[2 * lane + 1] = s;
             }
-            __syncthreads();
-            float row[JLD], rot[JLD];
+            if (isA) {
 #pragma unroll
-            for (int q4 = 0; q4 < JLD / 4; ++q4) {
-                float4 v = reinterpret_cast<const float4 *>(src)[q4];
-                float4 w = reinterpret_cast<const float4 *>(cs)[q4];
-                row[4 * q4] = v.x; row[4 * q4 + 1] = v.y; row[4 * q4 + 2] = v.z; row[4 * q4 + 3] = v.w;
-                rot[4 * q4] = w.x; rot[4 * q4 + 1] = w.y; rot[4 * q4 + 2] = w.z; rot[4 * q4 + 3] = w.w;
+                for (int q4 = 0; q4 < JLD / 4; ++q4) {
+                    float4 v = reinterpret_cast<const float4 *>(src)[q4];
+                    row[4 * q4] = v.x; row[4 * q4 + 1] = v.y; row[4 * q4 + 2] = v.z; row[4 * q4 + 3] = v.w;
+                }
             }
-            // column rotations: (x, y) <- (c x - s y, s x + c y) for every slot pair
+            // column rotations: (x, y) <- (c x - s y, s x + c y) for every slot pair, (c, s) wave-uniform
 #pragma unroll
             for (int j = 0; j < KP / 2; ++j) {
-                float c = rot[2 * j], s = rot[2 * j + 1], x = row[2 * j], y = row[2 * j + 1];
-                row[2 * j] = fmaf(c, x, -s * y);
-                row[2 * j + 1] = fmaf(s, x, c * y);
+                const float cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), j));
+                const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), j));
+                const float x = row[2 * j], y = row[2 * j + 1];
+                row[2 * j] = fmaf(cj, x, -sj * y);
+                row[2 * j + 1] = fmaf(sj, x, cj * y);
             }
-            // row rotations of A: rows (2i, 2i+1) live in lanes (2i, 2i+1); the V lanes apply the identity (1, 0), exact
-            // because every entry of V is finite
-            const float2 mine = reinterpret_cast<const float2 *>(cs)[mypair];
-            const float mc = isA ? mine.x : 1.f, ms = isA ? ((lane & 1) ? mine.y : -mine.y) : 0.f;
+            // row rotations of A: rows (2i, 2i+1) live in lanes (2i, 2i+1) and take the rotation of lane i; the V lanes apply
+            // the identity (1, 0), exact because every entry of V is finite
+            const float pc = __shfl(c, lane >> 1), ps = __shfl(s, lane >> 1);
+            const float mc = isA ? pc : 1.f, ms = isA ? ((lane & 1) ? ps : -ps) : 0.f;
             float out[JLD];
 #pragma unroll
             for (int k = 0; k < JLD; ++k)
                 out[sigma_slot(k)] = fmaf(mc, row[k], dpp_xor1(row[k]) * ms); // + Brent-Luk column move (register renaming)
 #pragma unroll
-            for (int q4 = 0; q4 < JLD / 4; ++q4)
-                reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
+            for (int k = 0; k < JLD; ++k) row[k] = out[k];
+            if (isA) {
+#pragma unroll
+                for (int q4 = 0; q4 < JLD / 4; ++q4)
+                    reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
+            }
             __syncthreads();
         }
     }
+    // eigenvectors: the V lanes publish their rows (columns are back in slot order after every complete sweep)
+    if (isV) {
+#pragma unroll
+        for (int q4 = 0; q4 < JLD / 4; ++q4)
+            reinterpret_cast<float4 *>(V0 + vrow * JLD)[q4] = make_float4(row[4 * q4], row[4 * q4 + 1], row[4 * q4 + 2], row[4 * q4 + 3]);
+    }
+    __syncthreads();
 }
 
 // out (LD layout) = V f(lambda) V^T ; f = max(0,.) (clamp) or 1/max(minEig,.) (inverse); A, V in the Jacobi (JLD) layout
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     add_noise27(A, noise, lane, -1.f);
     to_jacobi_layout(Bm, A, lane);
     {
-        jacobi27<DBG>(Bm, V, cs, lane, item);
+        jacobi27<DBG>(Bm, V, lane, item);
         DBG_T(5);
         rebuild27(Bm, Bm, V, fl, lane, false, 0.f); // reads the eigenvalues (diagonal) before it overwrites Bm: M1 lives in Bm
     }
