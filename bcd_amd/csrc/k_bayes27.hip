@@ -26,6 +26,8 @@ namespace {
 
 constexpr int K = 27, KP = 28, LD = 29, P = 9, MSZ = KP * LD, CHUNK = MSZ / K; // 30 members per staging chunk
 
+typedef float v16f __attribute__((ext_vector_type(16)));
+
 struct Geom27 {
     int W, H, b, side, words, maxS;
 };
@@ -430,35 +432,37 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
         __syncthreads();
     }
     DBG_T(3);
-    // centerPointCloud + empiricalCovarianceMatrix (:511-536): 378 lower-triangle entries, 6 per lane
+    // centerPointCloud + empiricalCovarianceMatrix (:511-536) on the matrix core: C = Xc^T Xc, two members per
+    // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: a chain of fma in member order, i.e. the reference's sequential sum with the
+    // product fused; A and B operands are the same centred value, so the result is bitwise symmetric).
+    // Operand layout: lane l holds element i = l & 31 of member 2s + (l >> 5); rows/columns 27..31 are zero.
     {
-        constexpr int NE = (K * (K + 1) / 2 + 63) / 64;
-        int er[NE], ec[NE];
-        float acc[NE], mr[NE], mc[NE];
+        const int mi = lane & 31, mk = lane >> 5;
+        const float my_mean = mi < K ? mean[mi] : 0.f;
+        v16f acc;
 #pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            int e = lane + it * 64, r = 0;
-            if (e >= K * (K + 1) / 2) e = 0;
-            while (e > r) { e -= r + 1; ++r; }
-            er[it] = r; ec[it] = e; acc[it] = 0.f; mr[it] = mean[r]; mc[it] = mean[e];
-        }
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         for (int i0 = 0; i0 < n; i0 += CHUNK) {
             int cn = min(CHUNK, n - i0);
             stage_chunk(chunk, colors, mem, i0, cn, W, lane);
-            for (int i = 0; i < cn; ++i) {
-#pragma unroll
-                for (int it = 0; it < NE; ++it) acc[it] += (chunk[i * K + er[it]] - mr[it]) * (chunk[i * K + ec[it]] - mc[it]);
+            for (int s2 = 0; s2 < cn; s2 += 2) {
+                const int m = s2 + mk;
+                const float a = (m < cn && mi < K) ? chunk[m * K + mi] - my_mean : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
             }
             __syncthreads();
         }
         const float inv = 1.f / (float)(n - 1);
+        // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-        for (int it = 0; it < NE; ++it)
-            if (lane + it * 64 < K * (K + 1) / 2) {
-                float v = acc[it] * inv;
-                A[er[it] * LD + ec[it]] = v; A[ec[it] * LD + er[it]] = v;
-                Cm[er[it] * LD + ec[it]] = v; Cm[ec[it] * LD + er[it]] = v;
+        for (int e = 0; e < 16; ++e) {
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * mk;
+            if (r < K && mi < K) {
+                const float v = acc[e] * inv;
+                A[r * LD + mi] = v;
+                Cm[r * LD + mi] = v;
             }
+        }
         __syncthreads();
     }
 
