@@ -153,23 +153,7 @@ __device__ void jacobi27(float *A0, float *V0, int lane, int item)
 }
 
 // out (LD layout) = V f(lambda) V^T ; f = max(0,.) (clamp) or 1/max(minEig,.) (inverse); A, V in the Jacobi (JLD) layout
-__device__ void rebuild27(float *out, const float *A, const float *V, float *fl, int lane, bool inverse, float min_eig)
-{
-    if (lane < KP) {
-        float lam = A[lane * JLD + lane];
-        fl[lane] = inverse ? 1.f / fmaxf(min_eig, lam) : fmaxf(0.f, lam);
-    }
-    __syncthreads();
-    for (int e = lane; e < K * K; e += 64) {
-        int r = e / K, c = e - r * K;
-        float s = 0.f;
-#pragma unroll 7
-        for (int k = 0; k < KP; ++k) s = fmaf(V[r * JLD + k], fl[k] * V[c * JLD + k], s);
-        out[r * LD + c] = s;
-    }
-    __syncthreads();
-}
-
+__device__ void rebuild27(float *out, const float *A, const float *V, float *fl, int lane, bool inverse, float min_eig);
 // JLD-layout copy of the lower triangle of M (LD layout), mirrored, padding row/column zeroed (what Eigen's
 // SelfAdjointEigenSolver reads)
 __device__ void to_jacobi_layout(float *J, const float *M, int lane)
@@ -330,18 +314,42 @@ __device__ void noise_times27(float *out, const float *noise, const float *in, i
     __syncthreads();
 }
 
-// out = X * Y (TRANS_Y == false) or X * Y^T (TRANS_Y == true); out must not alias X or Y
-template <bool TRANS_Y>
-__device__ void matmul27(float *out, const float *X, const float *Y, int lane)
+// 27 x 27 products on the f32 matrix core (v_mfma_f32_32x32x2_f32: exact f32, a chain of fma over k):
+//   out[i][j] = sum_k X[i][k] (* scale[k]) * Y[k][j]      (TRANS_Y: Y[j][k]),   k < kdim <= 28,
+// lane l feeds A[i = l & 31][k = 2s + (l >> 5)] and B[k][j = l & 31]; rows / columns 27..31 are zero padding.
+// All operands are in registers before the first store (single wavefront), so `out` may alias X or Y.
+template <bool TRANS_Y, bool SCALE>
+__device__ void mfma27(float *out, int ldo, const float *X, int ldx, const float *Y, int ldy, const float *scale, int kdim, int lane)
 {
-    for (int e = lane; e < K * K; e += 64) {
-        int r = e / K, c = e - r * K;
-        float s = 0.f;
-#pragma unroll 9
-        for (int k = 0; k < K; ++k) s = fmaf(X[r * LD + k], TRANS_Y ? Y[c * LD + k] : Y[k * LD + c], s);
-        out[r * LD + c] = s;
+    const int idx = lane & 31, kh = lane >> 5;
+    v16f acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll 7
+    for (int k0 = 0; k0 < kdim; k0 += 2) {
+        const int k = k0 + kh;
+        const bool ok = idx < K && k < kdim;
+        float a = ok ? X[idx * ldx + k] : 0.f;
+        if (SCALE) a *= ok ? scale[k] : 0.f;
+        const float b = ok ? (TRANS_Y ? Y[idx * ldy + k] : Y[k * ldy + idx]) : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * kh; // C/D layout: column = lane & 31
+        if (r < K && idx < K) out[r * ldo + idx] = acc[e];
     }
     __syncthreads();
+}
+
+__device__ void rebuild27(float *out, const float *A, const float *V, float *fl, int lane, bool inverse, float min_eig)
+{
+    if (lane < KP) {
+        float lam = A[lane * JLD + lane];
+        fl[lane] = inverse ? 1.f / fmaxf(min_eig, lam) : fmaxf(0.f, lam);
+    }
+    __syncthreads();
+    mfma27<true, true>(out, LD, V, JLD, V, JLD, fl, KP, lane);
 }
 
 __device__ int decode_members27(const uint32_t *mask, int p, const Geom27 &g, int *mem, int lane)
@@ -482,8 +490,8 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     // ---- Step 2 (:438-453): the Step-1 estimates are xhat = x - G (x - m) with G = N Cinv1, hence their empirical
     // mean is m and their empirical covariance is F C F^T, F = I - G
     noise_times27(V, noise, Bm, lane, true);       // V  = F
-    matmul27<false>(A, V, Cm, lane);               // A  = F C
-    matmul27<true>(Bm, A, V, lane);                // Bm = F C F^T
+    mfma27<false, false>(A, LD, V, LD, Cm, LD, nullptr, K, lane);  // A  = F C
+    mfma27<true, false>(Bm, LD, A, LD, V, LD, nullptr, K, lane);   // Bm = F C F^T
     for (int e = lane; e < K * K; e += 64) {       // exact symmetry (lower triangle wins)
         int r = e / K, c = e - r * K;
         if (r < c) Cm[r * LD + c] = Bm[c * LD + r];
