@@ -386,7 +386,7 @@ __device__ inline void stage_chunk(float *chunk, const float *__restrict__ color
 }
 
 template <bool DBG>
-__global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors, const float *__restrict__ pixcov,
+__global__ __launch_bounds__(64, 3) void k_bayes27(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                 const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
                                                 const int32_t *__restrict__ d_nlist, int *work, Geom27 g, float min_eig, float *sum,
                                                 int32_t *cnt)
@@ -521,31 +521,44 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     for (int i0 = 0; i0 < n; i0 += CHUNK) {
         int cn = min(CHUNK, n - i0);
         stage_chunk(chunk, colors, mem, i0, cn, W, lane);
-        for (int u = lane; u < cn * P; u += 64) {
-            int i = u / P, o = u - i * P;
-            const float *x = chunk + i * K;
-            const float *g0 = Cm + (3 * o) * LD, *g1 = g0 + LD, *g2 = g1 + LD;
-            float y0 = 0.f, y1 = 0.f, y2 = 0.f;
-#pragma unroll 9
-            for (int c = 0; c < K; ++c) {
-                float xc = x[c] - mean[c];
-                y0 = fmaf(g0[c], xc, y0); y1 = fmaf(g1[c], xc, y1); y2 = fmaf(g2[c], xc, y2);
+        // y = G2 (x - m) for the whole chunk on the matrix core: D[r][j] = sum_k G2[r][k] * xc_j[k] (fma chain over k), lane l
+        // feeds A = G2[l & 31][k] and B = xc of member l & 31, k = 2s + (l >> 5); it gets back components
+        // r = (e & 3) + 8 (e >> 2) + 4 (l >> 5) of member l & 31
+        {
+            const int mj = lane & 31, kh = lane >> 5;
+            v16f y;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) y[e] = 0.f;
+#pragma unroll 7
+            for (int k0 = 0; k0 < K; k0 += 2) {
+                const int k = k0 + kh;
+                const bool ok = k < K;
+                const float a = (ok && mj < K) ? Cm[mj * LD + k] : 0.f;
+                const float bq = (ok && mj < cn) ? chunk[mj * K + k] - mean[k] : 0.f;
+                y = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, y, 0, 0, 0);
             }
-            const int oy = o / 3 - 1, ox = o % 3 - 1;
-            if (in_lds) {
-                int d = mem[i0 + i] - p;                    // = dy * W + dx with |dx| <= b < W / 2
-                int dy = (int)rintf((float)d * invW), dx = d - dy * W;
-                int wq = (dy + b1 + oy) * AW + dx + b1 + ox;
-                unsafeAtomicAdd(accS + wq * 3 + 0, x[3 * o] - y0);
-                unsafeAtomicAdd(accS + wq * 3 + 1, x[3 * o + 1] - y1);
-                unsafeAtomicAdd(accS + wq * 3 + 2, x[3 * o + 2] - y2);
-                atomicAdd(accC + wq, 1);
-            } else {
-                int q = mem[i0 + i] + oy * W + ox;
-                unsafeAtomicAdd(sum + (size_t)q * 3 + 0, x[3 * o] - y0);
-                unsafeAtomicAdd(sum + (size_t)q * 3 + 1, x[3 * o + 1] - y1);
-                unsafeAtomicAdd(sum + (size_t)q * 3 + 2, x[3 * o + 2] - y2);
-                atomicAdd(cnt + q, 1);
+            if (mj < cn) {
+                const float *x = chunk + mj * K;
+                const int q0 = mem[i0 + mj];
+                const int d = q0 - p;                       // = dy * W + dx with |dx| <= b < W / 2
+                const int dy = (int)rintf((float)d * invW), dx = d - dy * W;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    if (r < K) {
+                        const int o = r / 3, ch = r - 3 * o, oy = o / 3 - 1, ox = o - 3 * (o / 3) - 1;
+                        const float v = x[r] - y[e];
+                        if (in_lds) {
+                            const int wq = (dy + b1 + oy) * AW + dx + b1 + ox;
+                            unsafeAtomicAdd(accS + wq * 3 + ch, v);
+                            if (ch == 0) atomicAdd(accC + wq, 1);
+                        } else {
+                            const int q = q0 + oy * W + ox;
+                            unsafeAtomicAdd(sum + (size_t)q * 3 + ch, v);
+                            if (ch == 0) atomicAdd(cnt + q, 1);
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
