@@ -319,7 +319,7 @@ __device__ void noise_times27(float *out, const float *noise, const float *in, i
 // lane l feeds A[i = l & 31][k = 2s + (l >> 5)] and B[k][j = l & 31]; rows / columns 27..31 are zero padding.
 // All operands are in registers before the first store (single wavefront), so `out` may alias X or Y.
 template <bool TRANS_Y, bool SCALE>
-__device__ void mfma27(float *out, int ldo, const float *X, int ldx, const float *Y, int ldy, const float *scale, int kdim, int lane)
+__device__ __attribute__((noinline)) void mfma27(float *out, int ldo, const float *X, int ldx, const float *Y, int ldy, const float *scale, int kdim, int lane)
 {
     const int idx = lane & 31, kh = lane >> 5;
     v16f acc;
@@ -385,65 +385,10 @@ __device__ inline void stage_chunk(float *chunk, const float *__restrict__ color
     __syncthreads();
 }
 
-template <bool DBG>
-__global__ __launch_bounds__(64, 3) void k_bayes27(const float *__restrict__ colors, const float *__restrict__ pixcov,
-                                                const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
-                                                const int32_t *__restrict__ d_nlist, int *work, Geom27 g, float min_eig, float *sum,
-                                                int32_t *cnt)
+// empirical covariance of the member patches on the matrix core (see the call site)
+__device__ __attribute__((noinline)) void covariance27(float *A, float *Cm, float *chunk, const float *mean, const float *__restrict__ colors,
+                                                       const int *mem, int n, int W, int lane)
 {
-    extern __shared__ float lds[];
-    const int lane = threadIdx.x;
-    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ; // A, V contiguous: reused as the aggregation window
-    float *chunk = Bm;                         // member-staging chunk: Bm is free while the clouds are streamed (mean/covariance, output)
-    float *cs = Bm + MSZ;                      // 2 x 28 floats (rotation parameters), read as float4: offsets are multiples of 16 bytes
-    float *noise = cs + 2 * KP;
-    float *mean = noise + P * 6;
-    float *fl = mean + K + 1;
-    int *mem = reinterpret_cast<int *>(fl + KP);
-
-    // persistent wavefronts: the list length lives in device memory (no host round trip between the marking and this
-    // launch), items are handed out through an atomic counter
-    const int nlist = *d_nlist;
-  for (;;) {
-    int item = 0;
-    if (lane == 0) item = atomicAdd(work, 1);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= nlist) break;
-    DBG_T(0);
-    const int p = list[item];
-    const int n = decode_members27(mask, p, g, mem, lane);
-    DBG_T(1);
-    const float n_inv = 1.f / (float)n;
-    const int W = g.W;
-
-    // computeNoiseCovPatchesMean (:400-419)
-    if (lane < P * 6) {
-        int o = lane / 6, j = lane - o * 6;
-        int offp = (o / 3 - 1) * W + (o % 3 - 1);
-        float acc = 0.f;
-        for (int i = 0; i < n; ++i) acc += pixcov[(size_t)(mem[i] + offp) * 6 + j];
-        noise[lane] = acc * n_inv;
-    }
-    __syncthreads();
-    DBG_T(2);
-    // empiricalMean (:500-509), members in order
-    {
-        float acc = 0.f;
-        for (int i0 = 0; i0 < n; i0 += CHUNK) {
-            int cn = min(CHUNK, n - i0);
-            stage_chunk(chunk, colors, mem, i0, cn, W, lane);
-            if (lane < K)
-                for (int i = 0; i < cn; ++i) acc += chunk[i * K + lane];
-            __syncthreads();
-        }
-        if (lane < K) mean[lane] = acc * n_inv;
-        __syncthreads();
-    }
-    DBG_T(3);
-    // centerPointCloud + empiricalCovarianceMatrix (:511-536) on the matrix core: C = Xc^T Xc, two members per
-    // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: a chain of fma in member order, i.e. the reference's sequential sum with the
-    // product fused; A and B operands are the same centred value, so the result is bitwise symmetric).
-    // Operand layout: lane l holds element i = l & 31 of member 2s + (l >> 5); rows/columns 27..31 are zero.
     {
         const int mi = lane & 31, mk = lane >> 5;
         const float my_mean = mi < K ? mean[mi] : 0.f;
@@ -473,6 +418,120 @@ __global__ __launch_bounds__(64, 3) void k_bayes27(const float *__restrict__ col
         }
         __syncthreads();
     }
+
+}
+
+// y = G2 (x - m) for one staged chunk on the matrix core, and its aggregation (see the call site)
+__device__ __attribute__((noinline)) void final_chunk27(const float *Cm, const float *chunk, const float *mean, const int *mem, int i0, int cn, int p,
+                                                        int W, float invW, bool in_lds, int AW, int b1, float *accS, int *accC, float *sum,
+                                                        int32_t *cnt, int lane)
+{
+        // D[r][j] = sum_k G2[r][k] * xc_j[k] (fma chain over k), lane l
+        // feeds A = G2[l & 31][k] and B = xc of member l & 31, k = 2s + (l >> 5); it gets back components
+        // r = (e & 3) + 8 (e >> 2) + 4 (l >> 5) of member l & 31
+        {
+            const int mj = lane & 31, kh = lane >> 5;
+            v16f y;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) y[e] = 0.f;
+#pragma unroll 7
+            for (int k0 = 0; k0 < K; k0 += 2) {
+                const int k = k0 + kh;
+                const bool ok = k < K;
+                const float a = (ok && mj < K) ? Cm[mj * LD + k] : 0.f;
+                const float bq = (ok && mj < cn) ? chunk[mj * K + k] - mean[k] : 0.f;
+                y = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, y, 0, 0, 0);
+            }
+            if (mj < cn) {
+                const float *x = chunk + mj * K;
+                const int q0 = mem[i0 + mj];
+                const int d = q0 - p;                       // = dy * W + dx with |dx| <= b < W / 2
+                const int dy = (int)rintf((float)d * invW), dx = d - dy * W;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    if (r < K) {
+                        const int o = r / 3, ch = r - 3 * o, oy = o / 3 - 1, ox = o - 3 * (o / 3) - 1;
+                        const float v = x[r] - y[e];
+                        if (in_lds) {
+                            const int wq = (dy + b1 + oy) * AW + dx + b1 + ox;
+                            unsafeAtomicAdd(accS + wq * 3 + ch, v);
+                            if (ch == 0) atomicAdd(accC + wq, 1);
+                        } else {
+                            const int q = q0 + oy * W + ox;
+                            unsafeAtomicAdd(sum + (size_t)q * 3 + ch, v);
+                            if (ch == 0) atomicAdd(cnt + q, 1);
+                        }
+                    }
+                }
+            }
+        }
+}
+
+template <bool DBG>
+__global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors, const float *__restrict__ pixcov,
+                                                const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
+                                                const int32_t *__restrict__ d_nlist, int *work, Geom27 g, float min_eig, float *sum,
+                                                int32_t *cnt)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x;
+    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ; // A, V contiguous: reused as the aggregation window
+    float *chunk = Bm;                         // member-staging chunk: Bm is free while the clouds are streamed (mean/covariance, output)
+    float *cs = Bm + MSZ;                      // 2 x 28 floats (rotation parameters), read as float4: offsets are multiples of 16 bytes
+    float *noise = cs + 2 * KP;
+    float *mean = noise + P * 6;
+    float *fl = mean + K + 1;
+    int *mem = reinterpret_cast<int *>(fl + KP);
+
+    // persistent wavefronts: the list length lives in device memory (no host round trip between the marking and this
+    // launch), items are handed out through an atomic counter
+    const int nlist = *d_nlist;
+  for (;;) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(work, 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= nlist) break;
+    DBG_T(0);
+    const int p = list[item];
+    const int n = decode_members27(mask, p, g, mem, lane);
+    DBG_T(1);
+    const float n_inv = 1.f / (float)n;
+    const int W = g.W;
+
+    // computeNoiseCovPatchesMean (:400-419) and empiricalMean (:500-509) in one sweep over the members, straight from global
+    // memory: lanes 0..53 own one noise component, lanes 0..26 also one colour component.  The loads of 8 members are issued
+    // back to back (independent addresses), the sums stay in member order.
+    {
+        const bool do_noise = lane < P * 6, do_mean = lane < K;
+        // (idle lanes repeat the loads of the last owner: no branches around the loads)
+        int noff, coff;
+        { const int l = min(lane, P * 6 - 1), o = l / 6, j = l - o * 6; noff = ((o / 3 - 1) * W + (o % 3 - 1)) * 6 + j; }
+        { const int l = min(lane, K - 1), o = l / 3, ch = l - o * 3; coff = ((o / 3 - 1) * W + (o % 3 - 1)) * 3 + ch; }
+        float accn = 0.f, accm = 0.f;
+        for (int i = 0; i < n; i += 8) {
+            float vn[8], vm[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = mem[min(i + u, n - 1)];
+                vn[u] = pixcov[(long long)q * 6 + noff];
+                vm[u] = colors[(long long)q * 3 + coff];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + u < n) { accn += vn[u]; accm += vm[u]; }
+        }
+        if (do_noise) noise[lane] = accn * n_inv;
+        if (do_mean) mean[lane] = accm * n_inv;
+        __syncthreads();
+    }
+    DBG_T(2);
+    DBG_T(3);
+    // centerPointCloud + empiricalCovarianceMatrix (:511-536) on the matrix core: C = Xc^T Xc, two members per
+    // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: a chain of fma in member order, i.e. the reference's sequential sum with the
+    // product fused; A and B operands are the same centred value, so the result is bitwise symmetric).
+    // Operand layout: lane l holds element i = l & 31 of member 2s + (l >> 5); rows/columns 27..31 are zero.
+    covariance27(A, Cm, chunk, mean, colors, mem, n, W, lane);
 
     // ---- Step 1 (:421-436): M1 = clamp(C - N) + N ; Cinv1 = inverse(M1)
     DBG_T(4);
@@ -521,46 +580,7 @@ __global__ __launch_bounds__(64, 3) void k_bayes27(const float *__restrict__ col
     for (int i0 = 0; i0 < n; i0 += CHUNK) {
         int cn = min(CHUNK, n - i0);
         stage_chunk(chunk, colors, mem, i0, cn, W, lane);
-        // y = G2 (x - m) for the whole chunk on the matrix core: D[r][j] = sum_k G2[r][k] * xc_j[k] (fma chain over k), lane l
-        // feeds A = G2[l & 31][k] and B = xc of member l & 31, k = 2s + (l >> 5); it gets back components
-        // r = (e & 3) + 8 (e >> 2) + 4 (l >> 5) of member l & 31
-        {
-            const int mj = lane & 31, kh = lane >> 5;
-            v16f y;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) y[e] = 0.f;
-#pragma unroll 7
-            for (int k0 = 0; k0 < K; k0 += 2) {
-                const int k = k0 + kh;
-                const bool ok = k < K;
-                const float a = (ok && mj < K) ? Cm[mj * LD + k] : 0.f;
-                const float bq = (ok && mj < cn) ? chunk[mj * K + k] - mean[k] : 0.f;
-                y = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, y, 0, 0, 0);
-            }
-            if (mj < cn) {
-                const float *x = chunk + mj * K;
-                const int q0 = mem[i0 + mj];
-                const int d = q0 - p;                       // = dy * W + dx with |dx| <= b < W / 2
-                const int dy = (int)rintf((float)d * invW), dx = d - dy * W;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int r = (e & 3) + 8 * (e >> 2) + 4 * kh;
-                    if (r < K) {
-                        const int o = r / 3, ch = r - 3 * o, oy = o / 3 - 1, ox = o - 3 * (o / 3) - 1;
-                        const float v = x[r] - y[e];
-                        if (in_lds) {
-                            const int wq = (dy + b1 + oy) * AW + dx + b1 + ox;
-                            unsafeAtomicAdd(accS + wq * 3 + ch, v);
-                            if (ch == 0) atomicAdd(accC + wq, 1);
-                        } else {
-                            const int q = q0 + oy * W + ox;
-                            unsafeAtomicAdd(sum + (size_t)q * 3 + ch, v);
-                            if (ch == 0) atomicAdd(cnt + q, 1);
-                        }
-                    }
-                }
-            }
-        }
+        final_chunk27(Cm, chunk, mean, mem, i0, cn, p, W, invW, in_lds, AW, b1, accS, accC, sum, cnt, lane);
         __syncthreads();
     }
     if (in_lds) {
