@@ -72,7 +72,7 @@ __device__ inline int sigma_slot(int s)
 //   * rows of V (lanes 32..58) never move between lanes and stay in registers for the whole solve;
 //   * the 14 rotations (c, s) are broadcast with v_readlane (wave-uniform SGPR operands of the column rotations).
 template <bool DBG>
-__device__ void jacobi27(float *A0, float *V0, int lane, int item)
+__device__ void jacobi27(float *A0, float *V0, float *cs, int lane, int item)
 {
     const bool isA = lane < KP, isV = lane >= 32 && lane < 32 + K;
     const int vrow = lane - 32;
@@ -109,6 +109,7 @@ __device__ void jacobi27(float *A0, float *V0, int lane, int item)
                     if (!(fabsf(theta) < 1e18f)) { c = 1.f; s = 0.f; } // theta^2 overflows: the rotation is the identity to fp32
                 }
             }
+            if (lane < KP / 2) reinterpret_cast<float2 *>(cs)[lane] = make_float2(c, s);
             if (isA) {
 #pragma unroll
                 for (int q4 = 0; q4 < JLD / 4; ++q4) {
@@ -116,11 +117,17 @@ __device__ void jacobi27(float *A0, float *V0, int lane, int item)
                     row[4 * q4] = v.x; row[4 * q4 + 1] = v.y; row[4 * q4 + 2] = v.z; row[4 * q4 + 3] = v.w;
                 }
             }
-            // column rotations: (x, y) <- (c x - s y, s x + c y) for every slot pair, (c, s) wave-uniform
+            __syncthreads();
+            float rot[JLD];
+#pragma unroll
+            for (int q4 = 0; q4 < JLD / 4; ++q4) {
+                float4 w4 = reinterpret_cast<const float4 *>(cs)[q4];
+                rot[4 * q4] = w4.x; rot[4 * q4 + 1] = w4.y; rot[4 * q4 + 2] = w4.z; rot[4 * q4 + 3] = w4.w;
+            }
+            // column rotations: (x, y) <- (c x - s y, s x + c y) for every slot pair
 #pragma unroll
             for (int j = 0; j < KP / 2; ++j) {
-                const float cj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), j));
-                const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), j));
+                const float cj = rot[2 * j], sj = rot[2 * j + 1];
                 const float x = row[2 * j], y = row[2 * j + 1];
                 row[2 * j] = fmaf(cj, x, -sj * y);
                 row[2 * j + 1] = fmaf(sj, x, cj * y);
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     add_noise27(A, noise, lane, -1.f);
     to_jacobi_layout(Bm, A, lane);
     {
-        jacobi27<DBG>(Bm, V, lane, item);
+        jacobi27<DBG>(Bm, V, cs, lane, item);
         DBG_T(5);
         rebuild27(Bm, Bm, V, fl, lane, false, 0.f); // reads the eigenvalues (diagonal) before it overwrites Bm: M1 lives in Bm
     }

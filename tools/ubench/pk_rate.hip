@@ -21,6 +21,9 @@ __global__ void k(float *out, long long *cyc, int iters)
             if (MODE == 3) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(r[i]) : "v"(b));
             if (MODE == 4) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(p[i]) : "v"(bb));
             if (MODE == 5) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[i]));
+            if (MODE == 6) { int sg; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sg) : "v"(r[i])); asm volatile("" :: "s"(sg)); }
+            if (MODE == 7) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[i]));
+            if (MODE == 8) { int sg; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sg) : "v"(r[i])); asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r[i]) : "s"(sg), "v"(b)); }
         }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -54,8 +57,8 @@ template <int MODE> void run(const char *name, int waves_per_simd)
 
 int main()
 {
-    for (int w : { 1, 2, 4, 8 }) {
-        run<0>("v_fma_f32", w); run<3>("v_mul_f32", w); run<1>("v_pk_fma_f32", w); run<2>("v_pk_mul_f32", w); run<4>("v_pk_add_f32", w); run<5>("v_rcp_f32", w);
+    for (int w : { 2, 8 }) {
+        run<0>("v_fma_f32", w); run<3>("v_mul_f32", w); run<1>("v_pk_fma_f32", w); run<2>("v_pk_mul_f32", w); run<4>("v_pk_add_f32", w); run<5>("v_rcp_f32", w); run<6>("v_readlane", w); run<7>("v_mov_dpp", w); run<8>("readlane+fma", w);
     }
     return 0;
 }
