@@ -38,6 +38,7 @@ hipError_t bcd_launch_mark_round(const uint32_t *, uint8_t *, int, int, int, int
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t bcd_bayes_lds_bytes(int w, int b);
 size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
+int bcd_bayes27_blocks_per_cu(int b);
 hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, const int32_t *, int *, int, int, int, int,
                                    int, float, float *, int32_t *, float *, size_t, hipStream_t);
 hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, const int32_t *, int, int, int, int, int, float *,
@@ -271,8 +272,8 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream));
     const size_t per_block = bcd_bayes_scratch_bytes_per_block(w, b);
     const int64_t cap = std::max<int64_t>(1, npix);
-    // persistent grids: as many workgroups as the CUs hold at once (w = 1: LDS-bound, 11 per CU; generic: 1024 scratch slices)
-    const int strong_blocks = (int)std::min<int64_t>(cap, w == 1 ? (int64_t)ctx->num_cus * 11 : 1024);
+    // persistent grids: as many workgroups as the CUs hold at once (w = 1: LDS-bound, 12 per CU at b = 6; generic: 1024 scratch slices)
+    const int strong_blocks = (int)std::min<int64_t>(cap, w == 1 ? (int64_t)ctx->num_cus * bcd_bayes27_blocks_per_cu(b) : 1024);
     const int weak_blocks = (int)std::min<int64_t>(cap, (int64_t)ctx->num_cus * 32);
     if (per_block) RCCHK(ensure(ctx, wk.gscratch, per_block * (size_t)strong_blocks));
     HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, d_c, d_c + 4, strong_blocks, W, H, w, b, min_eig,

@@ -24,7 +24,7 @@ namespace {
 
 #define DBG_T(i) do { if (DBG && item == 100 && lane == 0) bcd_dbg_cycles[i] = __builtin_readcyclecounter(); } while (0)
 
-constexpr int K = 27, KP = 28, LD = 29, P = 9, MSZ = KP * LD, CHUNK = MSZ / K; // 30 members per staging chunk
+constexpr int K = 27, KP = 28, LD = 29, P = 9, MSZ = KP * KP, CHUNK = MSZ / K; // matrix buffer: 784 floats; 29 members per staging chunk
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -53,7 +53,7 @@ __device__ inline int noise_idx(int i, int j)
 // has met once (one sweep).  Eigenvalues = diagonal of A (in slot order), eigenvectors = columns of V (same order):
 // V f(diag) V^T needs no bookkeeping of the permutation.  Matrices here use a leading dimension of 28 floats.
 constexpr int JLD = 28;
-static_assert(MSZ >= (KP + 1) * JLD, "the Jacobi layout needs one spare row per matrix buffer");
+static_assert(MSZ >= KP * JLD && MSZ >= (K - 1) * LD + K, "a matrix buffer holds 28 x 28 (Jacobi layout) or 27 rows of stride 29");
 
 __device__ inline float dpp_xor1(float v)
 {
@@ -359,9 +359,11 @@ __device__ void rebuild27(float *out, const float *A, const float *V, float *fl,
     mfma27<true, true>(out, LD, V, JLD, V, JLD, fl, KP, lane);
 }
 
-__device__ int decode_members27(const uint32_t *mask, int p, const Geom27 &g, int *mem, int lane)
+// members are kept as 16-bit window codes ((dl + b) << 8 | (dc + b)): half the LDS of pixel indices, decoded with member_pixel()
+__device__ inline int member_pixel(uint16_t code, int p, int W, int b) { return p + ((int)(code >> 8) - b) * W + ((int)(code & 255) - b); }
+
+__device__ int decode_members27(const uint32_t *mask, int p, const Geom27 &g, uint16_t *mem, int lane)
 {
-    int r = p / g.W, c = p - r * g.W;
     uint32_t m = (lane < g.words) ? mask[(size_t)p * g.words + lane] : 0u;
     int cntw = __popc(m), pre = cntw;
     for (int off = 1; off < 32; off <<= 1) {
@@ -374,27 +376,27 @@ __device__ int decode_members27(const uint32_t *mask, int p, const Geom27 &g, in
         int bit = __ffs(m) - 1;
         m &= m - 1;
         int k = lane * 32 + bit;
-        int dl = k / g.side - g.b, dc = k % g.side - g.b;
-        mem[pos++] = (r + dl) * g.W + (c + dc);
+        int kl = k / g.side, kc = k - kl * g.side;
+        mem[pos++] = (uint16_t)((kl << 8) | kc);
     }
     __syncthreads();
     return total;
 }
 
 // stage members [i0, i0+cn) of the similar set into the LDS chunk (pickColorPatchesFromColorImage :483-498)
-__device__ inline void stage_chunk(float *chunk, const float *__restrict__ colors, const int *mem, int i0, int cn, int W, int lane)
+__device__ inline void stage_chunk(float *chunk, const float *__restrict__ colors, const uint16_t *mem, int p, int b, int i0, int cn, int W, int lane)
 {
     for (int t = lane; t < cn * K; t += 64) {
         int i = t / K, k = t - i * K, o = k / 3, ch = k - o * 3;
         int offp = (o / 3 - 1) * W + (o % 3 - 1);
-        chunk[t] = colors[(size_t)(mem[i0 + i] + offp) * 3 + ch];
+        chunk[t] = colors[(size_t)(member_pixel(mem[i0 + i], p, W, b) + offp) * 3 + ch];
     }
     __syncthreads();
 }
 
 // empirical covariance of the member patches on the matrix core (see the call site)
 __device__ __attribute__((noinline)) void covariance27(float *A, float *Cm, float *chunk, const float *mean, const float *__restrict__ colors,
-                                                       const int *mem, int n, int W, int lane)
+                                                       const uint16_t *mem, int p, int b, int n, int W, int lane)
 {
     {
         const int mi = lane & 31, mk = lane >> 5;
@@ -404,7 +406,7 @@ __device__ __attribute__((noinline)) void covariance27(float *A, float *Cm, floa
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         for (int i0 = 0; i0 < n; i0 += CHUNK) {
             int cn = min(CHUNK, n - i0);
-            stage_chunk(chunk, colors, mem, i0, cn, W, lane);
+            stage_chunk(chunk, colors, mem, p, b, i0, cn, W, lane);
             for (int s2 = 0; s2 < cn; s2 += 2) {
                 const int m = s2 + mk;
                 const float a = (m < cn && mi < K) ? chunk[m * K + mi] - my_mean : 0.f;
@@ -429,8 +431,8 @@ __device__ __attribute__((noinline)) void covariance27(float *A, float *Cm, floa
 }
 
 // y = G2 (x - m) for one staged chunk on the matrix core, and its aggregation (see the call site)
-__device__ __attribute__((noinline)) void final_chunk27(const float *Cm, const float *chunk, const float *mean, const int *mem, int i0, int cn, int p,
-                                                        int W, float invW, bool in_lds, int AW, int b1, float *accS, int *accC, float *sum,
+__device__ __attribute__((noinline)) void final_chunk27(const float *Cm, const float *chunk, const float *mean, const uint16_t *mem, int i0, int cn, int p,
+                                                        int W, int b, bool in_lds, int AW, int b1, float *accS, int *accC, float *sum,
                                                         int32_t *cnt, int lane)
 {
         // D[r][j] = sum_k G2[r][k] * xc_j[k] (fma chain over k), lane l
@@ -451,9 +453,8 @@ __device__ __attribute__((noinline)) void final_chunk27(const float *Cm, const f
             }
             if (mj < cn) {
                 const float *x = chunk + mj * K;
-                const int q0 = mem[i0 + mj];
-                const int d = q0 - p;                       // = dy * W + dx with |dx| <= b < W / 2
-                const int dy = (int)rintf((float)d * invW), dx = d - dy * W;
+                const uint16_t code = mem[i0 + mj];
+                const int dy = (int)(code >> 8) - b, dx = (int)(code & 255) - b, q0 = p + dy * W + dx;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int r = (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     float *noise = cs + 2 * KP;
     float *mean = noise + P * 6;
     float *fl = mean + K + 1;
-    int *mem = reinterpret_cast<int *>(fl + KP);
+    uint16_t *mem = reinterpret_cast<uint16_t *>(fl + KP);
 
     // persistent wavefronts: the list length lives in device memory (no host round trip between the marking and this
     // launch), items are handed out through an atomic counter
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
             float vn[8], vm[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int q = mem[min(i + u, n - 1)];
+                const int q = member_pixel(mem[min(i + u, n - 1)], p, W, g.b);
                 vn[u] = pixcov[(long long)q * 6 + noff];
                 vm[u] = colors[(long long)q * 3 + coff];
             }
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: a chain of fma in member order, i.e. the reference's sequential sum with the
     // product fused; A and B operands are the same centred value, so the result is bitwise symmetric).
     // Operand layout: lane l holds element i = l & 31 of member 2s + (l >> 5); rows/columns 27..31 are zero.
-    covariance27(A, Cm, chunk, mean, colors, mem, n, W, lane);
+    covariance27(A, Cm, chunk, mean, colors, mem, p, g.b, n, W, lane);
 
     // ---- Step 1 (:421-436): M1 = clamp(C - N) + N ; Cinv1 = inverse(M1)
     DBG_T(4);
@@ -574,20 +575,19 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     // ---- finalDenoisingMatrixMultiplication (:656-670) on the noisy patches centred on m, aggregateOutputPatches (:672-693).
     // Every patch of every member lies in the (side+2)^2 window around p: the contributions are first summed there in LDS
     // (A and V are dead by now) and flushed with one global atomic per touched value, rows contiguous; windows that do not
-    // fit (b > 8) or images narrower than the search window go straight to global atomics.
+    // fit (b > 8) go straight to global atomics.
     const int AW = g.side + 2, b1 = g.b + 1;
-    const bool in_lds = AW * AW * 4 <= 2 * MSZ && W > g.side; // A and V; Bm holds the chunk
+    const bool in_lds = AW * AW * 4 <= 2 * MSZ; // A and V; Bm holds the chunk
     float *accS = A;
     int *accC = reinterpret_cast<int *>(A + AW * AW * 3);
     if (in_lds) {
         for (int e = lane; e < AW * AW * 4; e += 64) A[e] = 0.f;
         __syncthreads();
     }
-    const float invW = 1.f / (float)W;
     for (int i0 = 0; i0 < n; i0 += CHUNK) {
         int cn = min(CHUNK, n - i0);
-        stage_chunk(chunk, colors, mem, i0, cn, W, lane);
-        final_chunk27(Cm, chunk, mean, mem, i0, cn, p, W, invW, in_lds, AW, b1, accS, accC, sum, cnt, lane);
+        stage_chunk(chunk, colors, mem, p, g.b, i0, cn, W, lane);
+        final_chunk27(Cm, chunk, mean, mem, i0, cn, p, W, g.b, in_lds, AW, b1, accS, accC, sum, cnt, lane);
         __syncthreads();
     }
     if (in_lds) {
@@ -613,7 +613,14 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 size_t bcd_bayes27_lds_bytes(int b)
 {
     int side = 2 * b + 1;
-    return (size_t)(4 * MSZ + 2 * KP + P * 6 + (K + 1) + KP + side * side) * sizeof(float);
+    return (size_t)(4 * MSZ + 2 * KP + P * 6 + (K + 1) + KP) * sizeof(float) + (((size_t)side * side * sizeof(uint16_t) + 15) & ~(size_t)15);
+}
+
+// workgroups (= wavefronts) of k_bayes27 one CU holds: LDS-bound, at most 3 per SIMD (148 VGPRs)
+int bcd_bayes27_blocks_per_cu(int b)
+{
+    size_t n = (size_t)160 * 1024 / bcd_bayes27_lds_bytes(b);
+    return (int)(n > 12 ? 12 : n);
 }
 
 hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, const int32_t *d_nlist,
