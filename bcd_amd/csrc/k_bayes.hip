@@ -301,7 +301,14 @@ __global__ __launch_bounds__(64) void k_bayes_weak(const float *__restrict__ col
         int o = k / 3, ch = k - o * 3;
         int offp = (o / pw - g.w) * g.W + (o % pw - g.w);
         float acc = 0.f;
-        for (int i = 0; i < n; ++i) acc += colors[(size_t)(mem[i] + offp) * 3 + ch];
+        for (int i = 0; i < n; i += 8) { // 8 independent loads in flight, summed in member order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = colors[(size_t)(mem[min(i + u, n - 1)] + offp) * 3 + ch];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + u < n) acc += v[u];
+        }
         unsafeAtomicAdd(sum + (size_t)(p + offp) * 3 + ch, n_inv * acc);
         if (ch == 0) atomicAdd(cnt + p + offp, 1);
     }
