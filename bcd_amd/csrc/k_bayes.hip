@@ -193,6 +193,7 @@ __device__ void apply_estimate(const float *X, const float *Cinv, const float *m
 __device__ int decode_members(const uint32_t *mask, int p, const BayesGeom &g, int *mem, int lane)
 {
     int r = p / g.W, c = p - r * g.W;
+    const float inv_side = 1.f / (float)g.side;
     uint32_t m = (lane < g.words) ? mask[(size_t)p * g.words + lane] : 0u;
     int cntw = __popc(m), pre = cntw;
     for (int off = 1; off < 32; off <<= 1) {
@@ -205,7 +206,8 @@ __device__ int decode_members(const uint32_t *mask, int p, const BayesGeom &g, i
         int bit = __ffs(m) - 1;
         m &= m - 1;
         int k = lane * 32 + bit;
-        int dl = k / g.side - g.b, dc = k % g.side - g.b;
+        // k / side without an integer division: (k + 0.5) / side is at least 0.5 / side away from an integer, k < 2^10
+        int kl = (int)(((float)k + 0.5f) * inv_side), dl = kl - g.b, dc = k - kl * g.side - g.b;
         mem[pos++] = (r + dl) * g.W + (c + dc);
     }
     __syncthreads();

@@ -364,6 +364,7 @@ __device__ inline int member_pixel(uint16_t code, int p, int W, int b) { return 
 
 __device__ int decode_members27(const uint32_t *mask, int p, const Geom27 &g, uint16_t *mem, int lane)
 {
+    const float inv_side = 1.f / (float)g.side;
     uint32_t m = (lane < g.words) ? mask[(size_t)p * g.words + lane] : 0u;
     int cntw = __popc(m), pre = cntw;
     for (int off = 1; off < 32; off <<= 1) {
@@ -376,7 +377,8 @@ __device__ int decode_members27(const uint32_t *mask, int p, const Geom27 &g, ui
         int bit = __ffs(m) - 1;
         m &= m - 1;
         int k = lane * 32 + bit;
-        int kl = k / g.side, kc = k - kl * g.side;
+        // k / side without an integer division: (k + 0.5) / side is at least 0.5 / side away from an integer, k < 2^10
+        int kl = (int)(((float)k + 0.5f) * inv_side), kc = k - kl * g.side;
         mem[pos++] = (uint16_t)((kl << 8) | kc);
     }
     __syncthreads();
