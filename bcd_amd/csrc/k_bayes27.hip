@@ -386,12 +386,26 @@ __device__ int decode_members27(const uint32_t *mask, int p, const Geom27 &g, ui
 }
 
 // stage members [i0, i0+cn) of the similar set into the LDS chunk (pickColorPatchesFromColorImage :483-498)
-__device__ inline void stage_chunk(float *chunk, const float *__restrict__ colors, const uint16_t *mem, int p, int b, int i0, int cn, int W, int lane)
+// staging of members [i0, i0+cn) of the similar set (pickColorPatchesFromColorImage :483-498) in two halves, so that the global
+// loads of the next chunk are in flight while the current one is being consumed: stage_load -> registers, stage_store -> LDS
+constexpr int STAGE_REGS = (CHUNK * K + 63) / 64;
+__device__ inline void stage_load(float (&pre)[STAGE_REGS], const float *__restrict__ colors, const uint16_t *mem, int p, int b, int i0,
+                                  int cn, int W, int lane)
 {
-    for (int t = lane; t < cn * K; t += 64) {
-        int i = t / K, k = t - i * K, o = k / 3, ch = k - o * 3;
-        int offp = (o / 3 - 1) * W + (o % 3 - 1);
-        chunk[t] = colors[(size_t)(member_pixel(mem[i0 + i], p, W, b) + offp) * 3 + ch];
+#pragma unroll
+    for (int j = 0; j < STAGE_REGS; ++j) {
+        const int t = min(lane + 64 * j, cn * K - 1); // idle slots repeat the last element
+        const int i = t / K, k = t - i * K, o = k / 3, ch = k - o * 3;
+        const int offp = (o / 3 - 1) * W + (o % 3 - 1);
+        pre[j] = colors[(size_t)(member_pixel(mem[i0 + i], p, W, b) + offp) * 3 + ch];
+    }
+}
+__device__ inline void stage_store(float *chunk, const float (&pre)[STAGE_REGS], int cn, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < STAGE_REGS; ++j) {
+        const int t = lane + 64 * j;
+        if (t < cn * K) chunk[t] = pre[j];
     }
     __syncthreads();
 }
@@ -406,9 +420,12 @@ __device__ __attribute__((noinline)) void covariance27(float *A, float *Cm, floa
         v16f acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        float pre[STAGE_REGS];
+        stage_load(pre, colors, mem, p, b, 0, min(CHUNK, n), W, lane);
         for (int i0 = 0; i0 < n; i0 += CHUNK) {
             int cn = min(CHUNK, n - i0);
-            stage_chunk(chunk, colors, mem, p, b, i0, cn, W, lane);
+            stage_store(chunk, pre, cn, lane);
+            if (i0 + CHUNK < n) stage_load(pre, colors, mem, p, b, i0 + CHUNK, min(CHUNK, n - i0 - CHUNK), W, lane);
             for (int s2 = 0; s2 < cn; s2 += 2) {
                 const int m = s2 + mk;
                 const float a = (m < cn && mi < K) ? chunk[m * K + mi] - my_mean : 0.f;
@@ -476,6 +493,22 @@ __device__ __attribute__((noinline)) void final_chunk27(const float *Cm, const f
                 }
             }
         }
+}
+
+// the output pass over all chunks, next chunk's loads in flight during the product and the aggregation of the current one
+__device__ __attribute__((noinline)) void final_pass27(const float *Cm, float *chunk, const float *mean, const float *__restrict__ colors,
+                                                       const uint16_t *mem, int n, int p, int W, int b, bool in_lds, int AW, int b1,
+                                                       float *accS, int *accC, float *sum, int32_t *cnt, int lane)
+{
+    float pre[STAGE_REGS];
+    stage_load(pre, colors, mem, p, b, 0, min(CHUNK, n), W, lane);
+    for (int i0 = 0; i0 < n; i0 += CHUNK) {
+        int cn = min(CHUNK, n - i0);
+        stage_store(chunk, pre, cn, lane);
+        if (i0 + CHUNK < n) stage_load(pre, colors, mem, p, b, i0 + CHUNK, min(CHUNK, n - i0 - CHUNK), W, lane);
+        final_chunk27(Cm, chunk, mean, mem, i0, cn, p, W, b, in_lds, AW, b1, accS, accC, sum, cnt, lane);
+        __syncthreads();
+    }
 }
 
 template <bool DBG>
@@ -586,12 +619,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
         for (int e = lane; e < AW * AW * 4; e += 64) A[e] = 0.f;
         __syncthreads();
     }
-    for (int i0 = 0; i0 < n; i0 += CHUNK) {
-        int cn = min(CHUNK, n - i0);
-        stage_chunk(chunk, colors, mem, p, g.b, i0, cn, W, lane);
-        final_chunk27(Cm, chunk, mean, mem, i0, cn, p, W, g.b, in_lds, AW, b1, accS, accC, sum, cnt, lane);
-        __syncthreads();
-    }
+    final_pass27(Cm, chunk, mean, colors, mem, n, p, W, g.b, in_lds, AW, b1, accS, accC, sum, cnt, lane);
     if (in_lds) {
         const int row3 = AW * 3;
         const long long base = (long long)p - (long long)b1 * W - b1; // window origin; untouched cells may lie outside the image
