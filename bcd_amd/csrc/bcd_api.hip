@@ -23,6 +23,8 @@ hipError_t bcd_launch_selftest_div(uint32_t, int, int, unsigned long long *, hip
 hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t);
 hipError_t bcd_launch_window_distances(const float *, const uint8_t *, int, int, int, int, int, int, float *, hipStream_t);
 hipError_t bcd_launch_pixel_cov(const float *, const float *, int64_t, float *, hipStream_t);
+hipError_t bcd_launch_finalize_band(const float *, const int32_t *, int, int, int, const float *, const int32_t *, const float *, const int32_t *, float *,
+                                    hipStream_t);
 hipError_t bcd_launch_finalize(const float *, const int32_t *, int64_t, float *, hipStream_t);
 hipError_t bcd_launch_zero_bad(float *, int64_t, hipStream_t);
 hipError_t bcd_launch_downscale(int, const float *, int, int, int, float *, hipStream_t);
@@ -776,6 +778,16 @@ int bcd_hip_finalize(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_coun
 {
     if (!ctx || !d_sum || !d_count || !d_out || npix <= 0) return bad(ctx, "bad argument");
     HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, npix, d_out, ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_finalize_band(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int W, int rows, int halo, const float *d_up_sum,
+                          const int32_t *d_up_count, const float *d_down_sum, const int32_t *d_down_count, float *d_out)
+{
+    if (!ctx || !d_sum || !d_count || !d_out || W <= 0 || rows <= 0 || halo < 0) return bad(ctx, "bad argument");
+    if ((d_up_sum == nullptr) != (d_up_count == nullptr) || (d_down_sum == nullptr) != (d_down_count == nullptr)) return bad(ctx, "halo sum without count");
+    if ((d_up_sum || d_down_sum) && halo > rows) return bad(ctx, "halo larger than the band");
+    HIPCHK(ctx, bcd_launch_finalize_band(d_sum, d_count, W, rows, halo, d_up_sum, d_up_count, d_down_sum, d_down_count, d_out, ctx->stream));
     return BCD_HIP_OK;
 }
 

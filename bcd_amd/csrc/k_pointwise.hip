@@ -23,6 +23,29 @@ __global__ void k_finalize(const float *__restrict__ sum, const int32_t *__restr
     out[i] = inv * sum[i];
 }
 
+// finalisation of a band (multi-GPU row-band path): out = (1 / (count + halo counts)) * (sum + halo sums) on `rows` lines; the
+// first / last `halo` lines of the range also receive the accumulator halos of the neighbouring bands (nullptr at a frame border).
+// Same operations as "add the received halos, then k_finalize".
+__global__ void k_finalize_band(const float *__restrict__ sum, const int32_t *__restrict__ cnt, int W, int rows, int halo,
+                                const float *__restrict__ up_sum, const int32_t *__restrict__ up_cnt,
+                                const float *__restrict__ dn_sum, const int32_t *__restrict__ dn_cnt, float *__restrict__ out)
+{
+    const int64_t npix = (int64_t)W * rows;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 3) return;
+    const int64_t pix = i / 3;
+    const int r = (int)(pix / W);
+    float s = sum[i];
+    int c = cnt[pix];
+    if (up_sum && r < halo) { s += up_sum[i]; c += up_cnt[pix]; }
+    if (dn_sum && r >= rows - halo) {
+        const int64_t off = (int64_t)(rows - halo) * W;
+        s += dn_sum[i - off * 3];
+        c += dn_cnt[pix - off];
+    }
+    out[i] = (1.f / (float)c) * s;
+}
+
 // checkAndPutToZeroNegativeInfNaNValues (src/cli/main.cpp:389-420)
 __global__ void k_zero_bad(float *__restrict__ img, int64_t n)
 {
@@ -213,6 +236,13 @@ hipError_t bcd_launch_pixel_cov(const float *cov, const float *ns, int64_t npix,
 hipError_t bcd_launch_finalize(const float *sum, const int32_t *cnt, int64_t npix, float *out, hipStream_t st)
 {
     hipLaunchKernelGGL(k_finalize, dim3(nblk(npix * 3, 256)), dim3(256), 0, st, sum, cnt, npix, out);
+    return hipGetLastError();
+}
+hipError_t bcd_launch_finalize_band(const float *sum, const int32_t *cnt, int W, int rows, int halo, const float *up_sum, const int32_t *up_cnt,
+                                    const float *dn_sum, const int32_t *dn_cnt, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_finalize_band, dim3(nblk((int64_t)W * rows * 3, 256)), dim3(256), 0, st, sum, cnt, W, rows, halo, up_sum, up_cnt, dn_sum,
+                       dn_cnt, out);
     return hipGetLastError();
 }
 hipError_t bcd_launch_zero_bad(float *img, int64_t n, hipStream_t st)

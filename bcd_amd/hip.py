@@ -34,7 +34,7 @@ SYMBOLS = [
     "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
-    "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
+    "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
     "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_selftest_division",
 ]
@@ -199,6 +199,14 @@ class Context:
         self._chk(lib().bcd_hip_finalize(self.h, _dp(s), _dp(c), C.c_int64(c.numel()), _dp(out)))
         return out
 
+    def finalize_band(self, s, c, halo, up, down, out):
+        """out (rows x W x 3 view) = finalisation of the accumulator rows s / c with the neighbours' halos (pairs or None) added"""
+        rows, W, _ = s.shape
+        z = C.c_void_p(0)
+        self._chk(lib().bcd_hip_finalize_band(self.h, _dp(s), _dp(c), W, rows, halo, _dp(up[0]) if up else z, _dp(up[1]) if up else z,
+                                              _dp(down[0]) if down else z, _dp(down[1]) if down else z, _dp(out)))
+        return out
+
     def downscale_sum(self, a):
         H, W, D = a.shape
         o = self.torch.empty((H // 2, W // 2, D), dtype=a.dtype, device=a.device)
@@ -228,6 +236,12 @@ class Context:
         o = hi.clone()
         self._chk(lib().bcd_hip_merge(self.h, _dp(o), W, H, _dp(lo), D))
         return o
+
+    def merge_(self, hi, lo):
+        """in place on hi (a contiguous H x W x D tensor or row-slice view)"""
+        H, W, D = hi.shape
+        self._chk(lib().bcd_hip_merge(self.h, _dp(hi), W, H, _dp(lo), D))
+        return hi
 
     def spike_filter(self, col, ns, hist, cov, factor):
         H, W, D = hist.shape

@@ -123,10 +123,19 @@ def _finish_bands(eng, geom, rank, bands, spans, accs, got_up, got_down):
     S, halo, world = geom.S, geom.halo, geom.world
     up, down = rank > 0, rank < world - 1
     outs = [None] * S
+    fused = hasattr(eng, "finalize_band")
     for s in range(S):
         sb = bands[s]
         o0, o1, a0, a1 = spans[s]
         sum_, cnt = accs[s]
+        if fused:
+            # one launch: halo add + finalisation of the owned lines, written in place into the (persistent) local output
+            out = eng.out_buffer(s, sb.loc1 - sb.loc0, sum_)
+            eng.finalize_band(sum_[o0 - a0:o1 - a0], cnt[o0 - a0:o1 - a0], halo,
+                              (got_up[2 * s], got_up[2 * s + 1]) if up else None,
+                              (got_down[2 * s], got_down[2 * s + 1]) if down else None, out[o0:o1])
+            outs[s] = out
+            continue
         if up:
             sum_[o0 - a0:o0 - a0 + halo] += got_up[2 * s]
             cnt[o0 - a0:o0 - a0 + halo] += got_up[2 * s + 1]
@@ -146,13 +155,10 @@ def _finish_bands(eng, geom, rank, bands, spans, accs, got_up, got_down):
     if S > 1:
         send_up = [edge(s, lines[s], True) for s in range(S)] if up else None
         send_down = [edge(s, lines[s], False) for s in range(S)] if down else None
-        got_up, got_down = yield ("out", send_up, send_down)
-        for s in range(S):
-            o0, o1 = spans[s][0], spans[s][1]
-            if up:
-                outs[s][o0 - lines[s]:o0] = got_up[s]
-            if down:
-                outs[s][o1:o1 + lines[s]] = got_down[s]
+        # the received lines land directly in the outputs (contiguous row views)
+        recv_up = [outs[s][spans[s][0] - lines[s]:spans[s][0]] for s in range(S)] if up else None
+        recv_down = [outs[s][spans[s][1]:spans[s][1] + lines[s]] for s in range(S)] if down else None
+        yield ("out", send_up, send_down, recv_up, recv_down)
     # ---- D. merges coarse to fine; between two merges one line of the freshly merged output travels
     for s in range(S - 2, -1, -1):
         sb, nb = bands[s], bands[s + 1]
@@ -160,15 +166,14 @@ def _finish_bands(eng, geom, rank, bands, spans, accs, got_up, got_down):
         m0 = o0 - 2 if up else o0
         m1 = o1 + 2 if down else o1
         g_lo0 = (sb.loc0 + m0) // 2 - nb.loc0                     # local line of the coarser level under local line m0
-        outs[s][m0:m1] = eng.merge(outs[s][m0:m1], outs[s + 1][g_lo0:g_lo0 + (m1 - m0) // 2])
+        if fused:
+            eng.merge_(outs[s][m0:m1], outs[s + 1][g_lo0:g_lo0 + (m1 - m0) // 2])
+        else:
+            outs[s][m0:m1] = eng.merge(outs[s][m0:m1], outs[s + 1][g_lo0:g_lo0 + (m1 - m0) // 2])
         if s > 0:
             send_up = [outs[s][o0:o0 + 1].contiguous()] if up else None
             send_down = [outs[s][o1 - 1:o1].contiguous()] if down else None
-            got_up, got_down = yield ("mrg%d" % s, send_up, send_down)
-            if up:
-                outs[s][o0 - 1:o0] = got_up[0]
-            if down:
-                outs[s][o1:o1 + 1] = got_down[0]
+            yield ("mrg%d" % s, send_up, send_down, [outs[s][o0 - 1:o0]] if up else None, [outs[s][o1:o1 + 1]] if down else None)
     sb = bands[0]
     return outs[0][sb.own0 - sb.loc0:sb.own1 - sb.loc0]
 
@@ -240,7 +245,7 @@ def run_virtual(eng, geom, inputs_per_rank, prm, seed0, exact_marking=False):
     def snap(m):  # messages are views into live buffers: copy them like a real send would
         if m is None or m[0] == "sum":
             return m
-        return (m[0],) + tuple(None if x is None else [t.clone() for t in x] for x in m[1:])
+        return (m[0],) + tuple(None if x is None else [t.clone() for t in x] for x in m[1:3]) + tuple(m[3:])
 
     program = band_program_exact if exact_marking else band_program
     progs = [program(eng, geom, r, *inputs_per_rank[r], prm, seed0) for r in range(geom.world)]
@@ -254,6 +259,12 @@ def run_virtual(eng, geom, inputs_per_rank, prm, seed0, exact_marking=False):
         for r, p in enumerate(progs):
             from_up = msgs[r - 1][2] if r > 0 and total is None else None
             from_down = msgs[r + 1][1] if r < geom.world - 1 and total is None else None
+            if total is None and len(msgs[r]) == 5:        # receive buffers given: deliver in place
+                for dst, src in ((msgs[r][3], from_up), (msgs[r][4], from_down)):
+                    if dst is not None:
+                        for d, s_ in zip(dst, src):
+                            d.copy_(s_)
+                from_up = from_down = None
             try:
                 nxt.append(snap(p.send(total if total is not None else (from_up, from_down))))
             except StopIteration as e:
@@ -276,16 +287,17 @@ def run_distributed(eng, geom, rank, dist, inputs, prm, seed0, device=None, exac
                 dist.all_reduce(tsum)
                 msg = prog.send(int(tsum.item()))
                 continue
-            _, send_up, send_down = msg
+            send_up, send_down = msg[1], msg[2]
+            in_place = len(msg) == 5
             ops, got_up, got_down = [], None, None
             if rank > 0:
-                got_up = [torch.empty_like(t) for t in send_up]
+                got_up = msg[3] if in_place else [torch.empty_like(t) for t in send_up]
                 for t in send_up:
                     ops.append(dist.P2POp(dist.isend, t, rank - 1))
                 for t in got_up:
                     ops.append(dist.P2POp(dist.irecv, t, rank - 1))
             if rank < world - 1:
-                got_down = [torch.empty_like(t) for t in send_down]
+                got_down = msg[4] if in_place else [torch.empty_like(t) for t in send_down]
                 for t in send_down:
                     ops.append(dist.P2POp(dist.isend, t, rank + 1))
                 for t in got_down:
@@ -293,7 +305,7 @@ def run_distributed(eng, geom, rank, dist, inputs, prm, seed0, device=None, exac
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
-            msg = prog.send((got_up, got_down))
+            msg = prog.send(None if in_place else (got_up, got_down))
     except StopIteration as e:
         return e.value
 
@@ -371,6 +383,21 @@ class HipEngine:
 
     def merge(self, hi, lo):
         return self.ctx.merge(hi.contiguous(), lo.contiguous())
+
+    # ---- fused tail of a band (fewer, larger launches: at 8 ranks the tail of small torch ops was 45 % of a 720p step)
+    def out_buffer(self, scale, rows, like):
+        """persistent rows x W x 3 output of a scale's local band (lines outside the owned range are only ever read where a
+        received line was written first)"""
+        key = ("out", scale, rows, like.shape[1])
+        if key not in self._acc or not self.reuse_buffers:
+            self._acc[key] = self.torch.empty((rows, like.shape[1], 3), dtype=self.torch.float32, device=like.device)
+        return self._acc[key]
+
+    def finalize_band(self, s, c, halo, up, down, out):
+        return self.ctx.finalize_band(s, c, halo, up, down, out)
+
+    def merge_(self, hi, lo):
+        return self.ctx.merge_(hi, lo.contiguous())
 
 
 class BandDenoiser:

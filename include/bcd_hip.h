@@ -150,6 +150,11 @@ int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const floa
                              float *d_sum, int32_t *d_count);
 /* Denoiser::finalAggregation   src/core/Denoiser.cpp:458-469 */
 int bcd_hip_finalize(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int64_t npix, float *d_out);
+/* the same on `rows` lines of a row band (multi-GPU path), with the accumulator halos received from the neighbouring bands added
+ * to the first / last `halo` lines first (nullptr pair at a frame border): one launch instead of four adds and a finalisation */
+int bcd_hip_finalize_band(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int W, int rows, int halo,
+                          const float *d_up_sum, const int32_t *d_up_count, const float *d_down_sum, const int32_t *d_down_count,
+                          float *d_out);
 /* MultiscaleDenoiser pyramid + merge   src/core/MultiscaleDenoiser.cpp:243-334,453-548 */
 int bcd_hip_downscale_sum(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int D, float *d_out);
 int bcd_hip_downscale_avg(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int D, float *d_out);

@@ -31,8 +31,15 @@ for world in (1, 2, 4, 8):
                 if msg[0] == "sum":
                     msg = prog.send(int(msg[1]))
                     continue
-                _, up, down = msg
-                msg = prog.send((None if up is None else [t.clone() for t in up], None if down is None else [t.clone() for t in down]))
+                up, down = msg[1], msg[2]
+                if len(msg) == 5:   # receive buffers given: deliver in place
+                    for dst, src in ((msg[3], up), (msg[4], down)):
+                        if dst is not None:
+                            for d, t in zip(dst, src):
+                                d.copy_(t)
+                    msg = prog.send(None)
+                else:
+                    msg = prog.send((None if up is None else [t.clone() for t in up], None if down is None else [t.clone() for t in down]))
         except StopIteration as e:
             return e.value
     for _ in range(3):
