@@ -548,3 +548,25 @@ def test_unsupported_geometry_is_refused(hipctx):
     with pytest.raises(bh.BcdHipError):
         hipctx.denoise(*dev(col, ns, hist, cov), 6, bh.default_params())               # too many scales for 40 x 30
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("up,down", [(True, True), (True, False), (False, True), (False, False)])
+def test_finalize_band_equals_halo_adds_then_finalize(hipctx, up, down):
+    """the fused tail of the band path: one launch == add the received halos, then finalise (bit for bit)"""
+    import torch
+    rows, W, halo = 19, 37, 7
+    g = torch.Generator(device="cpu").manual_seed(3)
+    s = torch.rand((rows, W, 3), generator=g).cuda()
+    c = torch.randint(0, 5, (rows, W), generator=g, dtype=torch.int32).cuda()
+    us, ds = torch.rand((halo, W, 3), generator=g).cuda(), torch.rand((halo, W, 3), generator=g).cuda()
+    uc, dc = (torch.randint(0, 3, (halo, W), generator=g, dtype=torch.int32).cuda() for _ in range(2))
+    s2, c2 = s.clone(), c.clone()
+    if up:
+        s2[:halo] += us; c2[:halo] += uc
+    if down:
+        s2[rows - halo:] += ds; c2[rows - halo:] += dc
+    want = hipctx.finalize(s2, c2).cpu().numpy()
+    out = torch.empty_like(s)
+    hipctx.finalize_band(s, c, halo, (us, uc) if up else None, (ds, dc) if down else None, out)
+    assert bits_equal(out.cpu().numpy(), want)     # count 0 -> inf / nan like the reference, same bits
