@@ -17,7 +17,8 @@
 namespace {
 
 constexpr int PD_TW = 64; // tile width  (one wavefront per tile row)
-constexpr int PD_TH = 4;  // tile height (4 wavefronts per workgroup)
+constexpr int PD_TH = 4;
+constexpr int PD_CW = 12; // widest span of column displacements served by one staged window  // tile height (4 wavefronts per workgroup)
 
 // LDS pixel stride (floats): D/4 odd keeps ds_read_b128 at a per-lane stride of D*4 bytes conflict-free
 // IEEE-754 correctly rounded a / b without the range scaling of the compiler's sequence.  hipcc lowers an fp32 division to
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
     constexpr int DS = PdStride<D>::value;
     constexpr int Q = D / 4;
     extern __shared__ float4 lds4[];
-    const int ncols = PD_TW + 2 * b;
+    // the displacements of a line are evaluated in chunks of at most PD_CW + 1 columns, each with its own staged column window of
+    // 64 + PD_CW pixels: the LDS tile (73 KB -> two workgroups per CU) does not grow with the search radius
+    const int ncols = PD_TW + min(2 * b, PD_CW);
     float *lds_n = reinterpret_cast<float *>(lds4 + PD_TH * ncols * (DS / 4));
 
     // a wavefront covers a compact 16 x 4 pixel patch of the 64 x 4 tile (not a 64 x 1 line): neighbouring pixels in 2-D share
@@ -122,15 +125,17 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
     }
 
     int didx = 0;
-    for (int dl = 0; dl <= b; ++dl) {
+    for (int dl = 0; dl <= b; ++dl)
+      for (int cbeg = (dl == 0) ? 0 : -b; cbeg <= b; cbeg += PD_CW + 1) {
+        const int cend = min(b, cbeg + PD_CW);
         __syncthreads();
-        // stage rows row0+dl .. row0+dl+3, columns col0-b .. col0+63+b
+        // stage rows row0+dl .. row0+dl+3, columns col0+cbeg .. col0+63+cend
         const int npix = PD_TH * ncols;
         bool stage_bad = own_bad;
         for (int i = threadIdx.x; i < npix * Q; i += 256) {
             int p = i / Q, q = i - p * Q;
             int lr = p / ncols, lc = p - lr * ncols;
-            int gr = row0 + dl + lr, gc = col0 - b + lc;
+            int gr = row0 + dl + lr, gc = col0 + cbeg + lc;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gr < H && gc >= 0 && gc < W) v = reinterpret_cast<const float4 *>(hist)[((size_t)gr * W + gc) * Q + q];
             lds4[p * (DS / 4) + q] = v;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
         }
         for (int i = threadIdx.x; i < npix; i += 256) {
             int lr = i / ncols, lc = i - lr * ncols;
-            int gr = row0 + dl + lr, gc = col0 - b + lc;
+            int gr = row0 + dl + lr, gc = col0 + cbeg + lc;
             float nv = (gr < H && gc >= 0 && gc < W) ? ns[(size_t)gr * W + gc] : 1.f;
             lds_n[i] = nv;
             if (FAST) stage_bad = stage_bad || pd_n_bad(nv);
@@ -146,17 +151,17 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
         if (FAST && stage_bad) atomicOr(range_flag, 1); // some value is outside the range where pd_div<true> is proven exact
         __syncthreads();
 
-        const int dc0 = (dl == 0) ? 0 : -b;
+        const int dc0 = cbeg;
         // neighbour histograms are double-buffered in registers: the 15 ds_read_b128 of displacement dc+1 are in
         // flight while displacement dc is evaluated
         float4 bufA[Q], bufB[Q];
         auto fetch = [&](float4 *buf, int dc) __attribute__((always_inline)) {
-            const float4 *nb = lds4 + (ty * ncols + tx + dc + b) * (DS / 4);
+            const float4 *nb = lds4 + (ty * ncols + tx + dc - cbeg) * (DS / 4);
 #pragma unroll
             for (int q = 0; q < Q; ++q) buf[q] = nb[q];
         };
         auto evaluate = [&](const float4 *buf, int dc, int di) __attribute__((always_inline)) {
-            const float n2 = lds_n[ty * ncols + tx + dc + b];
+            const float n2 = lds_n[ty * ncols + tx + dc - cbeg];
             const float n12 = n1 * n2;
             const v2f n1v = { n1, n1 }, n2v = { n2, n2 }, n12v = { n12, n12 };
             float sum = 0.f;
@@ -188,15 +193,15 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
             }
         };
         fetch(bufA, dc0);
-        for (int dc = dc0; dc <= b; dc += 2) {
-            if (dc + 1 <= b) fetch(bufB, dc + 1);
+        for (int dc = dc0; dc <= cend; dc += 2) {
+            if (dc + 1 <= cend) fetch(bufB, dc + 1);
             evaluate(bufA, dc, didx++);
-            if (dc + 1 <= b) {
-                if (dc + 2 <= b) fetch(bufA, dc + 2);
+            if (dc + 1 <= cend) {
+                if (dc + 2 <= cend) fetch(bufA, dc + 2);
                 evaluate(bufB, dc + 1, didx++);
             }
         }
-    }
+      }
 }
 
 // generic-depth variant (any D <= 255): both histograms read from global memory, no staging.
@@ -494,7 +499,7 @@ hipError_t bcd_launch_selftest_div(uint32_t seed, int blocks, int per_thread, un
 size_t bcd_pairdist_lds_bytes(int D, int b)
 {
     int DS = ((D / 4) % 2 == 1) ? D : D + 4;
-    return (size_t)PD_TH * (PD_TW + 2 * b) * (DS + 1) * sizeof(float);
+    return (size_t)PD_TH * (PD_TW + (2 * b < PD_CW ? 2 * b : PD_CW)) * (DS + 1) * sizeof(float);
 }
 
 // fast != 0: scale-free division + range flag (d_range_flag must be zeroed by the caller); fast == 0: compiler division
