@@ -570,3 +570,19 @@ def test_finalize_band_equals_halo_adds_then_finalize(hipctx, up, down):
     out = torch.empty_like(s)
     hipctx.finalize_band(s, c, halo, (us, uc) if up else None, (ds, dc) if down else None, out)
     assert bits_equal(out.cpu().numpy(), want)     # count 0 -> inf / nan like the reference, same bits
+
+
+@pytest.mark.gpu
+def test_720p_three_scale_frame_against_the_oracle(hipctx):
+    """BASELINE config[1] at its full size: 1280 x 720, 3 scales, b = 6, w = 1, with -m 0 (order-free: the run the 1e-4 bar is
+    defined on); the oracle runs the reference's loop on the host cores of the box (about 20 s on 64 threads)"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H = 1280, 720
+    col, ns, hist, cov = core.synthetic_scene(W, H, 32, 1234, 0.35, 0.01)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), 3, bh.default_params(m=0.0)).cpu().numpy()
+    threads = min(64, _os.cpu_count() or 1)
+    want = ol.denoise_multiscale(col, ns, hist, cov, 3, ol.params(m=0.0, threads=threads))
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
