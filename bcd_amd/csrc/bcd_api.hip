@@ -73,6 +73,8 @@ struct Work {
     hipEvent_t ev_stage[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t ev_done = nullptr;
     hipEvent_t ev_built = nullptr; // this scale's pyramid level is complete
+    hipStream_t aux = nullptr;     // side stream: the fallback-pixel kernel runs beside the (latency-bound) full estimate kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct bcd_hip_ctx {
@@ -278,9 +280,15 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     const int strong_blocks = (int)std::min<int64_t>(cap, w == 1 ? (int64_t)ctx->num_cus * bcd_bayes27_blocks_per_cu(b) : 1024);
     const int weak_blocks = (int)std::min<int64_t>(cap, (int64_t)ctx->num_cus * 32);
     if (per_block) RCCHK(ensure(ctx, wk.gscratch, per_block * (size_t)strong_blocks));
+    // the two kernels only meet in the atomic accumulators: the fallback pixels (many cheap items) run on a side stream beside
+    // the full estimate (few long items that leave most of the chip's issue slots idle)
+    HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
+    HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
+    HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, d_c + 1, weak_blocks, W, H, w, b, d_sum, d_count, wk.aux));
+    HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
     HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, d_c, d_c + 4, strong_blocks, W, H, w, b, min_eig,
                                         d_sum, d_count, (float *)wk.gscratch.p, wk.gscratch.bytes, wk.stream));
-    HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, d_c + 1, weak_blocks, W, H, w, b, d_sum, d_count, wk.stream));
+    HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_join, 0));
     return BCD_HIP_OK;
 }
 
@@ -393,6 +401,9 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
     for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipEventCreate(&w.ev_stage[i]));
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_built, hipEventDisableTiming));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
     return BCD_HIP_OK;
 }
 
@@ -405,6 +416,9 @@ void work_destroy(Work &w)
     for (int i = 0; i < 4; ++i) if (w.ev_stage[i]) (void)hipEventDestroy(w.ev_stage[i]);
     if (w.ev_done) (void)hipEventDestroy(w.ev_done);
     if (w.ev_built) (void)hipEventDestroy(w.ev_built);
+    if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
+    if (w.ev_join) (void)hipEventDestroy(w.ev_join);
+    if (w.aux) (void)hipStreamDestroy(w.aux);
     if (w.owns_stream && w.stream) (void)hipStreamDestroy(w.stream);
 }
 
