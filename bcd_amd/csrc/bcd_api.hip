@@ -5,6 +5,7 @@
 #include "bcd_common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,7 +19,9 @@
 
 // launchers implemented in the k_*.hip files
 size_t bcd_pairdist_lds_bytes(int D, int b);
-hipError_t bcd_launch_pairdist(const float *, const float *, int, int, int, int, float *, uint8_t *, int, int *, hipStream_t);
+hipError_t bcd_launch_pairdist(const float *, const float *, int, int, int, int, float *, uint8_t *, int, int *, float, hipStream_t);
+hipError_t bcd_launch_uniform_n(const float *, int64_t, int *, hipStream_t);
+hipError_t bcd_launch_compare_planes(const float *, const uint8_t *, const float *, const uint8_t *, int64_t, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_selftest_div(uint32_t, int, int, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t);
 hipError_t bcd_launch_window_distances(const float *, const uint8_t *, int, int, int, int, int, int, float *, hipStream_t);
@@ -173,19 +176,32 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         e0 = wk.ev_pool[wk.ev_used].first;
         e1 = wk.ev_pool[wk.ev_used].second;
         ++wk.ev_used;
-        HIPCHK(ctx, hipEventRecord(e0, wk.stream));
     }
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int *d_flag = (int *)wk.counters.p + 40;
-    HIPCHK(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), wk.stream));
-    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, exact_mode == 1 ? 0 : 1, d_flag, wk.stream));
+    HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), wk.stream));
+    // fixed samples per pixel, a power of two (the usual case): the distance kernel drops the sample-count products (exactly,
+    // see k_pairdist).  One small reduction and one host round trip at the head of the chain (~30 us).
+    float uni_n = 0.f;
+    if (exact_mode != 1) {
+        HIPCHK(ctx, bcd_launch_uniform_n(d_ns, (int64_t)npix, d_flag + 1, wk.stream));
+        HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 41, d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
+        HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 42, d_ns, sizeof(float), hipMemcpyDeviceToHost, wk.stream));
+        HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+        float n0;
+        memcpy(&n0, wk.h_counters + 42, sizeof(n0));
+        int e = 0;
+        if (wk.h_counters[41] == 0 && n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
+    }
+    if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
+    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, exact_mode == 1 ? 0 : 1, d_flag, uni_n, wk.stream));
     if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
     // the fast kernel flags inputs outside the range where its division is proven exact: redo with the compiler's division
     if (exact_mode != 1) HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
     if (exact_mode == 0) {
         HIPCHK(ctx, hipStreamSynchronize(wk.stream));
         if (wk.h_counters[40] != 0)
-            HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, 0, d_flag, wk.stream));
+            HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, 0, d_flag, 0.f, wk.stream));
     }
     HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream));
     return BCD_HIP_OK;
@@ -744,7 +760,7 @@ int bcd_hip_window_distances(bcd_hip_ctx *ctx, const float *d_hist, const float 
     RCCHK(ensure(ctx, ctx->main.T, npix * nd * sizeof(float)));
     RCCHK(ensure(ctx, ctx->main.Cn, npix * nd));
     RCCHK(ensure(ctx, ctx->tmp_lo, n * sizeof(float)));
-    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->main.T.p, (uint8_t *)ctx->main.Cn.p, 0, nullptr, ctx->stream));
+    HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)ctx->main.T.p, (uint8_t *)ctx->main.Cn.p, 0, nullptr, 0.f, ctx->stream));
     HIPCHK(ctx, bcd_launch_window_distances((const float *)ctx->main.T.p, (const uint8_t *)ctx->main.Cn.p, W, H, w, b, line, col, (float *)ctx->tmp_lo.p, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->tmp_lo.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -863,6 +879,58 @@ int bcd_hip_zero_bad_values(bcd_hip_ctx *ctx, float *d_img, int64_t n)
     if (!ctx || !d_img || n <= 0) return bad(ctx, "bad argument");
     HIPCHK(ctx, bcd_launch_zero_bad(d_img, n, ctx->stream));
     return BCD_HIP_OK;
+}
+
+int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int search_radius,
+                                      int *variant, int64_t *mismatches)
+{
+    if (!ctx || !d_hist || !d_ns || !mismatches || W <= 0 || H <= 0 || D <= 0 || search_radius < 1) return bad(ctx, "bad argument");
+    Work &wk = ctx->main;
+    const size_t npix = (size_t)W * H;
+    const int nd = bcd_delta_count(search_radius);
+    RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
+    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+    float *T2 = nullptr;
+    uint8_t *C2 = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&T2, npix * nd * sizeof(float)));
+    if (hipMalloc((void **)&C2, npix * nd) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
+    int rc = BCD_HIP_OK;
+    do {
+        int *d_flag = (int *)wk.counters.p + 40;
+        unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>((int32_t *)wk.counters.p + 32);
+        if (hipMemsetAsync(d_flag, 0, 2 * sizeof(int), wk.stream) != hipSuccess || hipMemsetAsync(d_cnt, 0, sizeof(*d_cnt), wk.stream) != hipSuccess ||
+            bcd_launch_uniform_n(d_ns, (int64_t)npix, d_flag + 1, wk.stream) != hipSuccess ||
+            hipMemcpyAsync(wk.h_counters + 41, d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipMemcpyAsync(wk.h_counters + 42, d_ns, sizeof(float), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+        float n0, uni_n = 0.f;
+        memcpy(&n0, wk.h_counters + 42, sizeof(n0));
+        int e = 0;
+        if (wk.h_counters[41] == 0 && n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
+        // (entries whose neighbour lies outside the image are never written: clear both sets first)
+        if (hipMemsetAsync(wk.T.p, 0, npix * nd * sizeof(float), wk.stream) != hipSuccess || hipMemsetAsync(wk.Cn.p, 0, npix * nd, wk.stream) != hipSuccess ||
+            hipMemsetAsync(T2, 0, npix * nd * sizeof(float), wk.stream) != hipSuccess || hipMemsetAsync(C2, 0, npix * nd, wk.stream) != hipSuccess) {
+            rc = BCD_HIP_EDEVICE; break;
+        }
+        // production choice (fast division, uniform-count formula when it applies) against the compiler's division + general formula
+        if (bcd_launch_pairdist(d_hist, d_ns, W, H, D, search_radius, (float *)wk.T.p, (uint8_t *)wk.Cn.p, 1, d_flag, uni_n, wk.stream) != hipSuccess ||
+            bcd_launch_pairdist(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, d_flag, 0.f, wk.stream) != hipSuccess ||
+            bcd_launch_compare_planes((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, T2, C2, (int64_t)(npix * nd), d_cnt, wk.stream) != hipSuccess) {
+            rc = BCD_HIP_EDEVICE; break;
+        }
+        unsigned long long h = 0;
+        int flag = 0;
+        if (hipMemcpyAsync(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+        *mismatches = (int64_t)h;
+        if (variant) *variant = (uni_n > 0.f ? 2 : 1) | (flag << 4); // 1 = fast division, 2 = + uniform counts; bits 4.. = range / count flags raised
+    } while (false);
+    (void)hipFree(T2);
+    (void)hipFree(C2);
+    if (rc != BCD_HIP_OK) set_err(ctx, "distance kernel self-test failed to run");
+    return rc;
 }
 
 int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, int64_t *mismatches)

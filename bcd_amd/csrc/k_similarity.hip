@@ -74,10 +74,15 @@ template <int D> struct PdStride { static constexpr int value = ((D / 4) % 2 == 
 // ---------------------------------------------------------------------------------------------------
 // FAST = true: scale-free division (pd_div<true>); any staged value outside its guarded range raises *range_flag and the
 // host re-runs the scale with FAST = false (the compiler's division), so results are exact either way.
-template <int D, bool FAST>
+// UNI = true (with FAST): every pixel has the same sample count uni_n = 2^k (the usual case: fixed samples per pixel).  Then
+// n2 b1 - n1 b2 = 2^k RN(b1 - b2) and n1 n2 (b1 + b2) = 4^k RN(b1 + b2) exactly (scaling by a power of two commutes with rounding;
+// on the evaluated bins b1 + b2 > 1, so nothing is subnormal), the 4^k cancels in the correctly rounded quotient, and the term is
+// RN(RN(RN(b1 - b2)^2) / RN(b1 + b2)) bit for bit: three multiplications per bin less.  Every staged count is compared with uni_n;
+// a mismatch raises bit 1 of *range_flag and the host re-runs the scale with the general kernel.
+template <int D, bool FAST, bool UNI>
 __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist, const float *__restrict__ ns,
                                                    int W, int H, int b,
-                                                   float *__restrict__ T, uint8_t *__restrict__ Cn, int *range_flag)
+                                                   float *__restrict__ T, uint8_t *__restrict__ Cn, int *range_flag, float uni_n)
 {
     constexpr int DS = PdStride<D>::value;
     constexpr int Q = D / 4;
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
         // stage rows row0+dl .. row0+dl+3, columns col0+cbeg .. col0+63+cend
         const int npix = PD_TH * ncols;
         bool stage_bad = own_bad;
+        bool uni_bad = UNI && inside && n1 != uni_n;
         for (int i = threadIdx.x; i < npix * Q; i += 256) {
             int p = i / Q, q = i - p * Q;
             int lr = p / ncols, lc = p - lr * ncols;
@@ -144,11 +150,13 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
         for (int i = threadIdx.x; i < npix; i += 256) {
             int lr = i / ncols, lc = i - lr * ncols;
             int gr = row0 + dl + lr, gc = col0 + cbeg + lc;
-            float nv = (gr < H && gc >= 0 && gc < W) ? ns[(size_t)gr * W + gc] : 1.f;
+            float nv = (gr < H && gc >= 0 && gc < W) ? ns[(size_t)gr * W + gc] : (UNI ? uni_n : 1.f);
             lds_n[i] = nv;
             if (FAST) stage_bad = stage_bad || pd_n_bad(nv);
+            if (UNI) uni_bad = uni_bad || nv != uni_n;
         }
         if (FAST && stage_bad) atomicOr(range_flag, 1); // some value is outside the range where pd_div<true> is proven exact
+        if (UNI && uni_bad) atomicOr(range_flag, 2);    // a sample count differs from uni_n
         __syncthreads();
 
         const int dc0 = cbeg;
@@ -177,8 +185,14 @@ __global__ __launch_bounds__(256) void k_pairdist(const float *__restrict__ hist
                 // wave-uniform skip of a group of 4 bins that is empty for all 64 pixels of the wavefront (exact: skipped
                 // bins contribute nothing); inside an active group the divisions are independent
                 if (__builtin_amdgcn_ballot_w64(u0 || u1 || u2 || u3) != 0) {
-                    const v2f dlo = n2v * b1lo - n1v * b2lo, dhi = n2v * b1hi - n1v * b2hi;
-                    const v2f tlo = pd_div2<FAST>(dlo * dlo, n12v * slo), thi = pd_div2<FAST>(dhi * dhi, n12v * shi);
+                    v2f tlo, thi;
+                    if (UNI) {
+                        const v2f dlo = b1lo - b2lo, dhi = b1hi - b2hi;
+                        tlo = pd_div2<FAST>(dlo * dlo, slo); thi = pd_div2<FAST>(dhi * dhi, shi);
+                    } else {
+                        const v2f dlo = n2v * b1lo - n1v * b2lo, dhi = n2v * b1hi - n1v * b2hi;
+                        tlo = pd_div2<FAST>(dlo * dlo, n12v * slo); thi = pd_div2<FAST>(dhi * dhi, n12v * shi);
+                    }
                     sum = u0 ? sum + tlo.x : sum; // bins in order: the reference's sequential sum
                     sum = u1 ? sum + tlo.y : sum;
                     sum = u2 ? sum + thi.x : sum;
@@ -502,26 +516,59 @@ size_t bcd_pairdist_lds_bytes(int D, int b)
     return (size_t)PD_TH * (PD_TW + (2 * b < PD_CW ? 2 * b : PD_CW)) * (DS + 1) * sizeof(float);
 }
 
+// are all sample counts bitwise equal to the first one?  (out[0] |= 1 if not; the host looks at ns[0] itself)
+static __global__ void k_uniform_n(const float *__restrict__ ns, int64_t npix, int *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool diff = i < npix && __float_as_uint(ns[i]) != __float_as_uint(ns[0]);
+    if (__builtin_amdgcn_ballot_w64(diff) != 0 && (threadIdx.x & 63) == 0) atomicOr(out, 1);
+}
+
+// self-test: number of entries where two sets of T / C planes differ bitwise
+static __global__ void k_compare_planes(const float *__restrict__ Ta, const uint8_t *__restrict__ Ca, const float *__restrict__ Tb,
+                                        const uint8_t *__restrict__ Cb, int64_t n, unsigned long long *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool diff = i < n && (__float_as_uint(Ta[i]) != __float_as_uint(Tb[i]) || Ca[i] != Cb[i]);
+    unsigned long long bal = __builtin_amdgcn_ballot_w64(diff);
+    if (bal != 0 && (threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)__popcll(bal));
+}
+
+hipError_t bcd_launch_compare_planes(const float *Ta, const uint8_t *Ca, const float *Tb, const uint8_t *Cb, int64_t n, unsigned long long *out,
+                                     hipStream_t st)
+{
+    hipLaunchKernelGGL(k_compare_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Ta, Ca, Tb, Cb, n, out);
+    return hipGetLastError();
+}
+
+hipError_t bcd_launch_uniform_n(const float *ns, int64_t npix, int *d_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_uniform_n, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, ns, npix, d_out);
+    return hipGetLastError();
+}
+
 // fast != 0: scale-free division + range flag (d_range_flag must be zeroed by the caller); fast == 0: compiler division
+// uni_n > 0 (with fast): all sample counts equal this power of two (verified by the kernel, bit 1 of the flag)
 hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H, int D, int b,
-                               float *T, uint8_t *Cn, int fast, int *d_range_flag, hipStream_t st)
+                               float *T, uint8_t *Cn, int fast, int *d_range_flag, float uni_n, hipStream_t st)
 {
     dim3 grid((W + PD_TW - 1) / PD_TW, (H + PD_TH - 1) / PD_TH), block(256);
     size_t lds = bcd_pairdist_lds_bytes(D, b);
     bool tiled = (D % 4 == 0) && lds <= 160 * 1024;
-#define BCD_PD_LAUNCH(DD, FF)                                                                                        \
+#define BCD_PD_LAUNCH(DD, FF, UU)                                                                                    \
     {                                                                                                                \
         if (lds > 64 * 1024) {                                                                                       \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist<DD, FF>),                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist<DD, FF, UU>),              \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_pairdist<DD, FF>), grid, block, lds, st, hist, ns, W, H, b, T, Cn, d_range_flag);      \
+        hipLaunchKernelGGL((k_pairdist<DD, FF, UU>), grid, block, lds, st, hist, ns, W, H, b, T, Cn, d_range_flag, uni_n); \
         return hipGetLastError();                                                                                    \
     }
 #define BCD_PD_CASE(DD)                                                                                              \
     case DD:                                                                                                         \
-        if (fast) BCD_PD_LAUNCH(DD, true) else BCD_PD_LAUNCH(DD, false)
+        if (fast && uni_n > 0.f) BCD_PD_LAUNCH(DD, true, true)                                                      \
+        else if (fast) BCD_PD_LAUNCH(DD, true, false) else BCD_PD_LAUNCH(DD, false, false)
     if (tiled) switch (D) {
         BCD_PD_CASE(60)
         BCD_PD_CASE(120)

@@ -36,7 +36,7 @@ SYMBOLS = [
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
-    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_selftest_division",
+    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels",
 ]
 
 _lib = None
@@ -283,6 +283,13 @@ class Context:
 
     def reset_kernel_time(self):
         self._chk(lib().bcd_hip_reset_kernel_time(self.h))
+
+    def selftest_distance_kernels(self, hist, ns, b):
+        """(variant, mismatching plane entries) of the production distance kernel against the exact general one on these inputs"""
+        H, W, D = hist.shape
+        v, n = C.c_int(0), C.c_int64(0)
+        self._chk(lib().bcd_hip_selftest_distance_kernels(self.h, _dp(hist), _dp(ns), W, H, D, b, C.byref(v), C.byref(n)))
+        return v.value, n.value
 
     def selftest_division(self, samples, seed=1):
         n = C.c_int64(-1)

@@ -177,6 +177,11 @@ int bcd_hip_zero_bad_values(bcd_hip_ctx *ctx, float *d_img, int64_t n);
 /* self-test: the scale-free division used by the pair-distance kernel against the compiler's IEEE division on
  * `samples` hashed operand pairs drawn from its guarded range; *mismatches must come back 0 */
 int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, int64_t *mismatches);
+/* self-test of the pair-distance kernels on given inputs: the production variant (fast division; the uniform power-of-two sample-count
+ * formula when it applies) against the compiler's division with the general formula; *mismatches = entries of the T / C planes that
+ * differ bitwise (0 expected unless a range / count flag was raised: *variant bits 4..); *variant & 15: 1 = fast, 2 = fast + uniform */
+int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius,
+                                      int *variant, int64_t *mismatches);
 
 /* ---- host utilities (no device work) ----------------------------------------------------------- */
 /* the visiting order implied by (random_order, seed): main-pixel linear indices line*W+col in

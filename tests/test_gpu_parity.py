@@ -586,3 +586,43 @@ def test_720p_three_scale_frame_against_the_oracle(hipctx):
     ok = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), ok)
     assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["uniform_pow2", "uniform_12", "mixed", "one_pixel_differs"])
+def test_sample_count_paths_of_the_distance_kernel_bitexact(hipctx, kind):
+    """k_pairdist drops the sample-count products when every pixel has the same power-of-two count (exact identity); any other
+    input -- a uniform count that is no power of two, mixed counts, a single odd pixel -- takes the general formula.  Both bit-exact."""
+    W, H, b = 70, 37, 6
+    rng = np.random.default_rng(11)
+    spp = {"uniform_pow2": 16, "uniform_12": 12}.get(kind, 16)
+    samples, _ = ol.synth_samples(W, H, spp, seed=5, sigma=0.3, spike_prob=0.01)
+    if kind == "mixed":            # drop a random subset of the samples: 8..16 samples per pixel
+        keep = rng.random(samples.shape[0]) < 0.75
+        keep[::spp] = True
+        samples = np.ascontiguousarray(samples[keep])
+    elif kind == "one_pixel_differs":
+        samples = np.ascontiguousarray(samples[1:])      # pixel (0, 0) has one sample less
+    ns, mean, cov, hist = ol.oracle_ops()["accumulate"](samples, W, H)
+    assert (len(np.unique(ns)) == 1) == kind.startswith("uniform")
+    d_hist, d_ns = dev(hist, ns)
+    mask, cnt = hipctx.similarity_masks(d_hist, d_ns, 1, b, 1.0)
+    wmask, wcnt = ol.similarity_masks(ns, hist, 1, b, 1.0)
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask)
+    assert np.array_equal(cnt.cpu().numpy(), wcnt)
+    for (l, c) in [(1, 1), (H // 2, W // 2), (2, 3)]:
+        assert bits_equal(hipctx.window_distances(d_hist, d_ns, 1, b, l, c), ol.window_distances(ns, hist, 1, b, l, c))
+    # every entry of the 85 T / C planes: production variant == compiler division + general formula, bit for bit
+    variant, mismatches = hipctx.selftest_distance_kernels(d_hist, d_ns, b)
+    assert variant == (2 if kind == "uniform_pow2" else 1) and mismatches == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sigma,spikes", [(0.35, 0.01), (0.08, 0.0)])
+def test_distance_planes_of_a_benchmark_frame_bitexact(hipctx, sigma, spikes):
+    """all 85 T / C planes of a 640 x 360 frame of the benchmark generator (32 spp: uniform power-of-two counts, wave-uniform bin
+    skipping at work): production kernel == compiler division + general formula, bit for bit"""
+    import bcd_amd.core as core
+    col, ns, hist, cov = core.synthetic_scene(640, 360, 32, 1234, sigma, spikes)
+    variant, mismatches = hipctx.selftest_distance_kernels(*dev(hist, ns), 6)
+    assert variant == 2 and mismatches == 0
