@@ -12,6 +12,7 @@
 // This file is compiled with -ffp-contract=off: the reference is built without FMA contraction and the
 // membership test d <= tau is discrete.
 #include "bcd_common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -557,10 +558,12 @@ hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H,
     bool tiled = (D % 4 == 0) && lds <= 160 * 1024;
 #define BCD_PD_LAUNCH(DD, FF, UU)                                                                                    \
     {                                                                                                                \
-        if (lds > 64 * 1024) {                                                                                       \
+        static std::atomic<size_t> granted{0}; /* per instantiation: the attribute call is not free, make it once per size */ \
+        if (lds > 64 * 1024 && granted.load() < lds) {                                                               \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist<DD, FF, UU>),              \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) return e;                                                                           \
+            granted.store(lds);                                                                                      \
         }                                                                                                            \
         hipLaunchKernelGGL((k_pairdist<DD, FF, UU>), grid, block, lds, st, hist, ns, W, H, b, T, Cn, d_range_flag, uni_n); \
         return hipGetLastError();                                                                                    \
