@@ -1,14 +1,17 @@
-// k_bayes27.hip -- Bayesian patch estimate for the default patch radius w = 1 (K = 27), one wavefront per
-// processed pixel, 14.3 KB of LDS per wavefront (11 wavefronts per CU).
+// k_bayes27.hip -- Bayesian patch estimate for the default patch radius w = 1 (K = 27): persistent wavefronts (one
+// workgroup = one wavefront, 13.2 KB of LDS and 148 VGPRs: 12 per CU), one processed pixel at a time.
 //
 // Same mathematics as DenoisingUnit::denoiseSelectedPatches (src/core/DenoisingUnit.cpp:388-453) and
 // aggregateOutputPatches (:672-693), reorganised for the GPU:
-//   * the similar patches are streamed through a 30-member LDS chunk three times (mean, covariance,
-//     final estimate) instead of being held as n x 27 clouds; sums keep the reference's sequential order;
+//   * the noise mean and the colour mean are summed straight from global memory; the similar patches are then streamed
+//     through a 29-member LDS chunk twice (covariance, final estimate) instead of being held as n x 27 clouds; sums keep
+//     the reference's sequential member order;
+//   * the covariance, the spectral rebuild, the Step-2 products and the final estimate run on the f32 matrix core
+//     (v_mfma_f32_32x32x2_f32: exact f32, a chain of fma over k);
 //   * Step 2's covariance of the Step-1 estimates (:441-443) is obtained without touching the members
 //     again: the Step-1 estimate is affine, xhat = x - G (x - m), G = N Cinv1, so its empirical mean is m
 //     and its empirical covariance is F C F^T with F = I - G  (exact identity, fp32 round-off apart);
-//   * clampNegativeEigenValues (:606-630) is a parallel two-sided Jacobi eigendecomposition in LDS;
+//   * clampNegativeEigenValues (:606-630) is a parallel two-sided Jacobi eigendecomposition, rows in registers;
 //   * inverseSymmetricMatrix (:578-604) = V diag(1/max(minEig, lambda)) V^T equals the plain inverse
 //     whenever lambda_min >= minEig.  The inverse is computed with the symmetric sweep operator and
 //     accepted only if every pivot is positive and ||M^-1||_F * minEig <= 1 (which proves
@@ -46,9 +49,9 @@ __device__ inline int noise_idx(int i, int j)
 
 // ---- parallel two-sided Jacobi, Brent-Luk ordering, rows held in registers ------------------------------
 // Slots 0..27 (27 = zero padding) are paired (2i, 2i+1).  One round: lanes i < 14 compute the rotation of pair i from
-// LDS; then every lane loads ONE row (lanes 0..27: rows of A, lanes 32..58: rows of V) as 7 x ds_read_b128, applies the
-// 14 column-pair rotations on registers with static indices, lane pairs (2i, 2i+1) exchange their rows with a DPP
-// quad_perm (row rotation of A), and the result is written to the other (ping-pong) buffer at its Brent-Luk permuted
+// LDS; lanes 0..27 load ONE row of A each (7 x ds_read_b128), lanes 32..58 keep their row of V in registers; every lane applies
+// the 14 column-pair rotations on registers with static indices, lane pairs (2i, 2i+1) exchange their rows with a DPP
+// quad_perm (row rotation of A), and the rows of A are written back in place at their Brent-Luk permuted
 // position: slot s moves to sigma(s), 0->0, 1->2, 2i->2i+2, 26->27, 2i+1->2i-1.  After 27 rounds every pair of slots
 // has met once (one sweep).  Eigenvalues = diagonal of A (in slot order), eigenvectors = columns of V (same order):
 // V f(diag) V^T needs no bookkeeping of the permutation.  Matrices here use a leading dimension of 28 floats.
@@ -227,7 +230,7 @@ __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
 }
 
 // compact in-place two-sided Jacobi on LD-layout matrices (round-robin pairs, everything through LDS): only used by the rare
-// spectral fallback of inverse27, where the register-row solver's ping-pong buffers are not available
+// spectral fallback of inverse27 (LD layout in, LD layout out, no conversion)
 __device__ void jacobi27_inplace(float *A, float *V, float *prm /* 4 * KP/2 floats */, int lane)
 {
     float *rc = prm, *rs = prm + KP / 2;
