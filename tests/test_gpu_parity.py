@@ -626,3 +626,15 @@ def test_distance_planes_of_a_benchmark_frame_bitexact(hipctx, sigma, spikes):
     col, ns, hist, cov = core.synthetic_scene(640, 360, 32, 1234, sigma, spikes)
     variant, mismatches = hipctx.selftest_distance_kernels(*dev(hist, ns), 6)
     assert variant == 2 and mismatches == 0
+
+
+@pytest.mark.gpu
+def test_similarity_masks_bitexact_on_a_large_scale(hipctx):
+    """scales of >= 400 k pixels take the four-columns-per-lane forward-mask kernel: masks and counts against the oracle (host threads)"""
+    import bcd_amd.core as core
+    W, H, b = 1024, 400, 6
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 99, 0.3, 0.01)
+    mask, cnt = hipctx.similarity_masks(*dev(hist, ns), 1, b, 1.0)
+    wmask, wcnt = ol.similarity_masks(ns, hist, 1, b, 1.0, threads=min(64, _os.cpu_count() or 1))
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask)
+    assert np.array_equal(cnt.cpu().numpy(), wcnt)
