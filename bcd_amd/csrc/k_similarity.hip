@@ -624,14 +624,16 @@ hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H,
     dim3 grid((W + PD_TW - 1) / PD_TW, (H + PD_TH - 1) / PD_TH), block(256);
     size_t lds = bcd_pairdist_lds_bytes(D, b);
     bool tiled = (D % 4 == 0) && lds <= 160 * 1024;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
 #define BCD_PD_LAUNCH(DD, FF, UU)                                                                                    \
     {                                                                                                                \
-        static std::atomic<size_t> granted{0}; /* per instantiation: the attribute call is not free, make it once per size */ \
-        if (lds > 64 * 1024 && granted.load() < lds) {                                                               \
+        static std::atomic<size_t> granted[64]; /* per instantiation and device: make the attribute call once per size */ \
+        if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || granted[dev].load() < lds)) {                                \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist<DD, FF, UU>),              \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) return e;                                                                           \
-            granted.store(lds);                                                                                      \
+            if (dev >= 0 && dev < 64) granted[dev].store(lds);                                                       \
         }                                                                                                            \
         hipLaunchKernelGGL((k_pairdist<DD, FF, UU>), grid, block, lds, st, hist, ns, W, H, b, T, Cn, d_range_flag, uni_n); \
         return hipGetLastError();                                                                                    \
