@@ -23,7 +23,11 @@ hipError_t bcd_launch_pairdist(const float *, const float *, int, int, int, int,
 hipError_t bcd_launch_uniform_n(const float *, int64_t, int *, hipStream_t);
 hipError_t bcd_launch_compare_planes(const float *, const uint8_t *, const float *, const uint8_t *, int64_t, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_selftest_div(uint32_t, int, int, unsigned long long *, hipStream_t);
-hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t);
+hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t,
+                            const BcdBorderline *, const float *, const float *, int);
+int bcd_pairdist_cs_supported(int D);
+hipError_t bcd_launch_pairdist_cs(const float *, const float *, int, int, int, int, float *, uint8_t *, int *, float, hipStream_t);
+hipError_t bcd_launch_max_rel_dev(const float *, const float *, const uint8_t *, const uint8_t *, int, int, int, unsigned int *, hipStream_t);
 hipError_t bcd_launch_window_distances(const float *, const uint8_t *, int, int, int, int, int, int, float *, hipStream_t);
 hipError_t bcd_launch_pixel_cov(const float *, const float *, int64_t, float *, hipStream_t);
 hipError_t bcd_launch_finalize_band(const float *, const int32_t *, int, int, int, const float *, const int32_t *, const float *, const int32_t *, float *,
@@ -67,7 +71,8 @@ struct DevBuf {
 struct Work {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, gscratch, dep, tmp_lo; // grow-only
+    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, gscratch, dep, tmp_lo, border; // grow-only
+    int border_capacity = 0;       // entries of `border` offered to the last fast similarity pass (0: the exact kernels ran)
     int rounds_hint = 0;           // marking launches the last problem needed
     bool dep_ready = false;        // dependency lists of the current marking problem are in `dep` (reset by active_init)
     int32_t *h_counters = nullptr; // pinned
@@ -86,6 +91,7 @@ struct bcd_hip_ctx {
     bool owns_stream = false;
     bool profiling = false;
     bool concurrent_scales = true;
+    bool fast_similarity = true; // approximate distance planes + exact re-evaluation at the threshold (k_similarity_fast.hip)
     int num_cus = 256;
     std::mutex err_mutex;
     std::string err;
@@ -155,8 +161,18 @@ int check_params(bcd_hip_ctx *ctx, int W, int H, int D, const bcd_hip_params *pr
     return BCD_HIP_OK;
 }
 
-// exact_mode: 0 = fast division, range flag checked here (one stream synchronisation); 1 = the compiler's division;
-// 2 = fast division, flag copied to wk.h_counters[40] but NOT checked: the caller validates after its own synchronisation
+// did the last similarity() pass on this workspace leave the range flag raised or overflow its borderline list?  (valid after the
+// stream has been synchronised; the caller then repeats the pass with exact_mode = 1)
+bool similarity_needs_redo(const Work &wk)
+{
+    return wk.h_counters[40] != 0 || (wk.border_capacity > 0 && wk.h_counters[43] > wk.border_capacity);
+}
+
+// exact_mode: 0 = production kernels, flags checked here (one stream synchronisation); 1 = exact kernels with the compiler's division;
+// 2 = production kernels, flags copied to wk.h_counters[40] / [43] but NOT checked: the caller validates after its own
+// synchronisation with similarity_needs_redo().
+// Production kernels: w = 1 and a supported depth -> approximate planes (k_pairdist_cs) + exact verification of the borderline
+// pairs; otherwise the exact planes with the scale-free division (k_pairdist<FAST>).
 int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
                uint32_t *d_mask, int32_t *d_count, int exact_mode = 0)
 {
@@ -178,8 +194,11 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         ++wk.ev_used;
     }
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
-    int *d_flag = (int *)wk.counters.p + 40;
-    HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), wk.stream));
+    int *d_flag = (int *)wk.counters.p + 40; // [0] range / count flag, [1] uniform-count scan, [3] borderline pairs
+    HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream));
+    wk.h_counters[40] = 0;
+    wk.h_counters[43] = 0;
+    wk.border_capacity = 0;
     // fixed samples per pixel, a power of two (the usual case): the distance kernel drops the sample-count products (exactly,
     // see k_pairdist).  One small reduction and one host round trip at the head of the chain (~30 us).
     float uni_n = 0.f;
@@ -193,6 +212,26 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         int e = 0;
         if (wk.h_counters[41] == 0 && n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
     }
+    // the approximate path needs tau (1 +- delta) to be ordinary numbers well above the underflow threshold of a term
+    const bool fast = exact_mode != 1 && ctx->fast_similarity && w == 1 && bcd_pairdist_cs_supported(D) && tau >= 1e-18f && tau <= 1e18f;
+    if (fast) {
+        const int capacity = (int)std::min<size_t>(std::max<size_t>(npix, 1u << 16), 1u << 28);
+        RCCHK(ensure(ctx, wk.border, (size_t)capacity * sizeof(uint2)));
+        wk.border_capacity = capacity;
+        if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
+        HIPCHK(ctx, bcd_launch_pairdist_cs(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream));
+        if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
+        HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
+        BcdBorderline bl = { 0.f, (uint2 *)wk.border.p, d_flag + 3, capacity };
+        HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream,
+                                     &bl, d_hist, d_ns, D));
+        HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 43, d_flag + 3, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
+        if (exact_mode == 0) {
+            HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+            if (similarity_needs_redo(wk)) return similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 1);
+        }
+        return BCD_HIP_OK;
+    }
     if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
     HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, exact_mode == 1 ? 0 : 1, d_flag, uni_n, wk.stream));
     if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
@@ -203,7 +242,8 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         if (wk.h_counters[40] != 0)
             HIPCHK(ctx, bcd_launch_pairdist(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, 0, d_flag, 0.f, wk.stream));
     }
-    HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream));
+    HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream,
+                                 nullptr, nullptr, nullptr, 0));
     return BCD_HIP_OK;
 }
 
@@ -351,7 +391,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
                          prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)wk.state.p, &st.active_rounds));
         if (attempt == 1) break;
         if (!(prm->marked_skip_probability > 0.f)) HIPCHK(ctx, hipStreamSynchronize(wk.stream)); // no marking batch brought the flag back
-        if (wk.h_counters[40] == 0) break; // every input inside the range where the fast division is proven exact
+        if (!similarity_needs_redo(wk)) break; // inputs inside the guarded range, borderline list not overflowed
     }
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
     HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.stream));
@@ -364,6 +404,8 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     int64_t ns = 0, nw = 0, tot = 0;
     bayes_counts(wk, &ns, &nw, &tot);
     st.processed = ns + nw; st.fallback = nw; st.similar_total = tot;
+    st.similarity_path = wk.border_capacity > 0 ? 1 : 0;
+    st.borderline_pairs = wk.border_capacity > 0 ? wk.h_counters[43] : 0;
     if (prof) {
         st.ms_similarity = stage_ms(wk, 0, 1);
         st.ms_active = stage_ms(wk, 1, 2);
@@ -425,7 +467,7 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
 
 void work_destroy(Work &w)
 {
-    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep, &w.tmp_lo };
+    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep, &w.tmp_lo, &w.border };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (w.h_counters) (void)hipHostFree(w.h_counters);
     for (auto &pr : w.ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -488,6 +530,8 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
     }
     const char *env = getenv("BCD_HIP_SERIAL_SCALES");
     ctx->concurrent_scales = !(env && env[0] == '1');
+    env = getenv("BCD_HIP_EXACT_SIMILARITY");
+    ctx->fast_similarity = !(env && env[0] == '1');
     *out = ctx;
     return BCD_HIP_OK;
 }
@@ -520,6 +564,13 @@ int bcd_hip_set_concurrent_scales(bcd_hip_ctx *ctx, int enabled)
 {
     if (!ctx) return BCD_HIP_EINVAL;
     ctx->concurrent_scales = enabled != 0;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_set_fast_similarity(bcd_hip_ctx *ctx, int enabled)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    ctx->fast_similarity = enabled != 0;
     return BCD_HIP_OK;
 }
 
@@ -930,6 +981,59 @@ int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, con
     (void)hipFree(T2);
     (void)hipFree(C2);
     if (rc != BCD_HIP_OK) set_err(ctx, "distance kernel self-test failed to run");
+    return rc;
+}
+
+int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int search_radius,
+                                     float *max_rel_dev, int64_t *count_mismatches, int *flags)
+{
+    if (!ctx || !d_hist || !d_ns || !max_rel_dev || !count_mismatches || W <= 0 || H <= 0 || search_radius < 1) return bad(ctx, "bad argument");
+    if (!bcd_pairdist_cs_supported(D)) { set_err(ctx, "no approximate kernel for this histogram depth"); return BCD_HIP_EUNSUPPORTED; }
+    Work &wk = ctx->main;
+    const size_t npix = (size_t)W * H;
+    const int nd = bcd_delta_count(search_radius);
+    RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
+    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+    float *T2 = nullptr;
+    uint8_t *C2 = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&T2, npix * nd * sizeof(float)));
+    if (hipMalloc((void **)&C2, npix * nd) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
+    int rc = BCD_HIP_OK;
+    do {
+        int *d_flag = (int *)wk.counters.p + 40;
+        unsigned int *d_res = reinterpret_cast<unsigned int *>((int32_t *)wk.counters.p + 32);
+        if (hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream) != hipSuccess || hipMemsetAsync(d_res, 0, 2 * sizeof(unsigned int), wk.stream) != hipSuccess ||
+            bcd_launch_uniform_n(d_ns, (int64_t)npix, d_flag + 1, wk.stream) != hipSuccess ||
+            hipMemcpyAsync(wk.h_counters + 41, d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipMemcpyAsync(wk.h_counters + 42, d_ns, sizeof(float), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+        float n0, uni_n = 0.f;
+        memcpy(&n0, wk.h_counters + 42, sizeof(n0));
+        int e = 0;
+        if (wk.h_counters[41] == 0 && n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
+        if (hipMemsetAsync(wk.T.p, 0, npix * nd * sizeof(float), wk.stream) != hipSuccess || hipMemsetAsync(wk.Cn.p, 0, npix * nd, wk.stream) != hipSuccess ||
+            hipMemsetAsync(T2, 0, npix * nd * sizeof(float), wk.stream) != hipSuccess || hipMemsetAsync(C2, 0, npix * nd, wk.stream) != hipSuccess) {
+            rc = BCD_HIP_EDEVICE; break;
+        }
+        // approximate planes (production variant) against the exact planes (compiler's division, general formula)
+        if (bcd_launch_pairdist_cs(d_hist, d_ns, W, H, D, search_radius, (float *)wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream) != hipSuccess ||
+            bcd_launch_pairdist(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, d_flag, 0.f, wk.stream) != hipSuccess ||
+            bcd_launch_max_rel_dev((const float *)wk.T.p, T2, (const uint8_t *)wk.Cn.p, C2, W, H, search_radius, d_res, wk.stream) != hipSuccess) {
+            rc = BCD_HIP_EDEVICE; break;
+        }
+        unsigned int h[2] = { 0u, 0u };
+        int flag = 0;
+        if (hipMemcpyAsync(h, d_res, sizeof(h), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+        memcpy(max_rel_dev, &h[0], sizeof(float));
+        *count_mismatches = (int64_t)h[1];
+        if (flags) *flags = (uni_n > 0.f ? 2 : 1) | (flag << 4);
+    } while (false);
+    (void)hipFree(T2);
+    (void)hipFree(C2);
+    if (rc != BCD_HIP_OK) set_err(ctx, "approximate-distance self-test failed to run");
     return rc;
 }
 

@@ -35,3 +35,14 @@ __host__ __device__ inline int bcd_delta_index(int dl, int dc, int b)
     return dl == 0 ? dc : (b + 1) + (dl - 1) * (2 * b + 1) + (dc + b);
 }
 __host__ __device__ inline int bcd_delta_count(int b) { return (b + 1) + b * (2 * b + 1); }
+
+// ---- fast similarity path (k_similarity_fast.hip): approximate distance planes, exact decision at the threshold ----
+// relative half-width of the band around tau inside which a pair is re-evaluated exactly; the worst-case deviation of the
+// approximate patch distance from the reference's fp32 value is ~1e-5 (derivation in k_similarity_fast.hip)
+#define BCD_APPROX_DELTA 6.103515625e-05f /* 2^-14 */
+struct BcdBorderline {
+    float tau_hi;      // tau (1 + delta); the kernels get tau (1 - delta) as their threshold
+    uint2 *list;       // (pixel index, displacement index) of the pairs with tau_lo < d' <= tau_hi
+    int *counter;      // number of appended pairs (may exceed capacity: then the host falls back to the exact kernels)
+    int capacity;
+};

@@ -312,9 +312,18 @@ __device__ inline int lane_down(int v)     { return __shfl_down(v, 1); }
 // planes are loaded once and shared by the lines of the strip (1.5 loads per output instead of 3); the nine T values are
 // summed in the reference's order (patch line by line, left to right), the counts are integers.
 constexpr int FWD_RB = 4;
+// APPROX: the planes come from k_pairdist_cs (k_similarity_fast.hip); tau is then tau (1 - delta), pairs up to bl.tau_hi are
+// appended to the borderline list (their bit is decided by k_verify_pairs)
+__device__ inline void borderline_append(const BcdBorderline &bl, uint32_t pix, uint32_t didx)
+{
+    const int slot = atomicAdd(bl.counter, 1);
+    if (slot < bl.capacity) bl.list[slot] = make_uint2(pix, didx);
+}
+
+template <bool APPROX>
 __global__ __launch_bounds__(64) void k_fwd_masks_w1(const float *__restrict__ T, const uint8_t *__restrict__ Cn,
                                                      int W, int H, int b, float tau, int fwords, int nd,
-                                                     uint32_t *__restrict__ fwd)
+                                                     uint32_t *__restrict__ fwd, BcdBorderline bl)
 {
     const int lane = threadIdx.x;
     const int c = blockIdx.x * 62 + lane - 1; // lanes 1..62 produce output
@@ -357,7 +366,10 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const float *__restrict__ T
             const int n = nh[i] + nh[i + 1] + nh[i + 2];
             const int r = rb + i;
             const float d = s / (float)n; // 0/0 = NaN -> not similar
-            if (cols_ok && r >= 1 && r <= H - 2 && r + dl <= H - 2 && d <= tau) word[i] |= 1u << (didx & 31);
+            if (cols_ok && r >= 1 && r <= H - 2 && r + dl <= H - 2) {
+                if (d <= tau) word[i] |= 1u << (didx & 31);
+                else if (APPROX && writer && d <= bl.tau_hi) borderline_append(bl, (uint32_t)(r * W + c), (uint32_t)didx);
+            }
         }
     }
 #pragma unroll
@@ -368,9 +380,10 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const float *__restrict__ T
 // The same with four columns per lane (image widths that are multiples of 4): 16-byte plane loads instead of 4-byte ones -- the
 // kernel streams 391 MB of planes at 720p and the narrow version reached half of what a plain streaming kernel does.  A
 // wavefront covers 256 columns, of which the 248 of lanes 1..62 are produced (the outer lanes only supply the halo).
+template <bool APPROX>
 __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const float *__restrict__ T, const uint8_t *__restrict__ Cn,
                                                        int W, int H, int b, float tau, int fwords, int nd,
-                                                       uint32_t *__restrict__ fwd)
+                                                       uint32_t *__restrict__ fwd, BcdBorderline bl)
 {
     const int lane = threadIdx.x;
     const int c = blockIdx.x * 248 - 4 + 4 * lane; // first of the lane's four columns
@@ -418,7 +431,10 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const float *__restrict__
                 const int n = nh[i][j] + nh[i + 1][j] + nh[i + 2][j];
                 const int r = rb + i;
                 const float d = s / (float)n; // 0/0 = NaN -> not similar
-                if (cols_ok && r >= 1 && r <= H - 2 && r + dl <= H - 2 && d <= tau) word[i][j] |= 1u << (didx & 31);
+                if (cols_ok && r >= 1 && r <= H - 2 && r + dl <= H - 2) {
+                    if (d <= tau) word[i][j] |= 1u << (didx & 31);
+                    else if (APPROX && writer && d <= bl.tau_hi) borderline_append(bl, (uint32_t)(r * W + cj), (uint32_t)didx);
+                }
             }
         }
     }
@@ -656,20 +672,36 @@ hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H,
     return hipGetLastError();
 }
 
+hipError_t bcd_launch_verify_pairs(const float *, const float *, int, int, int, int, float, const void *, const int *, int, uint32_t *, hipStream_t);
+
+// ap != nullptr: T / Cn are the approximate planes of k_pairdist_cs; pairs within tau (1 +- BCD_APPROX_DELTA) are listed and
+// re-evaluated exactly from (hist, ns) before the symmetric masks are completed (w = 1 only)
 hipError_t bcd_launch_masks(const float *T, const uint8_t *Cn, int W, int H, int w, int b, float tau,
-                            uint32_t *mask, int32_t *count, uint32_t *fwd_scratch, hipStream_t st)
+                            uint32_t *mask, int32_t *count, uint32_t *fwd_scratch, hipStream_t st,
+                            const BcdBorderline *ap, const float *hist, const float *ns, int D)
 {
     const int side = 2 * b + 1, words = (side * side + 31) / 32;
     int64_t npix = (int64_t)W * H;
     if (w == 1 && fwd_scratch) {
         const int fwords = (bcd_delta_count(b) + 31) / 32;
+        BcdBorderline bl = { tau, nullptr, nullptr, 0 };
+        float tau_k = tau;
+        if (ap) { bl = *ap; bl.tau_hi = tau * (1.f + BCD_APPROX_DELTA); tau_k = tau * (1.f - BCD_APPROX_DELTA); }
         // the wide kernel needs enough lines to fill the chip (few, fat wavefronts); small scales keep the narrow one
-        if (W % 4 == 0 && (int64_t)W * H >= 400000)
-            hipLaunchKernelGGL(k_fwd_masks_w1v4, dim3((W + 247) / 248, (H + FWD_RB - 1) / FWD_RB, fwords), dim3(64), 0, st, T, Cn, W, H, b, tau,
-                               fwords, bcd_delta_count(b), fwd_scratch);
+        const bool wide = W % 4 == 0 && (int64_t)W * H >= 400000;
+        const dim3 gw((W + 247) / 248, (H + FWD_RB - 1) / FWD_RB, fwords), gn((W + 61) / 62, (H + FWD_RB - 1) / FWD_RB, fwords);
+        if (wide && ap)
+            hipLaunchKernelGGL(k_fwd_masks_w1v4<true>, gw, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
+        else if (wide)
+            hipLaunchKernelGGL(k_fwd_masks_w1v4<false>, gw, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
+        else if (ap)
+            hipLaunchKernelGGL(k_fwd_masks_w1<true>, gn, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
         else
-            hipLaunchKernelGGL(k_fwd_masks_w1, dim3((W + 61) / 62, (H + FWD_RB - 1) / FWD_RB, fwords), dim3(64), 0, st, T, Cn, W, H, b, tau, fwords,
-                               bcd_delta_count(b), fwd_scratch);
+            hipLaunchKernelGGL(k_fwd_masks_w1<false>, gn, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
+        if (ap) {
+            hipError_t e = bcd_launch_verify_pairs(hist, ns, W, H, D, b, tau, bl.list, bl.counter, bl.capacity, fwd_scratch, st);
+            if (e != hipSuccess) return e;
+        }
         dim3 grid((W + 63) / 64, (H + 3) / 4);
         if (b == 6 || b == 12) {
             const size_t lds = (size_t)(4 + b) * (64 + 2 * b) * fwords * sizeof(uint32_t);
@@ -681,6 +713,7 @@ hipError_t bcd_launch_masks(const float *T, const uint8_t *Cn, int W, int H, int
             hipLaunchKernelGGL(k_sym_masks, grid, dim3(256), 0, st, fwd_scratch, W, H, b, fwords, words, mask, count);
         return hipGetLastError();
     }
+    if (ap) return hipErrorInvalidValue;
     dim3 block(64, 4);
     dim3 grid((W + 63) / 64, H, (words + 3) / 4);
     hipLaunchKernelGGL(k_masks, grid, block, 0, st, T, Cn, W, H, w, b, tau, words, mask);

@@ -25,18 +25,19 @@ class BandJob(C.Structure):
 class ScaleStats(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("main_pixels", C.c_int64), ("processed", C.c_int64),
                 ("fallback", C.c_int64), ("similar_total", C.c_int64), ("active_rounds", C.c_int32),
-                ("ms_similarity", C.c_float), ("ms_active", C.c_float), ("ms_bayes", C.c_float), ("ms_total", C.c_float)]
+                ("ms_similarity", C.c_float), ("ms_active", C.c_float), ("ms_bayes", C.c_float), ("ms_total", C.c_float),
+                ("similarity_path", C.c_int32), ("borderline_pairs", C.c_int32)]
 
 
 # every symbol include/bcd_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
-    "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
+    "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
-    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels",
+    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels", "bcd_hip_selftest_approx_distance",
 ]
 
 _lib = None
@@ -290,6 +291,17 @@ class Context:
         v, n = C.c_int(0), C.c_int64(0)
         self._chk(lib().bcd_hip_selftest_distance_kernels(self.h, _dp(hist), _dp(ns), W, H, D, b, C.byref(v), C.byref(n)))
         return v.value, n.value
+
+    def set_fast_similarity(self, on):
+        self._chk(lib().bcd_hip_set_fast_similarity(self.h, 1 if on else 0))
+
+    def selftest_approx_distance(self, hist, ns, b):
+        """(max relative deviation of a patch distance, pairs with different bin counts, flags) of the approximate distance planes
+        against the exact ones on these inputs"""
+        H, W, D = hist.shape
+        r, n, f = C.c_float(0), C.c_int64(0), C.c_int(0)
+        self._chk(lib().bcd_hip_selftest_approx_distance(self.h, _dp(hist), _dp(ns), W, H, D, b, C.byref(r), C.byref(n), C.byref(f)))
+        return r.value, n.value, f.value
 
     def selftest_division(self, samples, seed=1):
         n = C.c_int64(-1)

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of the denoising hot path on MI355X (BASELINE.json metric).
 
-A "step" is one full denoise of one synthetic frame (3-scale, b=6, w=1, tau=1, m=1, seeded random order): the
-pyramid build, and per scale the pair-distance / mask kernels, the marking fixed point, the Bayesian patch
-kernel, finalisation and merge.  Inputs are resident in HBM before the timed region.
+A "step" is one full denoise of one synthetic 1920x1080 frame (BASELINE.json configs[2]: 3-scale, b=6, w=1, tau=1, m=1,
+seeded random order): the pyramid build, and per scale the pair-distance / mask kernels, the marking fixed point, the
+Bayesian patch kernel, finalisation and merge.  Inputs are resident in HBM before the timed region.
+After the timed region (N = 1, untimed, skipped by --no-extras): the pair-distance kernel with the scales serialised
+(`roofline.isolated_*`), the low-noise variant of the frame (`low_noise`), the same frame with -m 0 (`m0`), and the CPU
+oracle on all host cores and on one core (`cpu_baseline`).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into horizontal bands of
 main pixels (strong scaling); every rank owns a band plus (b+w)*2^(S-1) halo lines of input, rebuilds the pyramid
 for its band, and exchanges accumulator / output halo lines with its neighbours over RCCL.
@@ -31,8 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scales", type=int, default=3)
     ap.add_argument("--spp", type=int, default=32)
     ap.add_argument("--sigma", type=float, default=0.35, help="synthetic noise level (0.35 + 1%% spikes = SURVEY probe)")
@@ -41,32 +44,55 @@ def parse():
     ap.add_argument("--skip-prob", type=float, default=1.0, help="-m of bcd_cli")
     ap.add_argument("--random-order", type=int, default=1, help="-r of bcd_cli")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--isolated", action="store_true", help="also time the pair-distance kernel with the scales serialised (3 extra untimed steps)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs after the timed region (isolated kernel timing, low-noise frame, -m 0)")
     ap.add_argument("--exact-marking", action="store_true", help="N > 1: -m 1 marking follows the whole-frame order (state exchanges between marking launches)")
     ap.add_argument("--band-path", action="store_true", help="use the multi-GPU row-band code path even with one rank (debug)")
-    ap.add_argument("--cpu-sample", default="960x540", help="frame size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample", default="960x540", help="frame size of the bounded CPU-baseline sample (all host cores)")
+    ap.add_argument("--cpu-sample-1core", default="160x90", help="frame size of the one-core CPU-baseline sample")
     return ap.parse_args()
 
 
 def cpu_baseline(args):
-    """oracle (own C port of the reference CPU/OpenMP path) on the host cores, bounded sample of the same workload:
-    same generator, same flags, reference-style OpenMP scheduling (racy marks, strip order)."""
+    """oracle (own C port of the reference CPU/OpenMP path) on the host cores, bounded samples of the same workload:
+    same generator, same flags, reference-style OpenMP scheduling (racy marks, strip order); all cores and --ncores 1."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     import bcd_amd.core as core
-    w, h = [int(v) for v in args.cpu_sample.split("x")]
-    col, ns, hist, cov = core.synthetic_scene(w, h, args.spp, 1234, args.sigma, args.spikes)
     cores = os.cpu_count() or 1
-    prm = ol.params(tau=1.0, w=1, b=args.search_radius, m=args.skip_prob, threads=cores)
-    best = None
-    for _ in range(2):
-        t0 = time.perf_counter()
-        ol.denoise_multiscale(col, ns, hist, cov, args.scales, prm, racy=True)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+
+    def run(size, threads, reps):
+        w, h = [int(v) for v in size.split("x")]
+        col, ns, hist, cov = core.synthetic_scene(w, h, args.spp, 1234, args.sigma, args.spikes)
+        prm = ol.params(tau=1.0, w=1, b=args.search_radius, m=args.skip_prob, threads=threads)
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ol.denoise_multiscale(col, ns, hist, cov, args.scales, prm, racy=threads > 1)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return w, h, best
+
+    w, h, best = run(args.cpu_sample, cores, 2)
+    # the reference's schedule(dynamic, (W - 2) * 2b) hands out strips of 2b lines: at most ceil((H - 2) / 2b) threads have work
+    strips = [max(1, -(-((h >> s) - 2) // (2 * args.search_radius))) for s in range(args.scales)]
+    w1, h1, best1 = run(args.cpu_sample_1core, 1, 1)
     return {"value": round(w * h / 1e6 / best, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
-            "sample": "%dx%d synthetic frame (same generator/flags), %d-scale, OpenMP dynamic strips like the reference, "
-                      "best of 2, %.2f s" % (w, h, args.scales, best)}
+            "effective_parallelism_per_scale": [min(cores, n) for n in strips],
+            "sample": "%dx%d synthetic frame (same generator/flags), %d-scale, OpenMP dynamic strips of 2b lines like the reference "
+                      "(Denoiser.cpp:149-205), best of 2, %.2f s" % (w, h, args.scales, best),
+            "one_core": {"value": round(w1 * h1 / 1e6 / best1, 5), "unit": "Mpix/s", "cores": 1,
+                         "sample": "%dx%d synthetic frame, --ncores 1 (sequential visiting order), %.2f s" % (w1, h1, best1)}}
+
+
+def per_scale_stats(ctx, S):
+    scales = []
+    for s in range(S):
+        st = ctx.stats(s)
+        scales.append({"scale": s, "w": st.width, "h": st.height, "processed_frac": round(st.processed / max(1, st.main_pixels), 4),
+                       "fallback_frac": round(st.fallback / max(1, st.processed), 4),
+                       "mean_similar": round(st.similar_total / max(1, st.processed), 2), "rounds": st.active_rounds,
+                       "borderline_pairs": st.borderline_pairs if st.similarity_path == 1 else None})
+    return scales
 
 
 def main():
@@ -115,7 +141,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    ctx.reset_kernel_time()
+    kt_warm = ctx.kernel_time()  # (ms, launches) of the pair-distance kernel so far: the event pool is never reset, legs are differences
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -134,34 +160,56 @@ def main():
     ms_step = elapsed * 1e3 / args.steps
 
     # ---- roofline of the dominant kernel (pair-distance planes), HIP events on the engine's streams over the timed region
-    pd_ms, pd_launches = ctx.kernel_time()
+    kt_timed = ctx.kernel_time()
+    pd_ms, pd_launches = kt_timed[0] - kt_warm[0], kt_timed[1] - kt_warm[1]
+    scales = per_scale_stats(ctx, S)
+    single = world == 1 and not args.band_path
     # the three scales run concurrently on separate streams, so a launch's event-to-event time includes the kernels it
-    # overlaps with; the same kernel timed in isolation (scales one after the other, two extra untimed steps):
+    # overlaps with; the same kernel timed in isolation (scales one after the other, three extra untimed steps):
     iso_ms = None
-    if args.isolated and world == 1 and not args.band_path:
+    extras = {}
+    if single and not args.no_extras:
         ctx.set_concurrent_scales(False)
         step()
-        torch.cuda.synchronize()
-        ctx.reset_kernel_time()
+        k0 = ctx.kernel_time()
         step()
         step()
-        iso_total, iso_n = ctx.kernel_time()
-        iso_ms = iso_total / max(1, iso_n)
+        k1 = ctx.kernel_time()
+        iso_ms = (k1[0] - k0[0]) / max(1, k1[1] - k0[1])
         ctx.set_concurrent_scales(True)
-    scale_pixels = []
-    for s in range(S):
-        st = ctx.stats(s)
-        scale_pixels.append(st.width * st.height)
-    algo_bytes_per_step = ALGO_READ_BYTES_PER_PIXEL * sum(scale_pixels)
+
+        def leg(frame, prm_leg, reps):
+            d = [torch.from_numpy(a).cuda() for a in frame]
+            ctx.denoise(*d, S, prm_leg, out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ctx.denoise(*d, S, prm_leg, out)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) * 1e3 / reps
+            return {"value": round(W * H / 1e6 / (ms * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms, 4), "steps": reps,
+                    "per_scale": per_scale_stats(ctx, S)}
+        # on the default frame most processed pixels take the fallback path; the low-noise variant (sigma 0.10, no
+        # spikes) and -m 0 (every main pixel processed) exercise the full Bayesian estimate
+        extras["low_noise"] = dict(leg(core.synthetic_scene(W, H, args.spp, 1234, 0.10, 0.0), prm, 3),
+                                   workload="same frame generator with sigma 0.10, no spikes")
+        extras["m0"] = dict(leg((col, ns, hist, cov), bh.default_params(b=b, w=w, m=0.0, random_order=args.random_order, seed=1234), 2),
+                            workload="the default frame with -m 0 (no marking: every main pixel is processed)")
+    all_ms, all_launches = ctx.kernel_time()  # every launch of this process, warm-up and untimed legs included
+    algo_bytes_per_step = ALGO_READ_BYTES_PER_PIXEL * sum(sc["w"] * sc["h"] for sc in scales)
     achieved = (algo_bytes_per_step * args.steps / (pd_ms * 1e-3)) / 1e9 if pd_ms > 0 else 0.0
+    fast = all(sc["borderline_pairs"] is not None for sc in scales)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "k_pairdist<60>", "launches": pd_launches,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
+                "kernel": "k_pairdist_cs<60> (approximate planes; borderline pairs re-evaluated exactly by k_verify_pairs)" if fast else "k_pairdist<60>",
+                "launches": pd_launches,
                 "avg_launch_ms": round(pd_ms / max(1, pd_launches), 4),
+                "whole_process": {"launches": all_launches, "avg_launch_ms": round(all_ms / max(1, all_launches), 4),
+                                  "note": "all launches of this command incl. warm-up and the untimed legs: what `rocprofv3 --kernel-trace --stats` of the same command averages (profiles/)"},
                 "algorithmic_bytes_per_launch_avg": int(algo_bytes_per_step / S),
                 "isolated_avg_launch_ms": None if iso_ms is None else round(iso_ms, 4),
                 "isolated_frac": None if not iso_ms else round((algo_bytes_per_step / S) / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "VALU-bound kernel (85 displacements x 60 bins of exact chi-square per pixel); the 3 scales run concurrently on separate streams, so launch durations include overlap -- isolated timing: --isolated / profiles/; see DESIGN.md"}
+                "note": "VALU-bound kernel (85 displacements x 60 bins of chi-square per pixel); the 3 scales run concurrently on separate streams, so launch durations in the timed region include overlap -- isolated_* = the same kernel with the scales serialised; see DESIGN.md"}
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file):
         try:
@@ -169,15 +217,9 @@ def main():
             key = "%dx%d_s%d" % (W, H, S)
             if key in tr:
                 roofline["traffic"] = tr[key]["hbm_bytes_per_launch_avg"]
+                roofline["traffic_source"] = "profiled offline: tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload), profiles/pmc_traffic.json"
         except Exception:
             pass
-
-    scales = []
-    for s in range(S):
-        st = ctx.stats(s)
-        scales.append({"scale": s, "w": st.width, "h": st.height, "processed_frac": round(st.processed / max(1, st.main_pixels), 4),
-                       "fallback_frac": round(st.fallback / max(1, st.processed), 4),
-                       "mean_similar": round(st.similar_total / max(1, st.processed), 2), "rounds": st.active_rounds})
 
     if rank == 0:
         res = {
@@ -187,9 +229,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d synthetic frame (%d spp, sigma %.2f, spikes %.2f), %d-scale, b=%d w=1 d=1 e=1e-8, -m %g -r %d (seeded), no prefilter"
                                    % (W, H, args.spp, args.sigma, args.spikes, S, b, args.skip_prob, args.random_order),
-                       "parallelism": ("rowband%d%s" % (world, "-exactmark" if args.exact_marking else "")) if world > 1 else "single", "per_scale": scales},
+                       "parallelism": ("rowband%d%s" % (world, "-exactmark" if args.exact_marking else "-bandmark")) if world > 1 else "single", "per_scale": scales},
             "roofline": roofline,
         }
+        res.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(res), flush=True)

@@ -62,6 +62,8 @@ typedef struct bcd_hip_scale_stats {
     float   ms_active;
     float   ms_bayes;
     float   ms_total;
+    int32_t similarity_path;  /* 1 = approximate planes + exact verification at the threshold, 0 = exact planes */
+    int32_t borderline_pairs; /* pairs re-evaluated exactly (similarity_path == 1)  */
 } bcd_hip_scale_stats;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -75,6 +77,10 @@ int  bcd_hip_set_profiling(bcd_hip_ctx *ctx, int enabled);
 /* multiscale runs drive the (independent) scales concurrently, one HIP stream + host thread each (default on; also
  * disabled by BCD_HIP_SERIAL_SCALES=1).  Results are identical either way. */
 int  bcd_hip_set_concurrent_scales(bcd_hip_ctx *ctx, int enabled);
+/* similar-patch selection through approximate pair-distance planes with an exact re-evaluation of every pair within
+ * tau (1 +- 2^-14) (default on for w = 1 and D in {24, 36, 60}; also disabled by BCD_HIP_EXACT_SIMILARITY=1).  The masks are
+ * bit-identical either way; 0 forces the exact kernels. */
+int  bcd_hip_set_fast_similarity(bcd_hip_ctx *ctx, int enabled);
 int  bcd_hip_get_stats(const bcd_hip_ctx *ctx, int scale, bcd_hip_scale_stats *out);
 /* duration (ms, HIP events on the context's stream) and launch count of the pair-distance kernel
  * accumulated since the last reset -- the dominant kernel measured by bench.py's roofline */
@@ -182,6 +188,13 @@ int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, 
  * differ bitwise (0 expected unless a range / count flag was raised: *variant bits 4..); *variant & 15: 1 = fast, 2 = fast + uniform */
 int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius,
                                       int *variant, int64_t *mismatches);
+
+/* self-test of the approximate pair-distance kernel (k_pairdist_cs) on given inputs: *max_rel_dev = largest relative deviation of a
+ * patch distance d(p, p + delta) computed from the approximate planes from the one computed from the exact planes, over all pairs of
+ * main pixels (must stay far below 2^-14, the half-width of the band that is re-evaluated exactly); *count_mismatches = pairs whose
+ * integer bin counts differ (must be 0); *flags as *variant above */
+int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius,
+                                     float *max_rel_dev, int64_t *count_mismatches, int *flags);
 
 /* ---- host utilities (no device work) ----------------------------------------------------------- */
 /* the visiting order implied by (random_order, seed): main-pixel linear indices line*W+col in

@@ -638,3 +638,52 @@ def test_similarity_masks_bitexact_on_a_large_scale(hipctx):
     wmask, wcnt = ol.similarity_masks(ns, hist, 1, b, 1.0, threads=min(64, _os.cpu_count() or 1))
     assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask)
     assert np.array_equal(cnt.cpu().numpy(), wcnt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["bench_noisy", "bench_clean", "mixed_counts", "b12", "ragged"])
+def test_fast_similarity_path_equals_exact_kernels(hipctx, kind):
+    """approximate distance planes + exact re-evaluation of the pairs within tau (1 +- 2^-14) (k_similarity_fast.hip) give the
+    masks of the exact kernels bit for bit; the approximate patch distances stay far inside that band; bin counts are exact"""
+    import bcd_amd.core as core
+    b, tau = 6, 1.0
+    if kind == "bench_noisy":
+        col, ns, hist, cov = core.synthetic_scene(640, 360, 32, 1234, 0.35, 0.01)
+    elif kind == "bench_clean":
+        col, ns, hist, cov = core.synthetic_scene(640, 360, 32, 1234, 0.10, 0.0)
+    elif kind == "mixed_counts":
+        rng = np.random.default_rng(3)
+        samples, _ = ol.synth_samples(200, 64, 16, seed=5, sigma=0.3, spike_prob=0.01)
+        keep = rng.random(samples.shape[0]) < 0.75
+        keep[::16] = True
+        ns, mean, cov, hist = ol.oracle_ops()["accumulate"](np.ascontiguousarray(samples[keep]), 200, 64)
+    elif kind == "b12":
+        col, ns, hist, cov = core.synthetic_scene(200, 90, 16, 7, 0.2, 0.01)
+        b, tau = 12, 0.9
+    else:
+        col, ns, hist, cov = core.synthetic_scene(131, 37, 8, 11, 0.3, 0.01)
+    d_hist, d_ns = dev(hist, ns)
+    try:
+        hipctx.set_fast_similarity(True)
+        m1, c1 = hipctx.similarity_masks(d_hist, d_ns, 1, b, tau)
+        hipctx.set_fast_similarity(False)
+        m0, c0 = hipctx.similarity_masks(d_hist, d_ns, 1, b, tau)
+    finally:
+        hipctx.set_fast_similarity(True)
+    assert np.array_equal(m1.cpu().numpy(), m0.cpu().numpy())
+    assert np.array_equal(c1.cpu().numpy(), c0.cpu().numpy())
+    rel, count_mismatches, flags = hipctx.selftest_approx_distance(d_hist, d_ns, b)
+    assert count_mismatches == 0 and (flags >> 4) == 0
+    assert rel < 2.0 ** -14 / 8, rel  # measured ~3e-7; the exactly re-evaluated band is +-6.1e-5
+
+
+@pytest.mark.gpu
+def test_fast_similarity_path_is_the_default_and_reports_its_borderline_pairs(hipctx):
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    col, ns, hist, cov = core.synthetic_scene(320, 200, 32, 1234, 0.35, 0.01)
+    prm = bh.default_params(b=6, w=1, m=1.0, random_order=1, seed=1234)
+    out = hipctx.denoise(*dev(col, ns, hist, cov), 1, prm)
+    st = hipctx.stats(0)
+    assert st.similarity_path == 1 and 0 <= st.borderline_pairs < 320 * 200
+    assert np.isfinite(out.cpu().numpy()[1:-1, 1:-1]).all()
