@@ -22,10 +22,11 @@
 
 // per-phase cycle counters of one wavefront, filled only by the DBG instantiation (BCD_DBG_BAYES=1: printed after the launch)
 __device__ long long bcd_dbg_cycles[24];
+__device__ int bcd_dbg_item = 100; // which work item the DBG instantiation stamps (BCD_DBG_ITEM)
 
 namespace {
 
-#define DBG_T(i) do { if (DBG && item == 100 && lane == 0) bcd_dbg_cycles[i] = __builtin_readcyclecounter(); } while (0)
+#define DBG_T(i) do { if (DBG && item == bcd_dbg_item && lane == 0) bcd_dbg_cycles[i] = __builtin_readcyclecounter(); } while (0)
 
 constexpr int K = 27, KP = 28, LD = 29, P = 9, MSZ = KP * KP, CHUNK = MSZ / K; // matrix buffer: 784 floats; 29 members per staging chunk
 
@@ -93,7 +94,7 @@ __device__ void jacobi27(float *A0, float *V0, float *cs, int lane, int item)
         }
         off = wsum(off);
         dg = wsum(dg);
-        if (DBG && item == 100 && lane == 0) bcd_dbg_cycles[12 + sweep] = (long long)(1e18f * off / dg);
+        if (DBG && item == bcd_dbg_item && lane == 0) bcd_dbg_cycles[12 + sweep] = (long long)(1e18f * off / dg);
         if (off <= 1e-13f * dg) break;
         for (int round = 0; round < KP - 1; ++round) {
             // lanes 0..13: rotation of the slot pair (2 lane, 2 lane + 1); the other lanes compute on a harmless copy of pair 0
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
         }
     }
     DBG_T(10);
-    if (DBG && item == 100 && lane == 0) bcd_dbg_cycles[11] = n;
+    if (DBG && item == bcd_dbg_item && lane == 0) bcd_dbg_cycles[11] = n;
     __syncthreads(); // the next item reuses the LDS
   }
 }
@@ -664,6 +665,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     g.W = W; g.H = H; g.b = b; g.side = 2 * b + 1; g.words = (g.side * g.side + 31) / 32; g.maxS = g.side * g.side;
     if (g.words > 32) return hipErrorInvalidValue;
     if (getenv("BCD_DBG_BAYES")) {
+        if (const char *e = getenv("BCD_DBG_ITEM")) { int v = atoi(e); (void)hipMemcpyToSymbol(HIP_SYMBOL(bcd_dbg_item), &v, sizeof(v)); }
         hipLaunchKernelGGL(k_bayes27<true>, dim3(blocks), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, d_nlist, d_work, g, min_eig, sum, cnt);
         long long h[24];
         (void)hipStreamSynchronize(st);

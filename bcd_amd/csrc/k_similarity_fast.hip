@@ -9,27 +9,28 @@
 // (sequential bins, IEEE division) and sets their bits.  The masks are therefore bit-identical to the exact path.
 //
 // Error bound (fp32, u = 2^-24; inputs inside the guarded range of k_similarity.hip, so nothing overflows or is
-// subnormal on an evaluated bin):  reference term  t = RN(RN(diff^2) / den),   here  t' = RN-fused(RN(diff^2) * rcp(den)),
-// with the SAME diff and den (computed by the same operations as the reference: den = RN(RN(n1 n2) RN(b1+b2)), diff =
-// RN(RN(n2 b1) - RN(n1 b2)); for uniform power-of-two counts RN(b1-b2) and RN(b1+b2), see k_similarity.hip).  v_rcp_f32 is
-// accurate to 1 ulp (|rel| <= 2u), so |t'/t - 1| <= 3u + O(u^2) before the accumulation; all terms are >= 0, hence any
-// summation order of the <= 9 D terms of a patch distance carries a relative error <= (9 D - 1) u in either path, the
-// final division one more u.  For D = 60:  |d'/d - 1| <= (3 + 2 * 540 + 2) u ~ 6.5e-5 in the WORST case over all
-// round-offs pointing the same way -- BCD_APPROX_DELTA = 2^-13 = 1.22e-4 is almost twice that; the measured maximum over
-// whole frames is ~3e-7 (bcd_hip_selftest_approx_distance reports it; the GPU tests assert it stays below delta / 16).
-// Depths above 120 bins do not use this path.
+// subnormal on an evaluated bin).  Both paths compute the SAME diff and den with the same operations: den = RN(RN(n1 n2)
+// RN(b1+b2)), diff = RN(RN(n2 b1) - RN(n1 b2)) (uniform power-of-two counts: RN(b1-b2), RN(b1+b2), see k_similarity.hip).
+// With t* = RN(diff^2) / den (exact quotient):  reference term RN(t*) = t* (1 + e), |e| <= u;  here the product
+// RN(diff^2) * rcp(den) enters a fused multiply-add unrounded, and v_rcp_f32 is accurate to 1 ulp: t' = t* (1 + e'),
+// |e'| <= 2u.  All terms are >= 0, so every addition adds at most u of relative error to what it sums.  A term of the
+// reference's patch distance goes through <= (D - 1) + 8 additions and one division: d_ref = d* (1 + a), |a| <= (D + 9) u;
+// here through <= D + 8 fma / additions and one division: d' = d* (1 + a'), |a'| <= (D + 11) u.  Hence
+//     |d' / d_ref - 1| <= (2 D + 20) u + O(u^2)  =  8.3e-6 for D = 60
+// in the worst case (every round-off pointing the same way); BCD_APPROX_DELTA = 2^-14 = 6.1e-5 is 7 times that.  Measured
+// maximum over whole frames: ~4.4e-7 (bcd_hip_selftest_approx_distance; the GPU tests assert < delta / 8).
 //
-// Layout of the kernel (gfx950, SIMD-32, 512 VGPRs per lane and SIMD, 160 KB LDS per CU):
-//   workgroup = 4 x 64 pixel tile, 12 wavefronts = 4 pixel patches of 16 x 4  x  3 thirds of the histogram (the colour
-//   channels when D = 3 x nbOfBins): a wavefront keeps D/3 = 20 bins of its own pixels in VGPRs (~75 VGPRs: 6 wavefronts
-//   per SIMD instead of the 2 of the exact kernel), all 12 share one staged window of neighbour histograms in LDS (73 KB:
-//   two workgroups per CU = 24 wavefronts per CU).  With that occupancy LDS reads, branches and scalar work issue in the
-//   shadow of the VALU, and a divergent `if (b1 + b2 > 1)` around the 5 arithmetic instructions of a bin (execz branch)
-//   skips a bin as soon as it is empty for the 64 pixels of the wavefront: 49 % of the bins are evaluated on the noisy
-//   bench frame, 20 % on a clean one.  The partial sums of the three thirds meet in LDS once per staged window (13
-//   displacements), where the 12 wavefronts also re-map them to full 256-byte plane lines for the stores.
+// Cost model that shaped the kernel (measured on MI355X): a SIMD issues about one instruction of ANY kind per 2-3 cycles
+// -- VALU, scalar, branch and LDS instructions all compete for it -- so the aim is the smallest instruction count per
+// (pixel, displacement, bin), not the cheapest arithmetic alone:
+//   * a divergent `if (b1 + b2 > 1)` around the 5 arithmetic instructions of a bin (execz branch) under a wave-uniform
+//     test of its group of 4 bins: 49 % of the bins are evaluated on the noisy bench frame, 20 % on a clean one,
+//     ~7.5 instructions per bin on average (flat, select-based code: 9-10; the exact kernel: ~20);
+//   * 128 VGPRs -> 4 wavefronts per SIMD (the exact kernel: 2), neighbour histograms read two float4 ahead of their use.
 #include "bcd_common.h"
 #include <atomic>
+#include <cstdlib>
+
 
 namespace {
 
@@ -37,167 +38,189 @@ constexpr int CS_TW = 64, CS_TH = 4;   // tile
 constexpr int CS_CW = 12;              // widest span of column displacements served by one staged window
 constexpr int CS_NCOLS = CS_TW + CS_CW;
 constexpr int CS_ND = CS_CW + 1;       // displacements per window
-constexpr int CS_WAVES = 12, CS_THREADS = CS_WAVES * 64;
 
 constexpr float CS_BIN_MAX = 1048576.f;   // the guarded range of k_similarity.hip (PD_BIN_MAX, PD_N_MIN, PD_N_MAX)
 constexpr float CS_N_MIN = 0.0009765625f;
 constexpr float CS_N_MAX = 65536.f;
 
-template <int D> struct CsLayout {
-    static_assert(D % 12 == 0, "three thirds of whole float4 groups");
-    static constexpr int NB = D / 3;                              // bins per wavefront
-    static constexpr int ROW = ((CS_NCOLS * D + 63) / 64) * 64;   // window line stride (dwords): a multiple of the 64 banks
-    static constexpr int WIN = CS_TH * ROW;                       // window (dwords)
-    static constexpr int EXT = 3 * CS_ND * 256;                   // exchange area, T partials (aliases the window)
-    static constexpr int EXC = 3 * 4 * 256;                       //                C partials, four 8-bit counts per dword
-    static constexpr int BUF = WIN > EXT + EXC ? WIN : EXT + EXC; // window and exchange area share one buffer
-    static constexpr int LDS_DWORDS = BUF + CS_TH * CS_NCOLS;     // + sample counts of the window
+// ---------------------------------------------------------------------------------------------------
+// k_pairdist_rw: rolling window, displacements split between two wavefront sets.
+//   workgroup = 4 x 64 pixel tile, 8 wavefronts: wavefront (line ty, half hv) owns the 64 pixels of tile line ty (whole
+//   histogram in VGPRs) and evaluates the displacements j = hv, hv + 2, ... of the current displacement line.  The neighbour
+//   histograms live in a ring of four image lines in LDS (line g in slot g & 3; 64 + 12 columns): going from displacement line
+//   dl to dl + 1 replaces ONE line (row0 + dl by row0 + dl + 4) -- 10 staged lines per tile instead of 28 -- and that line
+//   is fetched into registers while dl is being evaluated.  No exchange between wavefronts: every wavefront stores whole
+//   256-byte lines of the T plane itself.  Search windows wider than 13 columns are covered by several passes over dl, one
+//   per chunk of <= 13 column displacements.
+// ---------------------------------------------------------------------------------------------------
+constexpr int RW_THREADS = 512;
+
+template <int D> struct RwLayout {
+    static_assert(D % 4 == 0, "whole float4 groups");
+    static constexpr int ROW = ((CS_NCOLS * D + 63) / 64) * 64; // ring line stride (dwords): a multiple of the 64 banks
+    static constexpr int LDS_DWORDS = 4 * ROW + 4 * CS_NCOLS;    // + sample counts
+    static constexpr int NPRE = (CS_NCOLS * (D / 4) + RW_THREADS - 1) / RW_THREADS; // float4 per thread of one prefetched line
 };
 
 template <int D, bool UNI>
-__global__ __launch_bounds__(CS_THREADS) void k_pairdist_cs(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H,
+__global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H,
                                                               int b, float *__restrict__ T, uint8_t *__restrict__ Cn, int *range_flag,
                                                               float uni_n)
 {
-    using L = CsLayout<D>;
-    constexpr int NB = L::NB, Q = NB / 4;
+    using L = RwLayout<D>;
+    constexpr int Q = D / 4, NPRE = L::NPRE;
     extern __shared__ float4 lds4[];
-    float *win = reinterpret_cast<float *>(lds4);
-    float *win_n = win + L::BUF;
-    float *exT = win;
-    uint32_t *exC = reinterpret_cast<uint32_t *>(win + L::EXT);
+    float *ring = reinterpret_cast<float *>(lds4);
+    float *ring_n = ring + 4 * L::ROW;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ch = wave >> 2, patch = wave & 3; // the four patches of a third land on the four SIMDs
-    const int tx = (patch << 4) | (lane & 15), ty = lane >> 4;
-    // XCD-aware tile order (see k_pairdist): each XCD gets one contiguous band of tiles, so the re-reads of a neighbour line by
-    // the 7 displacement rows of vertically adjacent tiles hit one L2
+    const int ty = wave & 3, hv = wave >> 2; // the two halves of a tile line land on the same SIMD
     int tile;
     {
         const int nt = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
         const int xcd = id & 7, k = id >> 3, q = nt >> 3, rem = nt & 7;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
     }
-    const int col0 = (tile % gridDim.x) * CS_TW, row0 = (tile / gridDim.x) * CS_TH;
-    const int c = col0 + tx, r = row0 + ty;
+    const int col0 = (tile % gridDim.x) * CS_TW, row0 = (tile / gridDim.x) * CS_TH; // row0 % 4 == 0: line g of the image lives in slot g & 3
+    const int c = col0 + lane, r = row0 + ty;
     const bool inside = (c < W) && (r < H);
     const size_t plane = (size_t)W * H;
     const size_t pix = (size_t)r * W + c;
 
-    float h1[NB];
+    float h1[D];
     float n1 = UNI ? uni_n : 1.f;
     {
-        const float4 *src = reinterpret_cast<const float4 *>(hist + (inside ? pix * D : 0) + ch * NB);
-        bool bad = false;
+        const float4 *src = reinterpret_cast<const float4 *>(hist + (inside ? pix * D : 0));
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             float4 v = inside ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
             h1[4 * q] = v.x; h1[4 * q + 1] = v.y; h1[4 * q + 2] = v.z; h1[4 * q + 3] = v.w;
         }
-        // every pixel of the image is the own pixel of exactly one tile: checking the own values covers the whole input
+        if (hv == 0) { // every pixel of the image is the own pixel of exactly one (line, half 0) wavefront: this covers the whole input
+            bool bad = false;
 #pragma unroll
-        for (int k = 0; k < NB; ++k) bad = bad || !(h1[k] >= 0.f && h1[k] <= CS_BIN_MAX);
-        if (inside) {
-            const float nv = ns[pix];
-            bad = bad || !(nv >= CS_N_MIN && nv <= CS_N_MAX);
-            if (UNI) { if (nv != uni_n) atomicOr(range_flag, 2); }
-            else n1 = nv;
+            for (int k = 0; k < D; ++k) bad = bad || !(h1[k] >= 0.f && h1[k] <= CS_BIN_MAX);
+            if (inside) {
+                const float nv = ns[pix];
+                bad = bad || !(nv >= CS_N_MIN && nv <= CS_N_MAX);
+                if (UNI && nv != uni_n) atomicOr(range_flag, 2);
+            }
+            if (bad) atomicOr(range_flag, 1);
         }
-        if (bad) atomicOr(range_flag, 1);
+        if (!UNI && inside) n1 = ns[pix];
     }
 
-    int didx = 0;
-    for (int dl = 0; dl <= b; ++dl)
-      for (int cbeg = (dl == 0) ? 0 : -b; cbeg <= b; cbeg += CS_ND) {
-        const int cend = min(b, cbeg + CS_CW), nc = cend - cbeg + 1;
-        __syncthreads(); // the combine step of the previous window has read the exchange area
-        // ---- stage lines row0+dl .. row0+dl+3, columns col0+cbeg .. col0+63+cend (whole pixels: D/4 float4 each)
-        {
-            const int wcols = CS_TW + (cend - cbeg);
-            const int npx = CS_TH * wcols;
-            for (int i = threadIdx.x; i < npx * (D / 4); i += CS_THREADS) {
-                const int p = i / (D / 4), q = i - p * (D / 4);
-                const int lr = p / wcols, lc = p - lr * wcols;
-                const int gr = row0 + dl + lr, gc = col0 + cbeg + lc;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gr < H && gc >= 0 && gc < W) v = reinterpret_cast<const float4 *>(hist)[((size_t)gr * W + gc) * (D / 4) + q];
-                *reinterpret_cast<float4 *>(win + lr * L::ROW + lc * D + 4 * q) = v;
-            }
-            if (!UNI)
-                for (int i = threadIdx.x; i < npx; i += CS_THREADS) {
-                    const int lr = i / wcols, lc = i - lr * wcols;
-                    const int gr = row0 + dl + lr, gc = col0 + cbeg + lc;
-                    win_n[lr * CS_NCOLS + lc] = (gr < H && gc >= 0 && gc < W) ? ns[(size_t)gr * W + gc] : 1.f;
-                }
+    // one image line (columns col0 + cbeg ...) -> registers / -> its ring slot
+    auto fetch_line = [&](float4 (&pre)[NPRE], float &pre_n, int g, int cbeg, int wcols) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int i = threadIdx.x + u * RW_THREADS;
+            const int lc = i / Q, q = i - lc * Q, gc = col0 + cbeg + lc;
+            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lc < wcols && g < H && gc >= 0 && gc < W) pre[u] = reinterpret_cast<const float4 *>(hist)[((size_t)g * W + gc) * Q + q];
+        }
+        if (!UNI) {
+            const int lc = threadIdx.x, gc = col0 + cbeg + lc;
+            pre_n = (lc < wcols && g < H && gc >= 0 && gc < W) ? ns[(size_t)g * W + gc] : 1.f;
+        }
+    };
+    auto store_line = [&](const float4 (&pre)[NPRE], float pre_n, int g, int wcols) __attribute__((always_inline)) {
+        float *dst = ring + (g & 3) * L::ROW;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int i = threadIdx.x + u * RW_THREADS;
+            if (i < wcols * Q) *reinterpret_cast<float4 *>(dst + 4 * i) = pre[u];
+        }
+        if (!UNI && (int)threadIdx.x < wcols) ring_n[(g & 3) * CS_NCOLS + threadIdx.x] = pre_n;
+    };
+
+    for (int cbeg = -b; cbeg <= b; cbeg += CS_ND) {
+        const int cend = min(b, cbeg + CS_CW), nc = cend - cbeg + 1, wcols = CS_TW + (cend - cbeg);
+        const int dl0 = cend >= 0 ? 0 : 1; // displacement line 0 only holds dc >= 0
+        float4 pre[NPRE];
+        float pre_n = 1.f;
+        __syncthreads(); // the previous pass is done with the ring
+        for (int g = row0 + dl0; g < row0 + dl0 + 4; ++g) {
+            fetch_line(pre, pre_n, g, cbeg, wcols);
+            store_line(pre, pre_n, g, wcols);
         }
         __syncthreads();
-
-        float Tp[CS_ND];
-        uint32_t Cp[4] = { 0u, 0u, 0u, 0u };
+        for (int dl = dl0; dl <= b; ++dl) {
+            // the line that enters the ring for dl + 1 travels while dl is evaluated
+            if (dl < b) fetch_line(pre, pre_n, row0 + dl + 4, cbeg, wcols);
+            const float *nrow = ring + ((ty + dl) & 3) * L::ROW;
+            const float *nrow_n = ring_n + ((ty + dl) & 3) * CS_NCOLS;
+            const int nr = r + dl;
+            // first displacement of this wavefront on this line (dl == 0 only holds dc >= 0)
+            const int j0 = (dl == 0 && cbeg < 0) ? -cbeg : 0;
+            int j = j0 + ((j0 ^ hv) & 1); // smallest j >= j0 of this wavefront's parity
+            // neighbour histograms are read PF float4 ahead of their use, across displacements: the LDS latency hides behind the
+            // arithmetic of the previous bins
+            constexpr int PF = 2;
+            float4 pf[PF];
+            {
+                const float *nb0 = nrow + (lane + min(j, nc - 1)) * D;
 #pragma unroll
-        for (int j = 0; j < CS_ND; ++j) {
-            Tp[j] = 0.f;
-            if (j < nc) {
-                const float *nb = win + ty * L::ROW + (tx + j) * D + ch * NB;
+                for (int u = 0; u < PF; ++u) pf[u] = *reinterpret_cast<const float4 *>(nb0 + 4 * u);
+            }
+            for (; j < nc; j += 2) {
+                const int dc = cbeg + j;
+                const float *nb = nrow + (lane + j) * D;
+                const float *nb_next = nrow + (lane + min(j + 2, nc - 1)) * D; // (a harmless re-read after the last displacement)
                 float n2 = 1.f, n12 = 1.f;
-                if (!UNI) { n2 = win_n[ty * CS_NCOLS + tx + j]; n12 = n1 * n2; }
+                if (!UNI) { n2 = nrow_n[lane + j]; n12 = n1 * n2; }
                 float sum = 0.f;
                 uint32_t cnt = 0;
-                float4 nbv[Q]; // the whole third of the neighbour's histogram first: Q ds_read_b128 in flight
-#pragma unroll
-                for (int q = 0; q < Q; ++q) nbv[q] = *reinterpret_cast<const float4 *>(nb + 4 * q);
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
-                    const float b2[4] = { nbv[q].x, nbv[q].y, nbv[q].z, nbv[q].w };
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    const float4 v = pf[q % PF];
+                    pf[q % PF] = (q + PF < Q) ? *reinterpret_cast<const float4 *>(nb + 4 * (q + PF)) : *reinterpret_cast<const float4 *>(nb_next + 4 * (q + PF - Q));
+                    const float b2[4] = { v.x, v.y, v.z, v.w };
+                    // one bin: DenoisingUnit.cpp:379-383 with the division replaced by rcp + fma (error bound in the header)
+                    auto term = [&](int e) __attribute__((always_inline)) {
                         const float b1 = h1[4 * q + e];
-                        const float s = b1 + b2[e];
-                        if (s > 1.f) { // DenoisingUnit.cpp:379 (exact); a bin that is empty for the whole wavefront is skipped (execz)
-                            asm volatile(""); // keep the branch: no if-conversion into selects
-                            if (UNI) {
-                                const float d = b1 - b2[e];
-                                sum = fmaf(d * d, __builtin_amdgcn_rcpf(s), sum);
-                            } else {
-                                const float d = n2 * b1 - n1 * b2[e];
-                                sum = fmaf(d * d, __builtin_amdgcn_rcpf(n12 * s), sum);
+                        if (UNI) { const float d = b1 - b2[e]; return d * d; }
+                        const float d = n2 * b1 - n1 * b2[e];
+                        return d * d;
+                    };
+                    auto den = [&](float s_) __attribute__((always_inline)) { return UNI ? s_ : n12 * s_; };
+                    // a wave-uniform branch per group of 4 bins (most groups are empty for all 64 pixels of a line segment), then a
+                    // divergent branch (execz) per bin: DenoisingUnit.cpp:379 decides exactly which bins count
+                    float sg[4];
+                    bool any = false;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sg[e] = h1[4 * q + e] + b2[e]; any = any || sg[e] > 1.f; }
+                    if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (sg[e] > 1.f) {
+                                asm volatile(""); // keep the branch: no if-conversion into selects
+                                sum = fmaf(term(e), __builtin_amdgcn_rcpf(den(sg[e])), sum);
+                                ++cnt;
                             }
-                            ++cnt;
-                        }
                     }
                 }
-                Tp[j] = sum;
-                Cp[j >> 2] |= cnt << (8 * (j & 3));
+                if (Q % PF != 0) { // the ring of read-ahead registers restarts at slot 0 for the next displacement
+                    float4 t[PF];
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) t[u] = pf[(u + Q) % PF];
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) pf[u] = t[u];
+                }
+                const int nc_ = c + dc;
+                if (inside && nc_ >= 0 && nc_ < W && nr < H) {
+                    const size_t o = (size_t)bcd_delta_index(dl, dc, b) * plane + pix;
+                    T[o] = sum;
+                    Cn[o] = (uint8_t)cnt;
+                }
+            }
+            if (dl < b) {
+                __syncthreads(); // line row0 + dl is not needed any more (nor is any other slot being replaced)
+                store_line(pre, pre_n, row0 + dl + 4, wcols);
+                __syncthreads();
             }
         }
-        __syncthreads(); // every wavefront is done with the window: it becomes the exchange area
-        {
-            const int slot = (patch << 6) | lane;
-#pragma unroll
-            for (int j = 0; j < CS_ND; ++j)
-                if (j < nc) exT[(ch * CS_ND + j) * 256 + slot] = Tp[j];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) exC[(ch * 4 + q) * 256 + slot] = Cp[q];
-        }
-        __syncthreads();
-        // ---- combine the three thirds; a wavefront stores whole tile lines (64 consecutive pixels of a plane)
-        for (int job = wave; job < nc * CS_TH; job += CS_WAVES) {
-            const int j = job >> 2, line = job & 3;
-            const int slot = ((lane >> 4) << 6) | (line << 4) | (lane & 15); // pixel (line, column = lane) of the tile
-            const float t = (exT[(0 * CS_ND + j) * 256 + slot] + exT[(1 * CS_ND + j) * 256 + slot]) + exT[(2 * CS_ND + j) * 256 + slot];
-            const uint32_t sh = 8 * (j & 3);
-            const uint32_t cn = ((exC[(0 * 4 + (j >> 2)) * 256 + slot] >> sh) & 255u) + ((exC[(1 * 4 + (j >> 2)) * 256 + slot] >> sh) & 255u) +
-                                ((exC[(2 * 4 + (j >> 2)) * 256 + slot] >> sh) & 255u);
-            const int oc = col0 + lane, orow = row0 + line;
-            const int qc = oc + cbeg + j, qr = orow + dl;
-            if (oc < W && orow < H && qc >= 0 && qc < W && qr < H) {
-                const size_t o = (size_t)(didx + j) * plane + (size_t)orow * W + oc;
-                T[o] = t;
-                Cn[o] = (uint8_t)cn;
-            }
-        }
-        didx += nc;
-      }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -280,45 +303,37 @@ __global__ __launch_bounds__(256) void k_max_rel_dev(const float *__restrict__ T
 
 } // namespace
 
-size_t bcd_pairdist_cs_lds_bytes(int D)
-{
-    switch (D) {
-    case 60: return (size_t)CsLayout<60>::LDS_DWORDS * 4;
-    case 36: return (size_t)CsLayout<36>::LDS_DWORDS * 4;
-    case 24: return (size_t)CsLayout<24>::LDS_DWORDS * 4;
-    default: return 0;
-    }
-}
-
 // 1 if the fast (approximate + verify) path has a kernel for this histogram depth
 int bcd_pairdist_cs_supported(int D) { return D == 60 || D == 36 || D == 24; }
 
 hipError_t bcd_launch_pairdist_cs(const float *hist, const float *ns, int W, int H, int D, int b, float *T, uint8_t *Cn, int *d_range_flag,
                                   float uni_n, hipStream_t st)
 {
-    dim3 grid((W + CS_TW - 1) / CS_TW, (H + CS_TH - 1) / CS_TH), block(CS_THREADS);
-    const size_t lds = bcd_pairdist_cs_lds_bytes(D);
+    dim3 grid((W + CS_TW - 1) / CS_TW, (H + CS_TH - 1) / CS_TH), block(RW_THREADS);
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-#define BCD_CS_LAUNCH(DD, UU)                                                                                        \
+#define BCD_RW_LAUNCH(DD, UU)                                                                                        \
     {                                                                                                                \
-        static std::atomic<int> granted[64];                                                                         \
+        const size_t lds = (size_t)RwLayout<DD>::LDS_DWORDS * 4;                                                     \
+        static std::atomic<int> granted[64]; /* per instantiation and device */                                     \
         if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || granted[dev].load() == 0)) {                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist_cs<DD, UU>),               \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist_rw<DD, UU>),               \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) return e;                                                                           \
             if (dev >= 0 && dev < 64) granted[dev].store(1);                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_pairdist_cs<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, T, Cn, d_range_flag, uni_n); \
+        hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, T, Cn, d_range_flag, uni_n); \
         return hipGetLastError();                                                                                    \
     }
+#define BCD_RW_DEPTH(DD) case DD: if (uni_n > 0.f) BCD_RW_LAUNCH(DD, true) else BCD_RW_LAUNCH(DD, false)
     switch (D) {
-    case 60: if (uni_n > 0.f) BCD_CS_LAUNCH(60, true) else BCD_CS_LAUNCH(60, false)
-    case 36: if (uni_n > 0.f) BCD_CS_LAUNCH(36, true) else BCD_CS_LAUNCH(36, false)
-    case 24: if (uni_n > 0.f) BCD_CS_LAUNCH(24, true) else BCD_CS_LAUNCH(24, false)
+    BCD_RW_DEPTH(60)
+    BCD_RW_DEPTH(36)
+    BCD_RW_DEPTH(24)
     default: break;
     }
-#undef BCD_CS_LAUNCH
+#undef BCD_RW_DEPTH
+#undef BCD_RW_LAUNCH
     return hipErrorInvalidValue;
 }
 

@@ -201,7 +201,7 @@ def main():
     fast = all(sc["borderline_pairs"] is not None for sc in scales)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
-                "kernel": "k_pairdist_cs<60> (approximate planes; borderline pairs re-evaluated exactly by k_verify_pairs)" if fast else "k_pairdist<60>",
+                "kernel": "k_pairdist_rw<60> (approximate planes; borderline pairs re-evaluated exactly by k_verify_pairs)" if fast else "k_pairdist<60>",
                 "launches": pd_launches,
                 "avg_launch_ms": round(pd_ms / max(1, pd_launches), 4),
                 "whole_process": {"launches": all_launches, "avg_launch_ms": round(all_ms / max(1, all_launches), 4),

@@ -17,7 +17,24 @@ def main():
     import bcd_amd.core as core
     import bcd_amd.hip as bh
     ctx = bh.Context(0)
-    sizes = [(1280, 720), (1920, 1080), (640, 360), (320, 180)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+    quick = "--quick" in sys.argv
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    sizes = [(1280, 720), (1920, 1080), (640, 360), (320, 180)] if not args else [tuple(int(v) for v in a.split("x")) for a in args]
+    if quick:
+        # fast path only, one size: for sweeps over BCD_CS_MODE and for counter passes
+        W, H = sizes[0] if args else (1280, 720)
+        for sigma, spikes in ((0.35, 0.01), (0.10, 0.0)):
+            col, ns, hist, cov = core.synthetic_scene(W, H, 32, 1234, sigma, spikes)
+            d_hist, d_ns = torch.from_numpy(hist).cuda(), torch.from_numpy(ns).cuda()
+            for _ in range(2):
+                ctx.similarity_masks(d_hist, d_ns, 1, 6, 1.0)
+            torch.cuda.synchronize()
+            ctx.reset_kernel_time()
+            for _ in range(5):
+                ctx.similarity_masks(d_hist, d_ns, 1, 6, 1.0)
+            kms, kn = ctx.kernel_time()
+            print("mode %s sigma %.2f %dx%d pairdist %.3f ms" % (os.environ.get("BCD_CS_MODE", "default"), sigma, W, H, kms / max(1, kn)), flush=True)
+        return
     for sigma, spikes in ((0.35, 0.01), (0.10, 0.0)):
         for (W, H) in sizes:
             col, ns, hist, cov = core.synthetic_scene(W, H, 32, 1234, sigma, spikes)
