@@ -5,6 +5,7 @@
 #include "bcd_common.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -76,6 +77,7 @@ struct Work {
     int rounds_hint = 0;           // marking launches the last problem needed
     bool dep_ready = false;        // dependency lists of the current marking problem are in `dep` (reset by active_init)
     int32_t *h_counters = nullptr; // pinned
+    bool initialised = false;      // set once every stream / event / pinned buffer below exists
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; // pair-distance kernel timing
     int ev_used = 0;
     hipEvent_t ev_stage[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -111,6 +113,25 @@ void set_err(bcd_hip_ctx *ctx, const std::string &msg)
     std::lock_guard<std::mutex> lock(ctx->err_mutex);
     ctx->err = msg;
 }
+
+// every entry point that allocates or launches runs on the context's device and leaves the caller's current device as it was
+struct DeviceGuard {
+    int prev = -1, dev;
+    bool ok = true;
+    explicit DeviceGuard(const bcd_hip_ctx *ctx) : dev(ctx ? ctx->device : -1)
+    {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+#define DEVICE_GUARD(ctx)                                                                                             \
+    DeviceGuard guard__(ctx);                                                                                         \
+    if (!guard__.ok) { set_err((ctx), "hipSetDevice failed"); return BCD_HIP_EDEVICE; }
 
 #define HIPCHK(ctx, expr)                                                                                             \
     do {                                                                                                              \
@@ -300,15 +321,17 @@ int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t
     wk.dep_ready = false;
     int rounds = 0;
     if (skip_prob > 0.f) {
-        const int max_rounds = 4 * (W + H) + 64;
-        int undecided = 1;
-        while (undecided != 0 && rounds < max_rounds) {
+        // every launch decides at least the earliest undecided pixel of the visiting order, so the iteration ends after at most
+        // (number of main pixels) launches; stop only when a whole batch makes no progress (which would be an engine bug)
+        int undecided = 1, before = INT_MAX;
+        while (undecided != 0) {
             int n = 0;
             RCCHK(active_step(ctx, wk, d_mask, d_nsim, W, H, w, b, row_begin, row_end, random_order, seed, 0, rounds == 0 && skip_prob >= 1.f,
                               d_state, &undecided, &n));
             rounds += n;
+            if (undecided != 0 && undecided >= before) { set_err(ctx, "marking fixed point made no progress"); return BCD_HIP_EDEVICE; }
+            before = undecided;
         }
-        if (undecided != 0) { set_err(ctx, "marking fixed point did not converge"); return BCD_HIP_EDEVICE; }
         wk.rounds_hint = rounds;
     }
     if (rounds_out) *rounds_out = rounds;
@@ -449,7 +472,8 @@ int mono(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_ns, c
 
 int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
 {
-    if (w.h_counters) return BCD_HIP_OK; // already initialised
+    if (w.initialised) return BCD_HIP_OK;
+    if (w.h_counters || w.aux || w.ev_done) return bad(ctx, "workspace left half-initialised by an earlier failure"); // never run on null handles
     if (stream) w.stream = stream;
     else {
         HIPCHK(ctx, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
@@ -462,6 +486,7 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
     HIPCHK(ctx, hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+    w.initialised = true;
     return BCD_HIP_OK;
 }
 
@@ -510,10 +535,11 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0 || device < 0 || device >= n) return BCD_HIP_EDEVICE;
-    if (hipSetDevice(device) != hipSuccess) return BCD_HIP_EDEVICE;
     bcd_hip_ctx *ctx = new (std::nothrow) bcd_hip_ctx();
     if (!ctx) return BCD_HIP_ENOMEM;
     ctx->device = device;
+    DeviceGuard guard(ctx);
+    if (!guard.ok) { delete ctx; return BCD_HIP_EDEVICE; }
     memset(ctx->stats, 0, sizeof(ctx->stats));
     if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
     else {
@@ -539,7 +565,7 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
 void bcd_hip_ctx_destroy(bcd_hip_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx);
     (void)hipDeviceSynchronize();
     work_destroy(ctx->main);
     for (int s = 0; s < MAX_SCALES; ++s) work_destroy(ctx->extra[s]);
@@ -585,7 +611,7 @@ int bcd_hip_kernel_time(const bcd_hip_ctx *cctx, float *ms_pairdist, int32_t *la
 {
     bcd_hip_ctx *ctx = const_cast<bcd_hip_ctx *>(cctx);
     if (!ctx) return BCD_HIP_EINVAL;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, hipDeviceSynchronize());
     float tot = 0.f;
     int count = 0;
@@ -607,7 +633,7 @@ int bcd_hip_kernel_time(const bcd_hip_ctx *cctx, float *ms_pairdist, int32_t *la
 int bcd_hip_reset_kernel_time(bcd_hip_ctx *ctx)
 {
     if (!ctx) return BCD_HIP_EINVAL;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, hipDeviceSynchronize());
     ctx->main.ev_used = 0;
     for (int s = 0; s < MAX_SCALES; ++s) ctx->extra[s].ev_used = 0;
@@ -621,7 +647,7 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
     if (!d_colors || !d_ns || !d_hist || !d_cov || !d_out) return bad(ctx, "null image pointer"); // Denoiser.cpp:266-293
     RCCHK(check_params(ctx, W, H, D, prm));
     if (nb_scales < 1 || nb_scales > MAX_SCALES) return bad(ctx, "bad number of scales");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DEVICE_GUARD(ctx);
     if (nb_scales == 1) return mono(ctx, ctx->main, d_colors, d_ns, d_hist, d_cov, W, H, D, prm, bcd_hip_scale_seed(prm->order_seed, 0), 0, d_out);
 
     // ---- pyramids (MultiscaleDenoiser.cpp:41-53): level s has dims of level s-1 // 2
@@ -713,7 +739,7 @@ int bcd_hip_denoise_band(bcd_hip_ctx *ctx, const float *d_colors, const float *d
     if (!d_colors || !d_ns || !d_hist || !d_cov || !d_sum || !d_count) return bad(ctx, "null image pointer");
     RCCHK(check_params(ctx, W, H, D, prm));
     if (main_row_begin < 0 || main_row_end > H || main_row_begin > main_row_end) return bad(ctx, "bad main row range");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DEVICE_GUARD(ctx);
     return mono_accumulate(ctx, ctx->main, d_colors, d_ns, d_hist, d_cov, W, H, D, main_row_begin, main_row_end, prm, order_seed, 0, d_sum, d_count);
 }
 
@@ -727,7 +753,7 @@ int bcd_hip_denoise_bands(bcd_hip_ctx *ctx, const bcd_hip_band_job *jobs, int nj
         RCCHK(check_params(ctx, j.W, j.H, j.D, prm));
         if (j.main_row_begin < 0 || j.main_row_end > j.H || j.main_row_begin > j.main_row_end) return bad(ctx, "bad main row range");
     }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DEVICE_GUARD(ctx);
     if (!ctx->concurrent_scales || njobs == 1) {
         for (int i = 0; i < njobs; ++i) {
             const bcd_hip_band_job &j = jobs[i];
@@ -765,7 +791,7 @@ int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h
     if (!ctx) return BCD_HIP_EINVAL;
     if (!h_colors || !h_ns || !h_hist || !h_cov || !h_out) return bad(ctx, "null image pointer");
     RCCHK(check_params(ctx, W, H, D, prm));
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DEVICE_GUARD(ctx);
     const size_t np = (size_t)W * H;
     float *d[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     const size_t sz[5] = { np * 3, np, np * D, np * 6, np * 3 };
@@ -786,6 +812,7 @@ int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h
 int bcd_hip_pixel_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_ns, int W, int H, float *d_out)
 {
     if (!ctx || !d_cov || !d_ns || !d_out || W <= 0 || H <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)W * H, d_out, ctx->stream));
     return BCD_HIP_OK;
 }
@@ -794,6 +821,7 @@ int bcd_hip_similarity_masks(bcd_hip_ctx *ctx, const float *d_hist, const float 
                              uint32_t *d_mask, int32_t *d_count)
 {
     if (!ctx || !d_hist || !d_ns || !d_mask || !d_count) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     bcd_hip_params p; bcd_hip_default_params(&p); p.patch_radius = w; p.search_radius = b;
     RCCHK(check_params(ctx, W, H, D, &p));
     return similarity(ctx, ctx->main, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count);
@@ -803,6 +831,7 @@ int bcd_hip_window_distances(bcd_hip_ctx *ctx, const float *d_hist, const float 
                              int line, int col, float *h_out)
 {
     if (!ctx || !d_hist || !d_ns || !h_out) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     bcd_hip_params p; bcd_hip_default_params(&p); p.patch_radius = w; p.search_radius = b;
     RCCHK(check_params(ctx, W, H, D, &p));
     if (line < w || line > H - 1 - w || col < w || col > W - 1 - w) return bad(ctx, "not a main pixel");
@@ -823,6 +852,7 @@ int bcd_hip_active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *
                        uint8_t *d_state, int32_t *rounds)
 {
     if (!ctx || !d_mask || !d_count || !d_state) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     return active_set(ctx, ctx->main, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, skip_probability, random_order, seed, d_state, rounds);
 }
 
@@ -830,6 +860,7 @@ int bcd_hip_active_init(bcd_hip_ctx *ctx, const int32_t *d_count, int W, int H, 
                         float skip_probability, uint32_t seed, int row_offset, uint8_t *d_state)
 {
     if (!ctx || !d_count || !d_state || W <= 0 || H <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, bcd_launch_active_init(d_count, W, H, w, main_row_begin, main_row_end, skip_probability, seed, row_offset, d_state, ctx->stream));
     ctx->main.dep_ready = false;
     return BCD_HIP_OK;
@@ -839,6 +870,7 @@ int bcd_hip_active_step(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t 
                         int main_row_end, int random_order, uint32_t seed, int row_offset, int first_pass, uint8_t *d_state, int32_t *undecided)
 {
     if (!ctx || !d_mask || !d_count || !d_state || !undecided) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     int u = 0;
     ctx->main.dep_ready = false; // stateless entry point: the dependency lists are rebuilt from (mask, count, state) on every call
     RCCHK(active_step(ctx, ctx->main, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, random_order, seed, row_offset, first_pass != 0,
@@ -852,12 +884,14 @@ int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const floa
                              float *d_sum, int32_t *d_count)
 {
     if (!ctx || !d_colors || !d_pixcov || !d_mask || !d_nsim || !d_state || !d_sum || !d_count) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     return bayes(ctx, ctx->main, d_colors, d_pixcov, d_mask, d_nsim, d_state, W, H, w, b, min_eig, d_sum, d_count);
 }
 
 int bcd_hip_finalize(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int64_t npix, float *d_out)
 {
     if (!ctx || !d_sum || !d_count || !d_out || npix <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, npix, d_out, ctx->stream));
     return BCD_HIP_OK;
 }
@@ -866,6 +900,7 @@ int bcd_hip_finalize_band(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d
                           const int32_t *d_up_count, const float *d_down_sum, const int32_t *d_down_count, float *d_out)
 {
     if (!ctx || !d_sum || !d_count || !d_out || W <= 0 || rows <= 0 || halo < 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     if ((d_up_sum == nullptr) != (d_up_count == nullptr) || (d_down_sum == nullptr) != (d_down_count == nullptr)) return bad(ctx, "halo sum without count");
     if ((d_up_sum || d_down_sum) && halo > rows) return bad(ctx, "halo larger than the band");
     HIPCHK(ctx, bcd_launch_finalize_band(d_sum, d_count, W, rows, halo, d_up_sum, d_up_count, d_down_sum, d_down_count, d_out, ctx->stream));
@@ -875,6 +910,7 @@ int bcd_hip_finalize_band(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d
 int bcd_hip_downscale_sum(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int D, float *d_out)
 {
     if (!ctx || !d_in || !d_out || W < 2 || H < 2 || D <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, bcd_launch_downscale(0, d_in, W, H, D, d_out, ctx->stream));
     return BCD_HIP_OK;
 }
@@ -882,6 +918,7 @@ int bcd_hip_downscale_sum(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int
 int bcd_hip_downscale_avg(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int D, float *d_out)
 {
     if (!ctx || !d_in || !d_out || W < 2 || H < 2 || D <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, bcd_launch_downscale(1, d_in, W, H, D, d_out, ctx->stream));
     return BCD_HIP_OK;
 }
@@ -889,6 +926,7 @@ int bcd_hip_downscale_avg(bcd_hip_ctx *ctx, const float *d_in, int W, int H, int
 int bcd_hip_downscale_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_ns, int W, int H, float *d_out)
 {
     if (!ctx || !d_cov || !d_ns || !d_out || W < 2 || H < 2) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, bcd_launch_downscale_cov(d_cov, d_ns, W, H, d_out, ctx->stream));
     return BCD_HIP_OK;
 }
@@ -896,6 +934,7 @@ int bcd_hip_downscale_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_n
 int bcd_hip_interpolate(bcd_hip_ctx *ctx, const float *d_lo, int w, int h, int D, float *d_hi, int W, int H)
 {
     if (!ctx || !d_lo || !d_hi || w != W / 2 || h != H / 2 || w <= 0 || h <= 0 || D <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, bcd_launch_interpolate(0, d_lo, w, h, D, d_hi, W, H, ctx->stream));
     return BCD_HIP_OK;
 }
@@ -903,6 +942,7 @@ int bcd_hip_interpolate(bcd_hip_ctx *ctx, const float *d_lo, int w, int h, int D
 int bcd_hip_merge(bcd_hip_ctx *ctx, float *d_hi, int W, int H, const float *d_lo, int D)
 {
     if (!ctx || !d_hi || !d_lo || W < 2 || H < 2 || D <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     return merge_on(ctx, ctx->main, d_hi, W, H, d_lo, D);
 }
 
@@ -910,6 +950,7 @@ int bcd_hip_spike_filter(bcd_hip_ctx *ctx, const float *d_col, const float *d_ns
                          int D, float factor, float *o_col, float *o_ns, float *o_hist, float *o_cov)
 {
     if (!ctx || !d_col || !d_ns || !d_hist || !d_cov || !o_col || !o_ns || !o_hist || !o_cov) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     if (W < 3 || H < 3 || D <= 0) return bad(ctx, "image smaller than 3x3");
     HIPCHK(ctx, bcd_launch_spike(d_col, d_ns, d_hist, d_cov, W, H, D, factor, o_col, o_ns, o_hist, o_cov, ctx->stream));
     return BCD_HIP_OK;
@@ -919,6 +960,7 @@ int bcd_hip_accumulate_samples(bcd_hip_ctx *ctx, const float *d_samples, const f
                                float gamma, float max_value, float *d_nsamples, float *d_mean, float *d_cov, float *d_hist)
 {
     if (!ctx || !d_samples || !d_nsamples || !d_mean || !d_cov || !d_hist) return bad(ctx, "null pointer");
+    DEVICE_GUARD(ctx);
     if (W <= 0 || H <= 0 || spp <= 0 || nb_bins < 3) return bad(ctx, "bad size");
     if ((size_t)3 * nb_bins * 64 * sizeof(float) > 160 * 1024) { set_err(ctx, "more than 213 bins per channel are not supported"); return BCD_HIP_EUNSUPPORTED; }
     HIPCHK(ctx, bcd_launch_accumulate_samples(d_samples, d_weights, (int64_t)W * H, spp, nb_bins, gamma, max_value, d_nsamples, d_mean, d_cov, d_hist, ctx->stream));
@@ -928,6 +970,7 @@ int bcd_hip_accumulate_samples(bcd_hip_ctx *ctx, const float *d_samples, const f
 int bcd_hip_zero_bad_values(bcd_hip_ctx *ctx, float *d_img, int64_t n)
 {
     if (!ctx || !d_img || n <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     HIPCHK(ctx, bcd_launch_zero_bad(d_img, n, ctx->stream));
     return BCD_HIP_OK;
 }
@@ -936,6 +979,7 @@ int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, con
                                       int *variant, int64_t *mismatches)
 {
     if (!ctx || !d_hist || !d_ns || !mismatches || W <= 0 || H <= 0 || D <= 0 || search_radius < 1) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     Work &wk = ctx->main;
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
@@ -988,6 +1032,7 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
                                      float *max_rel_dev, int64_t *count_mismatches, int *flags)
 {
     if (!ctx || !d_hist || !d_ns || !max_rel_dev || !count_mismatches || W <= 0 || H <= 0 || search_radius < 1) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     if (!bcd_pairdist_cs_supported(D)) { set_err(ctx, "no approximate kernel for this histogram depth"); return BCD_HIP_EUNSUPPORTED; }
     Work &wk = ctx->main;
     const size_t npix = (size_t)W * H;
@@ -1040,6 +1085,7 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
 int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, int64_t *mismatches)
 {
     if (!ctx || !mismatches || samples <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
     RCCHK(ensure(ctx, ctx->main.counters, 64 * sizeof(int32_t)));
     unsigned long long *d = reinterpret_cast<unsigned long long *>((int32_t *)ctx->main.counters.p + 32);
     HIPCHK(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <iostream>
 #include <map>
+#include <new>
+#include <stdexcept>
 
 using namespace std;
 
@@ -29,7 +31,7 @@ namespace bcd
 		}
 
 		enum PixelType { e_uint = 0, e_half = 1, e_float = 2 };
-		enum Compression { e_none = 0, e_rle = 1, e_zips = 2, e_zip = 3 };
+		enum Compression { e_none = 0, e_rle = 1, e_zips = 2, e_zip = 3, e_piz = 4 };
 
 		struct Channel
 		{
@@ -138,6 +140,296 @@ namespace bcd
 			return out.size() == expected;
 		}
 
+		// ---- PIZ (read only): per chunk of 32 scanlines  [u16 minNonZero][u16 maxNonZero][bitmap bytes min..max][i32 length][Huffman data];
+		// the 16-bit words of every channel are mapped through a lookup table of the values in use, Haar-wavelet transformed in
+		// place and Huffman coded with a run-length pseudo symbol (the published OpenEXR PIZ scheme).  The reference writes its
+		// colour images through Imf::RgbaOutputFile (src/io/exr/io_exr.cpp:147-164), whose default compression is PIZ.
+		namespace piz
+		{
+			const int c_encBits = 16, c_encSize = (1 << c_encBits) + 1;
+			const int c_shortZeroRun = 59, c_longZeroRun = 63, c_shortestLongRun = 2 + c_longZeroRun - c_shortZeroRun;
+			const int c_maxCodeLength = 58;
+
+			struct BitReader
+			{
+				const unsigned char* p;
+				const unsigned char* end;
+				uint64_t acc;
+				int nb;
+				bool ok;
+				BitReader(const unsigned char* b, const unsigned char* e) : p(b), end(e), acc(0), nb(0), ok(true) {}
+				uint32_t get(int n) // MSB first, n <= 32
+				{
+					while(nb < n)
+					{
+						if(p >= end) { ok = false; return 0; }
+						acc = (acc << 8) | *p++;
+						nb += 8;
+					}
+					nb -= n;
+					return uint32_t((acc >> nb) & ((uint64_t(1) << n) - 1));
+				}
+			};
+
+			/// canonical prefix code defined by the code lengths: the longest codes start at 0, codes of equal length follow the symbol order
+			struct Decoder
+			{
+				uint64_t first[c_maxCodeLength + 2]; // first code of each length
+				uint32_t count[c_maxCodeLength + 2];
+				uint32_t offset[c_maxCodeLength + 2]; // into `symbols`
+				vector<uint32_t> symbols;             // sorted by (length, symbol)
+				vector<uint32_t> fast;                // 12-bit prefix -> (symbol << 6 | length), 0 = longer code
+				bool build(const vector<unsigned char>& lengths)
+				{
+					memset(count, 0, sizeof(count));
+					for(unsigned char l : lengths) { if(l > c_maxCodeLength) return false; ++count[l]; }
+					uint64_t c = 0;
+					for(int l = c_maxCodeLength; l >= 1; --l)
+					{
+						const uint64_t nc = (c + count[l]) >> 1;
+						first[l] = c;
+						c = nc;
+					}
+					uint32_t o = 0;
+					for(int l = 1; l <= c_maxCodeLength; ++l) { offset[l] = o; o += count[l]; }
+					symbols.assign(o, 0);
+					vector<uint32_t> fill(offset, offset + c_maxCodeLength + 2);
+					for(size_t sym = 0; sym < lengths.size(); ++sym)
+						if(lengths[sym]) symbols[fill[lengths[sym]]++] = uint32_t(sym);
+					fast.assign(1 << 12, 0);
+					for(int l = 1; l <= 12; ++l)
+						for(uint32_t k = 0; k < count[l]; ++k)
+						{
+							const uint64_t code = first[l] + k;
+							if(code >> l) return false; // lengths that are no prefix code
+							const uint32_t entry = (symbols[offset[l] + k] << 6) | uint32_t(l);
+							for(uint32_t pad = 0; pad < (1u << (12 - l)); ++pad) fast[(size_t(code) << (12 - l)) | pad] = entry;
+						}
+					return true;
+				}
+			};
+
+			bool huffmanDecode(const unsigned char* in, size_t inSize, vector<uint16_t>& out, size_t nbOfValues)
+			{
+				out.assign(nbOfValues, 0);
+				if(inSize == 0) return nbOfValues == 0;
+				if(inSize < 20) return false;
+				uint32_t im, iM, nBits;
+				memcpy(&im, in, 4); memcpy(&iM, in + 4, 4); memcpy(&nBits, in + 12, 4);
+				if(im >= uint32_t(c_encSize) || iM >= uint32_t(c_encSize) || im > iM) return false;
+				// packed table of code lengths (6 bits each, with zero-run escapes)
+				vector<unsigned char> lengths(c_encSize, 0);
+				BitReader tr(in + 20, in + inSize);
+				for(uint32_t i = im; i <= iM; ++i)
+				{
+					const uint32_t l = tr.get(6);
+					if(!tr.ok) return false;
+					if(l == uint32_t(c_longZeroRun) || l >= uint32_t(c_shortZeroRun))
+					{
+						uint32_t run = l == uint32_t(c_longZeroRun) ? tr.get(8) + c_shortestLongRun : l - c_shortZeroRun + 2;
+						if(!tr.ok || i + run > iM + 1) return false;
+						i += run - 1; // (those lengths stay 0)
+					}
+					else
+						lengths[i] = (unsigned char)l;
+				}
+				const unsigned char* data = tr.p; // the table is padded to a whole byte
+				if(uint64_t(nBits) > uint64_t(in + inSize - data) * 8) return false;
+				Decoder dec;
+				if(!dec.build(lengths)) return false;
+				BitReader br(data, in + inSize);
+				uint64_t remaining = nBits;
+				size_t o = 0;
+				while(remaining > 0)
+				{
+					uint32_t sym = 0;
+					int len = 0;
+					// fast path: the next 12 bits (zero-extended at the end of the stream) select short codes directly
+					const int peek = int(min<uint64_t>(12, remaining));
+					while(br.nb < peek)
+					{
+						if(br.p >= br.end) return false;
+						br.acc = (br.acc << 8) | *br.p++;
+						br.nb += 8;
+					}
+					const uint32_t window = uint32_t((br.acc >> (br.nb - peek)) & ((1u << peek) - 1)) << (12 - peek);
+					const uint32_t e = dec.fast[window];
+					if(e && int(e & 63) <= peek)
+					{
+						len = int(e & 63);
+						sym = e >> 6;
+						br.nb -= len;
+					}
+					else
+					{
+						uint64_t code = 0;
+						bool found = false;
+						while(len < c_maxCodeLength && uint64_t(len) < remaining)
+						{
+							code = (code << 1) | br.get(1);
+							if(!br.ok) return false;
+							++len;
+							if(dec.count[len] && code >= dec.first[len] && code - dec.first[len] < dec.count[len])
+							{
+								sym = dec.symbols[dec.offset[len] + uint32_t(code - dec.first[len])];
+								found = true;
+								break;
+							}
+						}
+						if(!found) return false;
+					}
+					remaining -= uint64_t(len);
+					if(sym == iM)
+					{	// run-length pseudo symbol: repeat the previous value
+						if(remaining < 8 || o == 0) return false;
+						uint32_t run = br.get(8);
+						if(!br.ok) return false;
+						remaining -= 8;
+						if(o + run > nbOfValues) return false;
+						const uint16_t v = out[o - 1];
+						while(run--) out[o++] = v;
+					}
+					else
+					{
+						if(o >= nbOfValues || sym > 0xffffu) return false;
+						out[o++] = uint16_t(sym);
+					}
+				}
+				return o == nbOfValues;
+			}
+
+			inline void wdec14(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b)
+			{
+				const int ls = int16_t(l), hs = int16_t(h);
+				const int ai = ls + (hs & 1) + (hs >> 1);
+				a = uint16_t(int16_t(ai));
+				b = uint16_t(int16_t(ai - hs));
+			}
+
+			inline void wdec16(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b)
+			{
+				const int m = l, d = h;
+				const int bb = (m - (d >> 1)) & 0xffff;
+				const int aa = (d + bb - 0x8000) & 0xffff;
+				b = uint16_t(bb);
+				a = uint16_t(aa);
+			}
+
+			/// inverse 2-D Haar-like wavelet on nx x ny values with strides ox / oy (in uint16 units)
+			void waveletDecode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx)
+			{
+				const bool w14 = mx < (1 << 14);
+				const int n = nx > ny ? ny : nx;
+				int p = 1, p2;
+				while(p <= n) p <<= 1;
+				p >>= 1;
+				p2 = p;
+				p >>= 1;
+				while(p >= 1)
+				{
+					uint16_t* py = in;
+					uint16_t* ey = in + ptrdiff_t(oy) * (ny - p2);
+					const ptrdiff_t oy1 = ptrdiff_t(oy) * p, oy2 = ptrdiff_t(oy) * p2, ox1 = ptrdiff_t(ox) * p, ox2 = ptrdiff_t(ox) * p2;
+					uint16_t i00, i01, i10, i11;
+					for(; py <= ey; py += oy2)
+					{
+						uint16_t* px = py;
+						uint16_t* ex = py + ptrdiff_t(ox) * (nx - p2);
+						for(; px <= ex; px += ox2)
+						{
+							uint16_t* p01 = px + ox1;
+							uint16_t* p10 = px + oy1;
+							uint16_t* p11 = p10 + ox1;
+							if(w14)
+							{
+								wdec14(*px, *p10, i00, i10); wdec14(*p01, *p11, i01, i11);
+								wdec14(i00, i01, *px, *p01); wdec14(i10, i11, *p10, *p11);
+							}
+							else
+							{
+								wdec16(*px, *p10, i00, i10); wdec16(*p01, *p11, i01, i11);
+								wdec16(i00, i01, *px, *p01); wdec16(i10, i11, *p10, *p11);
+							}
+						}
+						if(nx & p)
+						{
+							uint16_t* p10 = px + oy1;
+							if(w14) wdec14(*px, *p10, i00, *p10); else wdec16(*px, *p10, i00, *p10);
+							*px = i00;
+						}
+					}
+					if(ny & p)
+					{
+						uint16_t* px = py;
+						uint16_t* ex = py + ptrdiff_t(ox) * (nx - p2);
+						for(; px <= ex; px += ox2)
+						{
+							uint16_t* p01 = px + ox1;
+							if(w14) wdec14(*px, *p01, i00, *p01); else wdec16(*px, *p01, i00, *p01);
+							*px = i00;
+						}
+					}
+					p2 = p;
+					p >>= 1;
+				}
+			}
+
+			/// one chunk: `lines` scanlines of W pixels; channelWords[c] = 16-bit words per pixel (1 half, 2 float / uint).  out = the chunk
+			/// in the uncompressed scanline layout.
+			bool decodeChunk(const unsigned char* src, size_t size, int W, int lines, const vector<int>& channelWords, vector<unsigned char>& out)
+			{
+				if(size < 4) return false;
+				uint16_t minNonZero, maxNonZero;
+				memcpy(&minNonZero, src, 2); memcpy(&maxNonZero, src + 2, 2);
+				const int bitmapSize = 8192;
+				if(maxNonZero >= bitmapSize) return false;
+				vector<unsigned char> bitmap(bitmapSize, 0);
+				size_t pos = 4;
+				if(minNonZero <= maxNonZero)
+				{
+					const size_t n = size_t(maxNonZero) - minNonZero + 1;
+					if(pos + n > size) return false;
+					memcpy(&bitmap[minNonZero], src + pos, n);
+					pos += n;
+				}
+				vector<uint16_t> lut(1 << 16, 0);
+				int k = 0;
+				for(int i = 0; i < (1 << 16); ++i)
+					if(i == 0 || (bitmap[i >> 3] & (1 << (i & 7)))) lut[k++] = uint16_t(i);
+				const uint16_t maxValue = uint16_t(k - 1);
+				if(pos + 4 > size) return false;
+				int32_t length;
+				memcpy(&length, src + pos, 4);
+				pos += 4;
+				if(length < 0 || pos + size_t(length) > size) return false;
+				size_t total = 0;
+				for(int words : channelWords) total += size_t(W) * lines * words;
+				vector<uint16_t> buffer;
+				if(!huffmanDecode(src + pos, size_t(length), buffer, total)) return false;
+				size_t start = 0;
+				for(int words : channelWords)
+				{
+					for(int j = 0; j < words; ++j) waveletDecode(&buffer[start + j], W, words, lines, W * words, maxValue);
+					start += size_t(W) * lines * words;
+				}
+				for(uint16_t& v : buffer) v = lut[v];
+				out.resize(total * 2);
+				unsigned char* o = out.data();
+				vector<size_t> cursor(channelWords.size());
+				start = 0;
+				for(size_t c = 0; c < channelWords.size(); ++c) { cursor[c] = start; start += size_t(W) * lines * channelWords[c]; }
+				for(int l = 0; l < lines; ++l)
+					for(size_t c = 0; c < channelWords.size(); ++c)
+					{
+						const size_t n = size_t(W) * channelWords[c];
+						memcpy(o, &buffer[cursor[c]], n * 2);
+						cursor[c] += n;
+						o += n * 2;
+					}
+				return true;
+			}
+		} // namespace piz
+
 		struct Reader
 		{
 			const vector<unsigned char>& d;
@@ -147,7 +439,7 @@ namespace bcd
 			template<typename T> T get()
 			{
 				T v = T();
-				if(pos + sizeof(T) > d.size()) { ok = false; return v; }
+				if(pos > d.size() || d.size() - pos < sizeof(T)) { ok = false; return v; }
 				memcpy(&v, &d[pos], sizeof(T));
 				pos += sizeof(T);
 				return v;
@@ -156,14 +448,14 @@ namespace bcd
 			{
 				string s;
 				while(pos < d.size() && d[pos]) s.push_back(char(d[pos++]));
-				if(pos >= d.size()) ok = false;
+				if(pos >= d.size()) { ok = false; return s; }
 				++pos;
 				return s;
 			}
 		};
 
 		/// planes[c] = W*H floats of channel c (channels in file order)
-		bool readExr(const char* path, int& W, int& H, vector<Channel>& channels, vector< vector<float> >& planes)
+		bool readExrUnchecked(const char* path, int& W, int& H, vector<Channel>& channels, vector< vector<float> >& planes)
 		{
 			FILE* f = fopen(path, "rb");
 			if(!f) return fail(string("cannot open '") + path + "'");
@@ -188,8 +480,8 @@ namespace bcd
 				if(name.empty()) break;
 				const string type = r.str();
 				const int32_t attrSize = r.get<int32_t>();
+				if(!r.ok || attrSize < 0 || size_t(attrSize) > data.size() - r.pos) return fail("corrupt EXR header");
 				const size_t next = r.pos + size_t(attrSize);
-				if(!r.ok || attrSize < 0 || next > data.size()) return fail("corrupt EXR header");
 				if(name == "channels")
 				{
 					while(r.ok && r.pos < next)
@@ -214,14 +506,20 @@ namespace bcd
 				r.pos = next;
 			}
 			if(!r.ok || channels.empty() || maxX < minX || maxY < minY) return fail("incomplete EXR header");
-			if(compression < e_none || compression > e_zip)
-				return fail("unsupported EXR compression (only NONE, RLE, ZIPS and ZIP are implemented; re-save PIZ/B44/DWA files)");
-			W = maxX - minX + 1;
-			H = maxY - minY + 1;
-			const int linesPerBlock = compression == e_zip ? 16 : 1;
+			if(compression < e_none || compression > e_piz)
+				return fail("unsupported EXR compression (NONE, RLE, ZIPS, ZIP and PIZ are implemented; re-save PXR24/B44/DWA files)");
+			// window extents in 64 bits, and a size the file could possibly hold: every chunk costs at least 8 bytes of header + 8 of offset
+			const int64_t W64 = int64_t(maxX) - minX + 1, H64 = int64_t(maxY) - minY + 1;
+			if(W64 <= 0 || H64 <= 0 || W64 > (1 << 24) || H64 > (1 << 24)) return fail("EXR data window out of range");
+			W = int(W64);
+			H = int(H64);
+			const int linesPerBlock = compression == e_zip ? 16 : (compression == e_piz ? 32 : 1);
 			const int nbOfBlocks = (H + linesPerBlock - 1) / linesPerBlock;
+			if(size_t(nbOfBlocks) > (data.size() - r.pos) / 16) return fail("EXR data window larger than the file can hold");
 			size_t bytesPerLine = 0;
-			for(const Channel& c : channels) bytesPerLine += size_t(c.type == e_half ? 2 : 4) * W;
+			vector<int> channelWords;
+			for(const Channel& c : channels) { bytesPerLine += size_t(c.type == e_half ? 2 : 4) * W; channelWords.push_back(c.type == e_half ? 1 : 2); }
+			if(uint64_t(W64) * uint64_t(H64) * channels.size() > (uint64_t(1) << 33)) return fail("EXR image too large");
 			vector<uint64_t> offsets(nbOfBlocks);
 			for(int b = 0; b < nbOfBlocks; ++b) offsets[b] = r.get<uint64_t>();
 			if(!r.ok) return fail("truncated EXR offset table");
@@ -230,11 +528,11 @@ namespace bcd
 			vector<unsigned char> raw, tmp;
 			for(int b = 0; b < nbOfBlocks; ++b)
 			{
-				if(offsets[b] + 8 > data.size()) return fail("EXR chunk offset out of range");
+				if(offsets[b] > data.size() - 8) return fail("EXR chunk offset out of range");
 				r.pos = size_t(offsets[b]);
 				const int y = r.get<int32_t>() - minY;
 				const int32_t chunkSize = r.get<int32_t>();
-				if(!r.ok || chunkSize < 0 || r.pos + size_t(chunkSize) > data.size() || y < 0 || y >= H) return fail("corrupt EXR chunk");
+				if(!r.ok || chunkSize < 0 || size_t(chunkSize) > data.size() - r.pos || y < 0 || y >= H) return fail("corrupt EXR chunk");
 				const int lines = min(linesPerBlock, H - y);
 				const size_t expected = bytesPerLine * lines;
 				const unsigned char* src = &data[r.pos];
@@ -247,6 +545,10 @@ namespace bcd
 				{
 					if(!rleDecode(src, size_t(chunkSize), raw, expected)) return fail("corrupt RLE data in EXR chunk");
 					undoPredictorAndReorder(raw, tmp);
+				}
+				else if(compression == e_piz)
+				{
+					if(!piz::decodeChunk(src, size_t(chunkSize), W, lines, channelWords, raw) || raw.size() != expected) return fail("corrupt PIZ data in EXR chunk");
 				}
 				else
 				{
@@ -269,6 +571,23 @@ namespace bcd
 					}
 			}
 			return true;
+		}
+
+		/// a crafted or truncated file must end in `false`, never in an exception escaping the library
+		bool readExr(const char* path, int& W, int& H, vector<Channel>& channels, vector< vector<float> >& planes)
+		{
+			try
+			{
+				return readExrUnchecked(path, W, H, channels, planes);
+			}
+			catch(const std::bad_alloc&)
+			{
+				return fail("out of memory while reading the EXR file (header announces more data than can be allocated)");
+			}
+			catch(const std::length_error&)
+			{
+				return fail("EXR header announces an impossible size");
+			}
 		}
 
 		void putString(vector<unsigned char>& o, const string& s) { o.insert(o.end(), s.begin(), s.end()); o.push_back(0); }

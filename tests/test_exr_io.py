@@ -47,7 +47,161 @@ def _pack_block(raw, comp):
     return bytes(out) if len(out) < len(raw) else raw
 
 
-def build_exr(path, planes, types, comp, min_xy=(0, 0)):
+# ---- PIZ encoder (test side), written from the published OpenEXR scheme: value bitmap + lookup table, in-place Haar-like
+# wavelet on the 16-bit words of every channel, canonical Huffman code with a run-length pseudo symbol --------------------------
+class _Bits:
+    def __init__(self):
+        self.out, self.acc, self.n, self.total = bytearray(), 0, 0, 0
+
+    def put(self, nbits, value):
+        self.acc = (self.acc << nbits) | value
+        self.n += nbits
+        self.total += nbits
+        while self.n >= 8:
+            self.n -= 8
+            self.out.append((self.acc >> self.n) & 0xFF)
+        self.acc &= (1 << self.n) - 1
+
+    def bytes(self):
+        return bytes(self.out) + (bytes([(self.acc << (8 - self.n)) & 0xFF]) if self.n else b"")
+
+
+def _huffman_compress(values):
+    import heapq
+    freq = {}
+    for v in values:
+        freq[v] = freq.get(v, 0) + 1
+    im, rlc = min(freq), max(freq) + 1
+    freq[rlc] = 1                                      # the run-length pseudo symbol
+    heap = [(f, s, (s,)) for s, f in freq.items()]
+    heapq.heapify(heap)
+    length = {s: 0 for s in freq}
+    while len(heap) > 1:
+        f1, t1, m1 = heapq.heappop(heap)
+        f2, t2, m2 = heapq.heappop(heap)
+        for s in m1 + m2:
+            length[s] += 1
+        heapq.heappush(heap, (f1 + f2, min(t1, t2), m1 + m2))
+    assert max(length.values()) <= 58
+    count = [0] * 60
+    for l in length.values():
+        count[l] += 1
+    first, c = [0] * 60, 0
+    for l in range(58, 0, -1):                          # the longest codes start at 0
+        first[l], c = c, (c + count[l]) >> 1
+    code = {}
+    for s in sorted(length):
+        code[s] = first[length[s]]
+        first[length[s]] += 1
+    table = _Bits()                                    # 6-bit lengths im..iM with zero-run escapes (59..62 short, 63 + 8 bits long)
+    i = im
+    while i <= rlc:
+        l = length.get(i, 0)
+        if l == 0:
+            run = 1
+            while i + run <= rlc and run < 255 + 6 and length.get(i + run, 0) == 0:
+                run += 1
+            if run >= 2:
+                if run >= 6:
+                    table.put(6, 63); table.put(8, run - 6)
+                else:
+                    table.put(6, 59 + run - 2)
+                i += run
+                continue
+        table.put(6, l)
+        i += 1
+    data = _Bits()
+    i = 0
+    while i < len(values):
+        s, run = values[i], 0
+        while i + run + 1 < len(values) and values[i + run + 1] == s and run < 255:
+            run += 1
+        if length[s] + length[rlc] + 8 < length[s] * run:
+            data.put(length[s], code[s]); data.put(length[rlc], code[rlc]); data.put(8, run)
+        else:
+            for _ in range(run + 1):
+                data.put(length[s], code[s])
+        i += run + 1
+    tb = table.bytes()
+    return struct.pack("<IIIII", im, rlc, len(tb), data.total, 0) + tb + data.bytes()
+
+
+def _wavelet_encode(a, nx, ox, ny, oy, mx):
+    """in place on the flat uint16 list `a` (start offset folded into the indices by the caller)"""
+    w14 = mx < (1 << 14)
+
+    def enc(x, y):
+        if w14:
+            xs, ys = x - 65536 if x >= 32768 else x, y - 65536 if y >= 32768 else y
+            return ((xs + ys) >> 1) & 0xFFFF, (xs - ys) & 0xFFFF
+        ao = (x + 0x8000) & 0xFFFF
+        m, d = (ao + y) >> 1, ao - y
+        if d < 0:
+            m = (m + 0x8000) & 0xFFFF
+        return m, d & 0xFFFF
+    n = min(nx, ny)
+    p, p2 = 1, 2
+    while p2 <= n:
+        oy1, oy2, ox1, ox2 = oy * p, oy * p2, ox * p, ox * p2
+        py = 0
+        while py <= oy * (ny - p2):
+            px = py
+            while px <= py + ox * (nx - p2):
+                p01, p10, p11 = px + ox1, px + oy1, px + oy1 + ox1
+                i00, i01 = enc(a[px], a[p01])
+                i10, i11 = enc(a[p10], a[p11])
+                a[px], a[p10] = enc(i00, i10)
+                a[p01], a[p11] = enc(i01, i11)
+                px += ox2
+            if nx & p:
+                a[px], a[px + oy1] = enc(a[px], a[px + oy1])
+            py += oy2
+        if ny & p:
+            px = py
+            while px <= py + ox * (nx - p2):
+                a[px], a[px + ox1] = enc(a[px], a[px + ox1])
+                px += ox2
+        p, p2 = p2, p2 << 1
+
+
+def _piz_block(channel_rows):
+    """channel_rows: per channel a (lines, W * words) uint16 array; returns the PIZ chunk payload"""
+    allv = np.concatenate([c.ravel() for c in channel_rows])
+    bitmap = np.zeros(8192, np.uint8)
+    np.bitwise_or.at(bitmap, allv >> 3, (1 << (allv & 7)).astype(np.uint8))
+    bitmap[0] &= 0xFE
+    nz = np.nonzero(bitmap)[0]
+    lo, hi = (int(nz[0]), int(nz[-1])) if nz.size else (8191, 0)
+    present = np.unpackbits(bitmap, bitorder="little").astype(bool)
+    present[0] = True
+    lut = np.where(present, np.cumsum(present) - 1, 0).astype(np.uint16)
+    mx = int(present.sum()) - 1
+    PIZ_STATS["max_value"] = max(PIZ_STATS.get("max_value", 0), mx)
+    coded = []
+    for c in channel_rows:
+        lines, row = c.shape
+        W = row if c.dtype_words == 1 else row // 2
+        flat = [int(v) for v in lut[c].ravel()]
+        for j in range(c.dtype_words):
+            sub = flat[j:]
+            _wavelet_encode(sub, W, c.dtype_words, lines, row, mx)
+            flat[j:] = sub
+        coded += flat
+    huf = _huffman_compress(coded)
+    out = struct.pack("<HH", lo, hi)
+    if lo <= hi:
+        out += bitmap[lo:hi + 1].tobytes()
+    return out + struct.pack("<i", len(huf)) + huf
+
+
+class _Rows(np.ndarray):
+    dtype_words = 1
+
+
+PIZ_STATS = {}
+
+
+def build_exr(path, planes, types, comp, min_xy=(0, 0), force_compressed=False):
     """planes: dict name -> HxW array; types: dict name -> 'half' | 'float' | 'uint'"""
     names = sorted(planes)
     H, W = planes[names[0]].shape
@@ -64,16 +218,26 @@ def build_exr(path, planes, types, comp, min_xy=(0, 0)):
     hdr += _attr("lineOrder", "lineOrder", b"\0") + _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
     hdr += _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + _attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
     hdr += b"\0"
-    lines = 16 if comp == 3 else 1
+    lines = {3: 16, 4: 32}.get(comp, 1)
     nblocks = (H + lines - 1) // lines
     chunks = []
     for b in range(nblocks):
         raw = b""
+        dts = {"half": np.float16, "float": np.float32, "uint": np.uint32}
         for l in range(b * lines, min(H, (b + 1) * lines)):
             for n in names:
-                dt = {"half": np.float16, "float": np.float32, "uint": np.uint32}[types[n]]
-                raw += planes[n][l].astype(dt).tobytes()
-        data = _pack_block(raw, comp)
+                raw += planes[n][l].astype(dts[types[n]]).tobytes()
+        if comp == 4:
+            rows = []
+            for n in names:
+                blk = np.ascontiguousarray(planes[n][b * lines:min(H, (b + 1) * lines)].astype(dts[types[n]]))
+                r = blk.view(np.uint16).reshape(blk.shape[0], -1).view(_Rows)
+                r.dtype_words = 1 if types[n] == "half" else 2
+                rows.append(r)
+            data = _piz_block(rows)
+            data = data if (len(data) < len(raw) or force_compressed) and len(data) != len(raw) else raw
+        else:
+            data = _pack_block(raw, comp)
         chunks.append(struct.pack("<ii", y0 + b * lines, len(data)) + data)
     off = len(hdr) + 8 * nblocks
     table = b""
@@ -83,7 +247,7 @@ def build_exr(path, planes, types, comp, min_xy=(0, 0)):
     open(path, "wb").write(hdr + table + b"".join(chunks))
 
 
-@pytest.mark.parametrize("comp", [0, 1, 2, 3])
+@pytest.mark.parametrize("comp", [0, 1, 2, 3, 4])
 def test_reads_independently_built_files(tmp_path, comp):
     rng = np.random.default_rng(comp)
     H, W = 37, 23
@@ -99,6 +263,61 @@ def test_reads_independently_built_files(tmp_path, comp):
     allc = core.read_exr(p, True)                 # alphabetical: A, B, G, R, Z
     assert allc.shape == (H, W, 5)
     assert np.array_equal(allc[..., 4], planes["Z"].astype(np.float32)) and (allc[..., 0] == 1).all()
+
+
+def test_piz_half_rgba_like_the_reference_writer_and_16_bit_wavelet(tmp_path):
+    """the reference writes colours through Imf::RgbaOutputFile (io_exr.cpp:147-164): half A, B, G, R, PIZ.  A smooth image keeps the
+    number of distinct 16-bit values of a chunk below 2^14 (14-bit wavelet, long runs -> run-length codes); a wide noisy float image
+    exceeds it (16-bit modular wavelet)."""
+    H, W = 70, 45
+    y, x = np.mgrid[0:H, 0:W]
+    planes = {"R": 0.2 + 0.6 * x / W, "G": 0.5 + 0.4 * np.sin(12.0 * y / H), "B": np.where((x // 16 + y // 16) % 2 == 0, 0.8, 0.15), "A": np.ones((H, W))}
+    p = str(tmp_path / "rgba.exr")
+    build_exr(p, planes, {k: "half" for k in planes}, 4)
+    raw = open(p, "rb").read()
+    assert len(raw) < H * W * 8 // 2                                  # it really is compressed
+    rgb = core.read_exr(p, False)
+    for k, name in enumerate("RGB"):
+        assert np.array_equal(rgb[..., k], planes[name].astype(np.float16).astype(np.float32)), name
+    rng = np.random.default_rng(5)
+    H, W = 35, 640
+    planes = {"Bin_0000": rng.standard_normal((H, W)) * 100, "Bin_0001": rng.random((H, W))}
+    PIZ_STATS.clear()
+    build_exr(p, planes, {"Bin_0000": "float", "Bin_0001": "float"}, 4, force_compressed=True)  # (noise does not compress: OpenEXR would store it raw)
+    assert PIZ_STATS["max_value"] >= 1 << 14                          # the 16-bit wavelet path
+    back = core.read_exr(p, True)
+    assert np.array_equal(back[..., 0], planes["Bin_0000"].astype(np.float32)) and np.array_equal(back[..., 1], planes["Bin_0001"].astype(np.float32))
+    # truncated / corrupted PIZ payloads are reported, not fatal
+    blob = bytearray(open(p, "rb").read())
+    open(p, "wb").write(bytes(blob[:len(blob) - 1000]))
+    with pytest.raises(IOError):
+        core.read_exr(p, True)
+    blob[-500] ^= 0x5A
+    open(p, "wb").write(bytes(blob))
+    try:
+        core.read_exr(p, True)            # a flipped bit may still decode (to other values) -- it must not crash
+    except IOError:
+        pass
+
+
+def test_crafted_headers_are_rejected(tmp_path):
+    """untrusted-file hardening: offsets near 2^64, a data window of 2^31 lines, an impossible width"""
+    p = str(tmp_path / "x.exr")
+    build_exr(p, {"R": np.zeros((4, 4))}, {"R": "half"}, 0)
+    good = open(p, "rb").read()
+    end_hdr = good.index(b"screenWindowWidth\0float\0") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1
+    bad = bytearray(good)
+    bad[end_hdr:end_hdr + 8] = struct.pack("<Q", 2 ** 64 - 4)         # chunk offset that wraps
+    open(p, "wb").write(bytes(bad))
+    with pytest.raises(IOError):
+        core.read_exr(p, False)
+    for box in ((0, 0, 3, 2 ** 31 - 2), (0, 0, 2 ** 31 - 2, 3), (0, -2 ** 31, 3, 2 ** 31 - 1)):
+        bad = bytearray(good)
+        i = bad.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+        bad[i:i + 16] = struct.pack("<iiii", *box)
+        open(p, "wb").write(bytes(bad))
+        with pytest.raises(IOError):
+            core.read_exr(p, False)
 
 
 def test_multichannel_roundtrip_is_exact(tmp_path):
@@ -140,7 +359,7 @@ def test_errors_are_reported_not_fatal(tmp_path):
     planes = {"R": np.zeros((4, 4))}
     build_exr(p, planes, {"R": "half"}, 0)
     raw = bytearray(open(p, "rb").read())
-    raw[raw.index(b"compression\0compression\0") + 28] = 4   # PIZ
+    raw[raw.index(b"compression\0compression\0") + 28] = 6   # B44
     open(p, "wb").write(bytes(raw))
     with pytest.raises(IOError, match="compression"):
         core.read_exr(p, False)

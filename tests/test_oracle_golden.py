@@ -131,3 +131,70 @@ def test_denoiser_reduces_error_and_orders_matter():
     # -m 0 is order/thread independent up to summation order (1.5e-6)
     o0b = ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0, threads=1))
     assert np.max(np.abs(o0 - o0b)) / np.max(np.abs(o0b)) < 1e-5
+
+
+def test_float64_numpy_restatement_of_the_bayesian_steps_agrees_with_the_oracle():
+    """Independent cross-check of the unpinned core (a11-a16): a float64 NumPy restatement written from the reference source
+    (/root/reference/src/core/DenoisingUnit.cpp:400-481 and 483-693, Denoiser.cpp:357-373,434-470) -- not from oracle/bcd_oracle.c --
+    with numpy.linalg.eigh in place of Eigen's solver, run on every main pixel of the 40 x 28 regression frame (-m 0) with the similar
+    sets of the fixture, must reproduce the oracle's fp32 image.  It does not pin the oracle to the reference (nothing can without
+    Eigen) but removes "single author, single reading" of the two Bayesian steps as a failure mode."""
+    f = load("core_regression.npz")
+    col, ns, cov, mask, want = f["col"].astype(np.float64), f["ns"].astype(np.float64), f["cov"].astype(np.float64), f["mask"], f["out_m0"]
+    H, W, _ = col.shape
+    b, w, min_eig = 6, 1, 1e-8
+    side = 2 * b + 1
+    pixcov = cov * (1.0 / ns)                                            # Denoiser.cpp:357-373
+    offs = [(ol_, oc) for ol_ in (-1, 0, 1) for oc in (-1, 0, 1)]        # patch pixels, row-major (DeepImage.hpp window iteration)
+
+    def block(v6):                                                       # CovarianceMatrix.h:18-27: xx,yy,zz,yz,xz,xy
+        xx, yy, zz, yz, xz, xy = v6
+        return np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]])
+
+    def patch_vec(img, l, c):                                            # :483-498: pixel-major, RGB
+        return np.concatenate([img[l + a, c + d] for (a, d) in offs])
+
+    def spectral(M, fn):                                                 # :578-630
+        lam, V = np.linalg.eigh(M)
+        return (V * fn(lam)) @ V.T
+
+    acc = np.zeros((H, W, 3))
+    cnt = np.zeros((H, W))
+    for l in range(w, H - w):
+        for c in range(w, W - w):
+            bits = np.unpackbits(mask[l, c].view(np.uint8), bitorder="little")[:side * side]
+            members = [(l + k // side - b, c + k % side - b) for k in np.nonzero(bits)[0]]   # window order (:196-219)
+            n = len(members)
+            X = np.stack([patch_vec(col, ql, qc) for (ql, qc) in members])
+            if n < 3 * 9 + 1:                                            # :182 -> denoiseOnlyMainPatch (:455-481)
+                est = X.mean(axis=0)
+                for o, (a, d) in enumerate(offs):
+                    acc[l + a, c + d] += est[3 * o:3 * o + 3]
+                    cnt[l + a, c + d] += 1
+                continue
+            N = np.zeros((27, 27))                                       # computeNoiseCovPatchesMean (:400-419)
+            for (ql, qc) in members:
+                for o, (a, d) in enumerate(offs):
+                    N[3 * o:3 * o + 3, 3 * o:3 * o + 3] += block(pixcov[ql + a, qc + d])
+            N /= n
+            # Step 1 (:421-436)
+            m1 = X.mean(axis=0)
+            Xc = X - m1
+            C = Xc.T @ Xc / (n - 1)
+            C1 = spectral(C - N, lambda lam: np.maximum(0.0, lam)) + N
+            I1 = spectral(C1, lambda lam: 1.0 / np.maximum(min_eig, lam))
+            X1 = X - (N @ (I1 @ Xc.T)).T                                 # finalDenoisingMatrixMultiplication (:656-670)
+            # Step 2 (:438-453): no clamp; the noisy patches are centred on the mean of the Step-1 estimates
+            m2 = X1.mean(axis=0)
+            X1c = X1 - m2
+            C2 = X1c.T @ X1c / (n - 1) + N
+            I2 = spectral(C2, lambda lam: 1.0 / np.maximum(min_eig, lam))
+            X2 = X - (N @ (I2 @ (X - m2).T)).T
+            for (ql, qc), est in zip(members, X2):                       # aggregateOutputPatches (:672-693)
+                for o, (a, d) in enumerate(offs):
+                    acc[ql + a, qc + d] += est[3 * o:3 * o + 3]
+                    cnt[ql + a, qc + d] += 1
+    got = acc / cnt[..., None]                                           # finalAggregation (Denoiser.cpp:458-469)
+    assert (f["fallback"] > 0).any() and (f["nsim"] >= 28).any()         # both paths are exercised on this frame
+    err = np.max(np.abs(got - want)) / np.max(np.abs(want))
+    assert err < 1e-5, err
