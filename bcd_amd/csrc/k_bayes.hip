@@ -285,36 +285,68 @@ __global__ __launch_bounds__(64) void k_bayes_strong_generic(const float *__rest
   }
 }
 
-// denoiseOnlyMainPatch (:455-481): average of the similar colour patches added to the main patch only
+// denoiseOnlyMainPatch (:455-481): average of the similar colour patches added to the main patch only.
+// One lane per (fallback pixel, patch pixel): a wavefront takes 64 / P pixels at once (7 for the 3 x 3 patch), every lane walks
+// the similar-set bitmask of its pixel in window order (the reference's member order, so the three channel sums are the
+// reference's sequential sums) and adds its patch pixel of every member; no LDS, no barrier.  Four members are decoded per step
+// so that their loads are in flight together.  |S| = 0 gives 0 * inf = NaN like the reference (assert compiled out, :212-213).
 __global__ __launch_bounds__(64) void k_bayes_weak(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
                                                    const int32_t *__restrict__ list, const int32_t *__restrict__ d_nlist, BayesGeom g,
                                                    float *sum, int32_t *cnt)
 {
-    extern __shared__ float lds[];
-    int *mem = reinterpret_cast<int *>(lds);
-    const int lane = threadIdx.x, pw = 2 * g.w + 1;
+    const int lane = threadIdx.x, pw = 2 * g.w + 1, P = g.P;
+    const int per_wave = P <= 64 ? 64 / P : 1;       // pixels per wavefront
+    const int passes = P <= 64 ? 1 : (P + 63) / 64;  // patches larger than a wavefront: several patch pixels per lane
+    const int slot = P <= 64 ? lane / P : 0;
     const int nlist = *d_nlist;
-  for (int item = blockIdx.x; item < nlist; item += gridDim.x) {
-    __syncthreads(); // mem[] of the previous item is no longer read
-    const int p = list[item];
-    const int n = decode_members(mask, p, g, mem, lane);
-    const float n_inv = 1.f / (float)n; // inf when n == 0, like the reference (assert compiled out, :212-213)
-    for (int k = lane; k < g.K; k += 64) {
-        int o = k / 3, ch = k - o * 3;
-        int offp = (o / pw - g.w) * g.W + (o % pw - g.w);
-        float acc = 0.f;
-        for (int i = 0; i < n; i += 8) { // 8 independent loads in flight, summed in member order
-            float v[8];
+    const float inv_side = 1.f / (float)g.side;
+    for (int base = blockIdx.x * per_wave; base < nlist; base += gridDim.x * per_wave) {
+        const int item = base + slot;
+        for (int pass = 0; pass < passes; ++pass) {
+            const int o = (P <= 64 ? lane - slot * P : lane) + 64 * pass;
+            if (slot >= per_wave || item >= nlist || o >= P) continue;
+            const int p = list[item];
+            const int offp = (o / pw - g.w) * g.W + (o % pw - g.w);
+            const float *src = colors + (size_t)(p + offp) * 3;  // colour of patch pixel o of the member at window offset 0
+            const uint32_t *mw = mask + (size_t)p * g.words;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            int n = 0;
+            for (int wd = 0; wd < g.words; ++wd) {
+                uint32_t m = mw[wd];
+                while (m) {
+                    int rel[4];
+                    int got = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = colors[(size_t)(mem[min(i + u, n - 1)] + offp) * 3 + ch];
+                    for (int u = 0; u < 4; ++u) {
+                        rel[u] = 0;
+                        if (m) {
+                            const int k = wd * 32 + __ffs(m) - 1;
+                            m &= m - 1;
+                            // k / side without an integer division: (k + 0.5) / side is at least 0.5 / side away from an integer, k < 2^10
+                            const int kl = (int)(((float)k + 0.5f) * inv_side), kc = k - kl * g.side;
+                            rel[u] = ((kl - g.b) * g.W + (kc - g.b)) * 3;
+                            got = u + 1;
+                        }
+                    }
+                    float v[4][3];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i + u < n) acc += v[u];
+                    for (int u = 0; u < 4; ++u) {
+                        v[u][0] = src[rel[u]]; v[u][1] = src[rel[u] + 1]; v[u][2] = src[rel[u] + 2]; // (idle slots re-read the main patch)
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < got) { a0 += v[u][0]; a1 += v[u][1]; a2 += v[u][2]; }
+                    n += got;
+                }
+            }
+            const float n_inv = 1.f / (float)n;
+            float *dst = sum + (size_t)(p + offp) * 3;
+            unsafeAtomicAdd(dst, n_inv * a0);
+            unsafeAtomicAdd(dst + 1, n_inv * a1);
+            unsafeAtomicAdd(dst + 2, n_inv * a2);
+            atomicAdd(cnt + p + offp, 1);
         }
-        unsafeAtomicAdd(sum + (size_t)(p + offp) * 3 + ch, n_inv * acc);
-        if (ch == 0) atomicAdd(cnt + p + offp, 1);
     }
-  }
 }
 
 BayesGeom make_geom(int W, int H, int w, int b)
@@ -393,6 +425,6 @@ hipError_t bcd_launch_bayes_weak(const float *colors, const uint32_t *mask, cons
     if (blocks <= 0) return hipSuccess;
     BayesGeom g = make_geom(W, H, w, b);
     if (g.words > 32) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_bayes_weak, dim3(blocks), dim3(64), (size_t)g.maxS * sizeof(int), st, colors, mask, list, d_nlist, g, sum, cnt);
+    hipLaunchKernelGGL(k_bayes_weak, dim3(blocks), dim3(64), 0, st, colors, mask, list, d_nlist, g, sum, cnt);
     return hipGetLastError();
 }
