@@ -46,9 +46,12 @@ hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *,
 hipError_t bcd_launch_mark_deps(const uint32_t *, const int32_t *, uint8_t *, uint32_t *, int, int, int, int, int, uint32_t, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_mark_round(const uint32_t *, uint8_t *, int, int, int, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
+hipError_t bcd_launch_jacobi27_batch(const float *, int, int *, int, float *, float *, hipStream_t);
 size_t bcd_bayes_lds_bytes(int w, int b);
 size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
-int bcd_bayes27_blocks_per_cu(int b);
+size_t bcd_bayes27_record_bytes();
+hipError_t bcd_launch_bayes27(const float *, const float *, const uint32_t *, const int32_t *, int, int, int *, int, int, int, int, float, float *, float *,
+                              int32_t *, hipStream_t);
 hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, const int32_t *, int *, int, int, int, int,
                                    int, float, float *, int32_t *, float *, size_t, hipStream_t);
 hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, const int32_t *, int, int, int, int, int, float *,
@@ -338,9 +341,11 @@ int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t
     return BCD_HIP_OK;
 }
 
-// lists of processed pixels + both estimate kernels, without any host round trip: the list lengths stay in device memory
-// and persistent workgroups share the lists.  The lengths and the sum of |S| are copied to wk.h_counters[16..20): read them
-// with bayes_counts() after the stream has been synchronised.
+// lists of processed pixels + the estimate kernels.  The list lengths and the sum of |S| are copied to wk.h_counters[16..20):
+// read them with bayes_counts() after the stream has been synchronised.
+// w = 1: the full estimate is three kernels with a per-pixel record in HBM between them (k_bayes27.hip); the host reads the
+// number of full-estimate pixels (one short round trip, the fallback kernel is already running on its side stream) to size the
+// record buffer and to cut very long lists (-m 0) into chunks.  Other patch radii: one persistent kernel, no round trip.
 int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask, const int32_t *d_nsim,
           const uint8_t *d_state, int W, int H, int w, int b, float min_eig, float *d_sum, int32_t *d_count)
 {
@@ -349,24 +354,37 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     RCCHK(ensure(ctx, wk.strong, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.weak, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
-    int32_t *d_c = (int32_t *)wk.counters.p + 16; // [0] strong, [1] weak, [2..3] sum |S|, [4] work counter of the strong kernel
+    int32_t *d_c = (int32_t *)wk.counters.p + 16; // [0] strong, [1] weak, [2..3] sum |S|, [4..6] work counters of the estimate kernels
     HIPCHK(ctx, hipMemsetAsync(d_c, 0, 8 * sizeof(int32_t), wk.stream));
     HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)wk.strong.p, (int32_t *)wk.weak.p, d_c, wk.stream));
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream));
-    const size_t per_block = bcd_bayes_scratch_bytes_per_block(w, b);
     const int64_t cap = std::max<int64_t>(1, npix);
-    // persistent grids: as many workgroups as the CUs hold at once (w = 1: LDS-bound, 12 per CU at b = 6; generic: 1024 scratch slices)
-    const int strong_blocks = (int)std::min<int64_t>(cap, w == 1 ? (int64_t)ctx->num_cus * bcd_bayes27_blocks_per_cu(b) : 1024);
     const int weak_blocks = (int)std::min<int64_t>(cap, (int64_t)ctx->num_cus * 32);
-    if (per_block) RCCHK(ensure(ctx, wk.gscratch, per_block * (size_t)strong_blocks));
-    // the two kernels only meet in the atomic accumulators: the fallback pixels (many cheap items) run on a side stream beside
-    // the full estimate (few long items that leave most of the chip's issue slots idle)
+    // the two paths only meet in the atomic accumulators: the fallback pixels (many cheap items) run on a side stream beside
+    // the full estimate (few long items)
     HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
     HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
     HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, d_c + 1, weak_blocks, W, H, w, b, d_sum, d_count, wk.aux));
     HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
-    HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, d_c, d_c + 4, strong_blocks, W, H, w, b, min_eig,
-                                        d_sum, d_count, (float *)wk.gscratch.p, wk.gscratch.bytes, wk.stream));
+    if (w == 1) {
+        HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+        const int n_strong = wk.h_counters[16];
+        const size_t rec = bcd_bayes27_record_bytes();
+        const int chunk_max = 1 << 17; // 131072 pixels = 1.3 GB of records
+        if (n_strong > 0) RCCHK(ensure(ctx, wk.gscratch, rec * (size_t)std::min(n_strong, chunk_max)));
+        for (int first = 0; first < n_strong; first += chunk_max) {
+            const int n = std::min(chunk_max, n_strong - first);
+            if (first > 0) HIPCHK(ctx, hipMemsetAsync(d_c + 4, 0, 3 * sizeof(int32_t), wk.stream)); // (zeroed with the list counters for the first chunk)
+            HIPCHK(ctx, bcd_launch_bayes27(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, first, n, d_c + 4, ctx->num_cus, W, H, b, min_eig,
+                                           (float *)wk.gscratch.p, d_sum, d_count, wk.stream));
+        }
+    } else {
+        const size_t per_block = bcd_bayes_scratch_bytes_per_block(w, b);
+        const int strong_blocks = (int)std::min<int64_t>(cap, 1024); // generic kernel: 1024 scratch slices
+        if (per_block) RCCHK(ensure(ctx, wk.gscratch, per_block * (size_t)strong_blocks));
+        HIPCHK(ctx, bcd_launch_bayes_strong(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, d_c, d_c + 4, strong_blocks, W, H, w, b, min_eig,
+                                            d_sum, d_count, (float *)wk.gscratch.p, wk.gscratch.bytes, wk.stream));
+    }
     HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_join, 0));
     return BCD_HIP_OK;
 }
@@ -1080,6 +1098,22 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
     (void)hipFree(C2);
     if (rc != BCD_HIP_OK) set_err(ctx, "approximate-distance self-test failed to run");
     return rc;
+}
+
+int bcd_hip_eig27_batch(bcd_hip_ctx *ctx, const float *d_A, int n, float *d_eig, float *d_V, float *ms)
+{
+    if (!ctx || !d_A || !d_eig || !d_V || n <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
+    Work &wk = ctx->main;
+    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+    int32_t *d_c = (int32_t *)wk.counters.p + 48; // work counter
+    HIPCHK(ctx, hipMemsetAsync(d_c, 0, sizeof(int32_t), wk.stream));
+    HIPCHK(ctx, hipEventRecord(wk.ev_stage[0], wk.stream));
+    HIPCHK(ctx, bcd_launch_jacobi27_batch(d_A, n, d_c, std::min(ctx->num_cus * 12, (n + 1) / 2), d_eig, d_V, wk.stream));
+    HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
+    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    if (ms) *ms = stage_ms(wk, 0, 1);
+    return BCD_HIP_OK;
 }
 
 int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, int64_t *mismatches)

@@ -391,16 +391,12 @@ size_t bcd_bayes_scratch_bytes_per_block(int w, int b)
     return 2 * (size_t)g.maxS * g.K * sizeof(float);
 }
 
-hipError_t bcd_launch_bayes27(const float *, const float *, const uint32_t *, const int32_t *, const int32_t *, int *, int, int, int, int, float,
-                              float *, int32_t *, hipStream_t);
-
-// the list lengths stay in device memory (d_nlist, written by k_active_lists); `blocks` persistent workgroups share the lists
 hipError_t bcd_launch_bayes_strong(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list,
                                    const int32_t *d_nlist, int *d_work, int blocks, int W, int H, int w, int b, float min_eig, float *sum,
                                    int32_t *cnt, float *gscratch, size_t gscratch_bytes, hipStream_t st)
 {
     if (blocks <= 0) return hipSuccess;
-    if (w == 1) return bcd_launch_bayes27(colors, pixcov, mask, list, d_nlist, d_work, blocks, W, H, b, min_eig, sum, cnt, st);
+    if (w == 1) return hipErrorInvalidValue; // the 3 x 3 patch has its own launcher (bcd_launch_bayes27)
     BayesGeom g = make_geom(W, H, w, b);
     if (g.words > 32) return hipErrorInvalidValue;
     const size_t per_block = bcd_bayes_scratch_bytes_per_block(w, b);

@@ -18,15 +18,11 @@
 //     lambda_min(M) >= minEig); otherwise the spectral form is evaluated with the Jacobi solver.
 #include "bcd_common.h"
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
-
-// per-phase cycle counters of one wavefront, filled only by the DBG instantiation (BCD_DBG_BAYES=1: printed after the launch)
-__device__ long long bcd_dbg_cycles[24];
-__device__ int bcd_dbg_item = 100; // which work item the DBG instantiation stamps (BCD_DBG_ITEM)
 
 namespace {
 
-#define DBG_T(i) do { if (DBG && item == bcd_dbg_item && lane == 0) bcd_dbg_cycles[i] = __builtin_readcyclecounter(); } while (0)
 
 constexpr int K = 27, KP = 28, LD = 29, P = 9, MSZ = KP * KP, CHUNK = MSZ / K; // matrix buffer: 784 floats; 29 members per staging chunk
 
@@ -35,6 +31,10 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 struct Geom27 {
     int W, H, b, side, words, maxS;
 };
+
+// The out-of-line phases below receive their LDS buffers as plain pointers; without this hint the compiler addresses them with
+// FLAT instructions (aperture check, both memory counters, a fraction of the ds_read / ds_write rate).
+#define LDS_POINTER(p) __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)(p)))
 
 __device__ inline float wsum(float v)
 {
@@ -69,102 +69,146 @@ __device__ inline int sigma_slot(int s)
     return s == 0 ? 0 : (s == 1 ? 2 : (s == 26 ? 27 : ((s & 1) ? s - 2 : s + 2)));
 }
 
-// A0 holds the symmetric input (JLD layout, row/col 27 zero).  The kernel is bound by LDS bandwidth (measured: 21 KB per
-// wavefront and round with everything staged through LDS), so only what must change lanes goes through LDS:
-//   * rows of A (lanes 0..27) are stored at their Brent-Luk permuted slot and reloaded -- in place: the workgroup is a single
-//     wavefront, every row is in registers before the first permuted row is written back;
-//   * rows of V (lanes 32..58) never move between lanes and stay in registers for the whole solve;
-//   * the 14 rotations (c, s) are broadcast with v_readlane (wave-uniform SGPR operands of the column rotations).
-template <bool DBG>
-__device__ void jacobi27(float *A0, float *V0, float *cs, int lane, int item)
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched eigensolver: the same Brent-Luk two-sided Jacobi, two matrices per wavefront and nothing else in the kernel.
+// Matrix h of a pair lives in lanes 32 h .. 32 h + 27 (rows of A, moved through LDS every round) and, in a second register
+// set of the same lanes, the rows of V (never move).  The LDS traffic and the row / column rotations of A are shared by the
+// two matrices -- per matrix and round ~100 VALU and ~10 LDS instructions instead of ~140 and ~21 -- and with 6.5 KB of LDS
+// per wavefront the residency is bound by registers only (3 wavefronts per SIMD = 24 matrices per CU instead of 12).
+//   in:  A  [n][28 x 28] (JLD layout, row / column 27 zero)      out: eig [n][28] (slot order), V [n][28 x 28] (rows 0..26)
+// ---------------------------------------------------------------------------------------------------------------------
+// one wavefront per workgroup: no s_barrier is emitted for it, only the ordering of the LDS accesses
+__device__ inline void wave_sync() { __syncthreads(); }
+
+__device__ inline float half_sum(float v)
 {
-    const bool isA = lane < KP, isV = lane >= 32 && lane < 32 + K;
-    const int vrow = lane - 32;
-    const float *src = A0 + (isA ? lane : 0) * JLD;
-    float *dst = A0 + (isA ? sigma_slot(lane) : 0) * JLD;
-    float row[JLD];
-#pragma unroll
-    for (int k = 0; k < JLD; ++k) row[k] = (isV && k == vrow) ? 1.f : 0.f; // V = identity
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        float off = 0.f, dg = 0.f;
-        for (int e = lane; e < KP * JLD; e += 64) {
-            int r = e / JLD, c = e - r * JLD;
-            float v = A0[e];
-            if (r == c) dg = fmaf(v, v, dg); else off = fmaf(v, v, off);
-        }
-        off = wsum(off);
-        dg = wsum(dg);
-        if (DBG && item == bcd_dbg_item && lane == 0) bcd_dbg_cycles[12 + sweep] = (long long)(1e18f * off / dg);
-        if (off <= 1e-13f * dg) break;
-        for (int round = 0; round < KP - 1; ++round) {
-            // lanes 0..13: rotation of the slot pair (2 lane, 2 lane + 1); the other lanes compute on a harmless copy of pair 0
-            float c = 1.f, s = 0.f;
-            {
-                const int p = lane < KP / 2 ? 2 * lane : 0, q = p + 1;
-                const float apq = A0[p * JLD + q], app = A0[p * JLD + p], aqq = A0[q * JLD + q];
-                if (apq != 0.f) {
-                    // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working
-                    // precision (c^2 + s^2 = 1 +- 1e-7), not the exact minimiser
-                    float theta = (aqq - app) * __builtin_amdgcn_rcpf(2.f * apq);
-                    float t = __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.f)));
-                    t = theta < 0.f ? -t : t;
-                    c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
-                    s = t * c;
-                    if (!(fabsf(theta) < 1e18f)) { c = 1.f; s = 0.f; } // theta^2 overflows: the rotation is the identity to fp32
-                }
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(64, 3) void k_jacobi27_batch(const float *__restrict__ Ain, int n, int *work,
+                                                          float *__restrict__ eig, float *__restrict__ Vout)
+{
+    __shared__ float4 lds4[(2 * KP * JLD + 2 * KP) / 4];
+    float *Abuf = reinterpret_cast<float *>(lds4);
+    float *cs = Abuf + 2 * KP * JLD; // [matrix][28]
+    const int lane = threadIdx.x, h = lane >> 5, r = lane & 31;
+    float *Ah = Abuf + h * KP * JLD;
+    float *cs_h = cs + h * KP;
+    const bool isRow = r < KP;
+    const float *src = Ah + (isRow ? r : 0) * JLD;
+    float *dst = Ah + (isRow ? sigma_slot(r) : 0) * JLD;
+    for (;;) {
+        int first = 0;
+        if (lane == 0) first = atomicAdd(work, 2);
+        first = __builtin_amdgcn_readfirstlane(first);
+        if (first >= n) break;
+        const int item = first + h;
+        const bool live = item < n;
+        // matrix -> LDS (an absent second matrix is the identity: converged from the start)
+        {
+            const float4 *g = reinterpret_cast<const float4 *>(Ain + (size_t)(live ? item : first) * (KP * JLD));
+            for (int e = r; e < KP * JLD / 4; e += 32) {
+                float4 v = g[e];
+                if (!live) { const int e0 = 4 * e, rr = e0 / JLD, c0 = e0 - rr * JLD; v = make_float4(rr == c0, rr == c0 + 1, rr == c0 + 2, rr == c0 + 3); }
+                reinterpret_cast<float4 *>(Ah)[e] = v;
             }
-            if (lane < KP / 2) reinterpret_cast<float2 *>(cs)[lane] = make_float2(c, s);
-            if (isA) {
+        }
+        wave_sync();
+        float vrow[JLD];
+#pragma unroll
+        for (int k = 0; k < JLD; ++k) vrow[k] = (k == r) ? 1.f : 0.f; // V = identity
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            float off = 0.f, dg = 0.f;
+            for (int e = r; e < KP * JLD; e += 32) {
+                const int rr = e / JLD, c = e - rr * JLD;
+                const float v = Ah[e];
+                if (rr == c) dg = fmaf(v, v, dg); else off = fmaf(v, v, off);
+            }
+            off = half_sum(off);
+            dg = half_sum(dg);
+            if (__builtin_amdgcn_ballot_w64(!(off <= 1e-13f * dg)) == 0) break; // both matrices converged
+            for (int round = 0; round < KP - 1; ++round) {
+                // lanes 0..13 of each half: rotation of the slot pair (2 r, 2 r + 1); the other lanes compute on a harmless copy of pair 0
+                float c = 1.f, s_ = 0.f;
+                {
+                    const int p = r < KP / 2 ? 2 * r : 0, q = p + 1;
+                    const float apq = Ah[p * JLD + q], app = Ah[p * JLD + p], aqq = Ah[q * JLD + q];
+                    if (apq != 0.f) {
+                        // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working
+                        // precision (c^2 + s^2 = 1 +- 1e-7), not the exact minimiser
+                        float theta = (aqq - app) * __builtin_amdgcn_rcpf(2.f * apq);
+                        float t = __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.f)));
+                        t = theta < 0.f ? -t : t;
+                        c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
+                        s_ = t * c;
+                        if (!(fabsf(theta) < 1e18f)) { c = 1.f; s_ = 0.f; } // theta^2 overflows: the rotation is the identity to fp32
+                    }
+                }
+                float row[JLD];
 #pragma unroll
                 for (int q4 = 0; q4 < JLD / 4; ++q4) {
                     float4 v = reinterpret_cast<const float4 *>(src)[q4];
                     row[4 * q4] = v.x; row[4 * q4 + 1] = v.y; row[4 * q4 + 2] = v.z; row[4 * q4 + 3] = v.w;
                 }
+                if (r < KP / 2) reinterpret_cast<float2 *>(cs_h)[r] = make_float2(c, s_);
+                wave_sync();
+                float rot[JLD];
+#pragma unroll
+                for (int q4 = 0; q4 < JLD / 4; ++q4) {
+                    float4 w4 = reinterpret_cast<const float4 *>(cs_h)[q4];
+                    rot[4 * q4] = w4.x; rot[4 * q4 + 1] = w4.y; rot[4 * q4 + 2] = w4.z; rot[4 * q4 + 3] = w4.w;
+                }
+                const float2 pcs = reinterpret_cast<const float2 *>(cs_h)[isRow ? (r >> 1) : 0];
+                // column rotations of A: (x, y) <- (c x - s y, s x + c y) for every slot pair
+#pragma unroll
+                for (int j = 0; j < KP / 2; ++j) {
+                    const float cj = rot[2 * j], sj = rot[2 * j + 1];
+                    const float x = row[2 * j], y = row[2 * j + 1];
+                    row[2 * j] = fmaf(cj, x, -sj * y);
+                    row[2 * j + 1] = fmaf(sj, x, cj * y);
+                }
+                // row rotations of A: rows (2i, 2i+1) live in lanes (2i, 2i+1) of their half and take the rotation of pair i
+                {
+                    const float mc = pcs.x, ms = (r & 1) ? pcs.y : -pcs.y;
+                    float out[JLD];
+#pragma unroll
+                    for (int k = 0; k < JLD; ++k)
+                        out[sigma_slot(k)] = fmaf(mc, row[k], dpp_xor1(row[k]) * ms); // + Brent-Luk column move (register renaming)
+                    if (isRow) {
+#pragma unroll
+                        for (int q4 = 0; q4 < JLD / 4; ++q4)
+                            reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
+                    }
+                }
+                // the same column rotations (and column move) on the rows of V
+                {
+                    float out[JLD];
+#pragma unroll
+                    for (int j = 0; j < KP / 2; ++j) {
+                        const float cj = rot[2 * j], sj = rot[2 * j + 1];
+                        const float x = vrow[2 * j], y = vrow[2 * j + 1];
+                        out[sigma_slot(2 * j)] = fmaf(cj, x, -sj * y);
+                        out[sigma_slot(2 * j + 1)] = fmaf(sj, x, cj * y);
+                    }
+#pragma unroll
+                    for (int k = 0; k < JLD; ++k) vrow[k] = out[k];
+                }
+                wave_sync(); // the rows of A are back in LDS before the next round reads its pivots
             }
-            __syncthreads();
-            float rot[JLD];
-#pragma unroll
-            for (int q4 = 0; q4 < JLD / 4; ++q4) {
-                float4 w4 = reinterpret_cast<const float4 *>(cs)[q4];
-                rot[4 * q4] = w4.x; rot[4 * q4 + 1] = w4.y; rot[4 * q4 + 2] = w4.z; rot[4 * q4 + 3] = w4.w;
-            }
-            // column rotations: (x, y) <- (c x - s y, s x + c y) for every slot pair
-#pragma unroll
-            for (int j = 0; j < KP / 2; ++j) {
-                const float cj = rot[2 * j], sj = rot[2 * j + 1];
-                const float x = row[2 * j], y = row[2 * j + 1];
-                row[2 * j] = fmaf(cj, x, -sj * y);
-                row[2 * j + 1] = fmaf(sj, x, cj * y);
-            }
-            // row rotations of A: rows (2i, 2i+1) live in lanes (2i, 2i+1) and take the rotation of lane i; the V lanes apply
-            // the identity (1, 0), exact because every entry of V is finite
-            const float pc = __shfl(c, lane >> 1), ps = __shfl(s, lane >> 1);
-            const float mc = isA ? pc : 1.f, ms = isA ? ((lane & 1) ? ps : -ps) : 0.f;
-            float out[JLD];
-#pragma unroll
-            for (int k = 0; k < JLD; ++k)
-                out[sigma_slot(k)] = fmaf(mc, row[k], dpp_xor1(row[k]) * ms); // + Brent-Luk column move (register renaming)
-#pragma unroll
-            for (int k = 0; k < JLD; ++k) row[k] = out[k];
-            if (isA) {
-#pragma unroll
-                for (int q4 = 0; q4 < JLD / 4; ++q4)
-                    reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
-            }
-            __syncthreads();
         }
-    }
-    // eigenvectors: the V lanes publish their rows (columns are back in slot order after every complete sweep)
-    if (isV) {
+        if (live) {
+            if (isRow) eig[(size_t)item * KP + r] = Ah[r * JLD + r];
+            if (r < K) {
+                float4 *o = reinterpret_cast<float4 *>(Vout + (size_t)item * (KP * JLD) + r * JLD);
 #pragma unroll
-        for (int q4 = 0; q4 < JLD / 4; ++q4)
-            reinterpret_cast<float4 *>(V0 + vrow * JLD)[q4] = make_float4(row[4 * q4], row[4 * q4 + 1], row[4 * q4 + 2], row[4 * q4 + 3]);
+                for (int q4 = 0; q4 < JLD / 4; ++q4) o[q4] = make_float4(vrow[4 * q4], vrow[4 * q4 + 1], vrow[4 * q4 + 2], vrow[4 * q4 + 3]);
+            }
+        }
+        wave_sync(); // the next pair reuses the LDS
     }
-    __syncthreads();
 }
 
-// out (LD layout) = V f(lambda) V^T ; f = max(0,.) (clamp) or 1/max(minEig,.) (inverse); A, V in the Jacobi (JLD) layout
-__device__ void rebuild27(float *out, const float *A, const float *V, float *fl, int lane, bool inverse, float min_eig);
 // JLD-layout copy of the lower triangle of M (LD layout), mirrored, padding row/column zeroed (what Eigen's
 // SelfAdjointEigenSolver reads)
 __device__ void to_jacobi_layout(float *J, const float *M, int lane)
@@ -193,6 +237,7 @@ __device__ inline float bcast_lane(float v, int k) { return __int_as_float(__bui
 
 __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
 {
+    LDS_POINTER(M);
     const int r = lane < K ? lane : 0;
     float m[K];
 #pragma unroll
@@ -234,6 +279,7 @@ __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
 // spectral fallback of inverse27 (LD layout in, LD layout out, no conversion)
 __device__ void jacobi27_inplace(float *A, float *V, float *prm /* 4 * KP/2 floats */, int lane)
 {
+    LDS_POINTER(A); LDS_POINTER(V); LDS_POINTER(prm);
     float *rc = prm, *rs = prm + KP / 2;
     int *rp = reinterpret_cast<int *>(prm + KP), *rq = rp + KP / 2;
     for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; V[r * LD + c] = (r == c) ? 1.f : 0.f; }
@@ -296,6 +342,7 @@ __device__ void jacobi27_inplace(float *A, float *V, float *prm /* 4 * KP/2 floa
 // M <- inverseSymmetricMatrix(M) (DenoisingUnit.cpp:578-604), in place.  scratch: S0, S1 (matrix sized), fl, prm (2*KP floats)
 __device__ void inverse27(float *M, float *S0, float *S1, float *fl, float *prm, int lane, float min_eig)
 {
+    LDS_POINTER(M); LDS_POINTER(S0); LDS_POINTER(S1); LDS_POINTER(fl); LDS_POINTER(prm);
     // backup for the spectral path, taken before the sweep destroys M: lower triangle mirrored, like Eigen's solver reads it
     for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; S0[r * LD + c] = M[(r >= c ? r : c) * LD + (r >= c ? c : r)]; }
     __syncthreads();
@@ -332,6 +379,8 @@ __device__ void noise_times27(float *out, const float *noise, const float *in, i
 template <bool TRANS_Y, bool SCALE>
 __device__ __attribute__((noinline)) void mfma27(float *out, int ldo, const float *X, int ldx, const float *Y, int ldy, const float *scale, int kdim, int lane)
 {
+    LDS_POINTER(out); LDS_POINTER(X); LDS_POINTER(Y);
+    if (SCALE) LDS_POINTER(scale);
     const int idx = lane & 31, kh = lane >> 5;
     v16f acc;
 #pragma unroll
@@ -351,16 +400,6 @@ __device__ __attribute__((noinline)) void mfma27(float *out, int ldo, const floa
         if (r < K && idx < K) out[r * ldo + idx] = acc[e];
     }
     __syncthreads();
-}
-
-__device__ void rebuild27(float *out, const float *A, const float *V, float *fl, int lane, bool inverse, float min_eig)
-{
-    if (lane < KP) {
-        float lam = A[lane * JLD + lane];
-        fl[lane] = inverse ? 1.f / fmaxf(min_eig, lam) : fmaxf(0.f, lam);
-    }
-    __syncthreads();
-    mfma27<true, true>(out, LD, V, JLD, V, JLD, fl, KP, lane);
 }
 
 // members are kept as 16-bit window codes ((dl + b) << 8 | (dc + b)): half the LDS of pixel indices, decoded with member_pixel()
@@ -418,6 +457,7 @@ __device__ inline void stage_store(float *chunk, const float (&pre)[STAGE_REGS],
 __device__ __attribute__((noinline)) void covariance27(float *A, float *Cm, float *chunk, const float *mean, const float *__restrict__ colors,
                                                        const uint16_t *mem, int p, int b, int n, int W, int lane)
 {
+    LDS_POINTER(A); LDS_POINTER(Cm); LDS_POINTER(chunk); LDS_POINTER(mean); LDS_POINTER(mem);
     {
         const int mi = lane & 31, mk = lane >> 5;
         const float my_mean = mi < K ? mean[mi] : 0.f;
@@ -458,6 +498,7 @@ __device__ __attribute__((noinline)) void final_chunk27(const float *Cm, const f
                                                         int W, int b, bool in_lds, int AW, int b1, float *accS, int *accC, float *sum,
                                                         int32_t *cnt, int lane)
 {
+    LDS_POINTER(Cm); LDS_POINTER(chunk); LDS_POINTER(mean); LDS_POINTER(mem); LDS_POINTER(accS); LDS_POINTER(accC);
         // D[r][j] = sum_k G2[r][k] * xc_j[k] (fma chain over k), lane l
         // feeds A = G2[l & 31][k] and B = xc of member l & 31, k = 2s + (l >> 5); it gets back components
         // r = (e & 3) + 8 (e >> 2) + 4 (l >> 5) of member l & 31
@@ -504,6 +545,7 @@ __device__ __attribute__((noinline)) void final_pass27(const float *Cm, float *c
                                                        const uint16_t *mem, int n, int p, int W, int b, bool in_lds, int AW, int b1,
                                                        float *accS, int *accC, float *sum, int32_t *cnt, int lane)
 {
+    LDS_POINTER(Cm); LDS_POINTER(chunk); LDS_POINTER(mean); LDS_POINTER(mem); LDS_POINTER(accS); LDS_POINTER(accC);
     float pre[STAGE_REGS];
     stage_load(pre, colors, mem, p, b, 0, min(CHUNK, n), W, lane);
     for (int i0 = 0; i0 < n; i0 += CHUNK) {
@@ -515,37 +557,47 @@ __device__ __attribute__((noinline)) void final_pass27(const float *Cm, float *c
     }
 }
 
-template <bool DBG>
+// Per processed pixel the estimate is three kernels; between them a pixel's state lives in a record in HBM (~9.9 KB):
+//   PHASE 1  k_bayes27<1>  members, noise / colour means, covariance C; writes  A = C - N (28 x 28, zero-padded), C, N, m
+//   (k_jacobi27_batch: eigen-decomposition of every A, two per wavefront)
+//   PHASE 2  k_bayes27<2>  reads C, N, m, eigenvalues and eigenvectors; clamp, inverses, Step 2, final estimate, aggregation.
+// Splitting costs ~20 KB of HBM traffic per pixel (nothing next to the ~300 us a pixel takes) and buys a solver that is not
+// tied to the LDS footprint and register pressure of the other phases (12 -> 24 matrices per CU, shared rotations).
+struct Records27 {
+    float *A, *V, *C, *aux, *eig; // [items][784], [items][784], [items][784], [items][AUX27], [items][28]
+};
+constexpr int AUX27 = 96; // noise 54, mean 27, padding
+
+template <int PHASE>
 __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                 const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
-                                                const int32_t *__restrict__ d_nlist, int *work, Geom27 g, float min_eig, float *sum,
+                                                int first_item, int nb_items, int *work, Geom27 g, float min_eig, Records27 rec, float *sum,
                                                 int32_t *cnt)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
-    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ; // A, V contiguous: reused as the aggregation window
+    // PHASE 1 has no use for V: three matrix buffers (15 wavefronts per CU instead of 12)
+    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = PHASE == 1 ? V : V + MSZ; // A, V contiguous: reused as the aggregation window
     float *chunk = Bm;                         // member-staging chunk: Bm is free while the clouds are streamed (mean/covariance, output)
-    float *cs = Bm + MSZ;                      // 2 x 28 floats (rotation parameters), read as float4: offsets are multiples of 16 bytes
+    float *cs = Bm + MSZ;                      // 2 x 28 floats (scratch of the spectral inverse), read as float4: offsets are multiples of 16 bytes
     float *noise = cs + 2 * KP;
     float *mean = noise + P * 6;
     float *fl = mean + K + 1;
     uint16_t *mem = reinterpret_cast<uint16_t *>(fl + KP);
 
-    // persistent wavefronts: the list length lives in device memory (no host round trip between the marking and this
-    // launch), items are handed out through an atomic counter
-    const int nlist = *d_nlist;
+    // persistent wavefronts: items are handed out through an atomic counter
   for (;;) {
-    int item = 0;
-    if (lane == 0) item = atomicAdd(work, 1);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= nlist) break;
-    DBG_T(0);
-    const int p = list[item];
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(work, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= nb_items) break;
+    const int p = list[first_item + slot];
     const int n = decode_members27(mask, p, g, mem, lane);
-    DBG_T(1);
-    const float n_inv = 1.f / (float)n;
     const int W = g.W;
+    float *recA = rec.A + (size_t)slot * MSZ, *recC = rec.C + (size_t)slot * MSZ, *recX = rec.aux + (size_t)slot * AUX27;
 
+  if (PHASE == 1) {
+    const float n_inv = 1.f / (float)n;
     // computeNoiseCovPatchesMean (:400-419) and empiricalMean (:500-509) in one sweep over the members, straight from global
     // memory: lanes 0..53 own one noise component, lanes 0..26 also one colour component.  The loads of 8 members are issued
     // back to back (independent addresses), the sums stay in member order.
@@ -572,27 +624,38 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
         if (do_mean) mean[lane] = accm * n_inv;
         __syncthreads();
     }
-    DBG_T(2);
-    DBG_T(3);
     // centerPointCloud + empiricalCovarianceMatrix (:511-536) on the matrix core: C = Xc^T Xc, two members per
     // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: a chain of fma in member order, i.e. the reference's sequential sum with the
     // product fused; A and B operands are the same centred value, so the result is bitwise symmetric).
     // Operand layout: lane l holds element i = l & 31 of member 2s + (l >> 5); rows/columns 27..31 are zero.
     covariance27(A, Cm, chunk, mean, colors, mem, p, g.b, n, W, lane);
-
-    // ---- Step 1 (:421-436): M1 = clamp(C - N) + N ; Cinv1 = inverse(M1)
-    DBG_T(4);
+    // ---- Step 1 (:421-436), first half: the matrix whose negative eigenvalues are clamped, C - N
     add_noise27(A, noise, lane, -1.f);
     to_jacobi_layout(Bm, A, lane);
-    {
-        jacobi27<DBG>(Bm, V, cs, lane, item);
-        DBG_T(5);
-        rebuild27(Bm, Bm, V, fl, lane, false, 0.f); // reads the eigenvalues (diagonal) before it overwrites Bm: M1 lives in Bm
+    for (int e = lane; e < MSZ / 4; e += 64) {
+        reinterpret_cast<float4 *>(recA)[e] = reinterpret_cast<const float4 *>(Bm)[e];
+        reinterpret_cast<float4 *>(recC)[e] = reinterpret_cast<const float4 *>(Cm)[e];
     }
+    if (lane < P * 6) recX[lane] = noise[lane];
+    if (lane < K) recX[P * 6 + lane] = mean[lane];
+    __syncthreads(); // the next item reuses the LDS
+  } else {
+    // ---- state of PHASE 1 and the eigen-decomposition
+    {
+        const float *recV = rec.V + (size_t)slot * MSZ;
+        for (int e = lane; e < MSZ / 4; e += 64) {
+            reinterpret_cast<float4 *>(Cm)[e] = reinterpret_cast<const float4 *>(recC)[e];
+            reinterpret_cast<float4 *>(V)[e] = reinterpret_cast<const float4 *>(recV)[e];
+        }
+        if (lane < P * 6) noise[lane] = recX[lane];
+        if (lane < K) mean[lane] = recX[P * 6 + lane];
+        if (lane < KP) fl[lane] = fmaxf(0.f, rec.eig[(size_t)slot * KP + lane]); // clampNegativeEigenValues (:606-630)
+        __syncthreads();
+    }
+    // ---- Step 1 (:421-436), second half: M1 = clamp(C - N) + N ; Cinv1 = inverse(M1)
+    mfma27<true, true>(Bm, LD, V, JLD, V, JLD, fl, KP, lane); // V max(0, lambda) V^T
     add_noise27(Bm, noise, lane, +1.f);
-    DBG_T(6);
     inverse27(Bm, A, V, fl, cs, lane, min_eig);
-    DBG_T(7);
     // ---- Step 2 (:438-453): the Step-1 estimates are xhat = x - G (x - m) with G = N Cinv1, hence their empirical
     // mean is m and their empirical covariance is F C F^T, F = I - G
     noise_times27(V, noise, Bm, lane, true);       // V  = F
@@ -606,10 +669,8 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; if (r < c) Bm[r * LD + c] = Cm[r * LD + c]; }
     __syncthreads();
     add_noise27(Bm, noise, lane, +1.f);
-    DBG_T(8);
     inverse27(Bm, A, V, fl, cs, lane, min_eig);
-    noise_times27(Cm, noise, Bm, lane, false);
-    DBG_T(9);     // Cm = G2 = N Cinv2
+    noise_times27(Cm, noise, Bm, lane, false);     // Cm = G2 = N Cinv2
 
     // ---- finalDenoisingMatrixMultiplication (:656-670) on the noisy patches centred on m, aggregateOutputPatches (:672-693).
     // Every patch of every member lies in the (side+2)^2 window around p: the contributions are first summed there in LDS
@@ -636,44 +697,53 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
             if (c != 0) atomicAdd(cnt + (base + (long long)wy * W + wx), c);
         }
     }
-    DBG_T(10);
-    if (DBG && item == bcd_dbg_item && lane == 0) bcd_dbg_cycles[11] = n;
     __syncthreads(); // the next item reuses the LDS
+  }
   }
 }
 
 } // namespace
 
+// LDS of the widest phase (PHASE 2: four matrix buffers)
 size_t bcd_bayes27_lds_bytes(int b)
 {
     int side = 2 * b + 1;
     return (size_t)(4 * MSZ + 2 * KP + P * 6 + (K + 1) + KP) * sizeof(float) + (((size_t)side * side * sizeof(uint16_t) + 15) & ~(size_t)15);
 }
 
-// workgroups (= wavefronts) of k_bayes27 one CU holds: LDS-bound, at most 3 per SIMD (148 VGPRs)
-int bcd_bayes27_blocks_per_cu(int b)
-{
-    size_t n = (size_t)160 * 1024 / bcd_bayes27_lds_bytes(b);
-    return (int)(n > 12 ? 12 : n);
-}
+// bytes of HBM one processed pixel needs between the phases (A, V, C, noise + mean, eigenvalues)
+size_t bcd_bayes27_record_bytes() { return (size_t)(3 * MSZ + AUX27 + KP) * sizeof(float); }
 
-hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, const int32_t *d_nlist,
-                              int *d_work, int blocks, int W, int H, int b, float min_eig, float *sum, int32_t *cnt, hipStream_t st)
+// Full estimate of items [first_item, first_item + nb_items) of `list`: three launches; `records` holds nb_items records
+// (bcd_bayes27_record_bytes() each), d_work three zeroed ints.
+hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int first_item, int nb_items,
+                              int *d_work, int num_cus, int W, int H, int b, float min_eig, float *records, float *sum,
+                              int32_t *cnt, hipStream_t st)
 {
-    if (blocks <= 0) return hipSuccess;
+    if (nb_items <= 0) return hipSuccess;
     Geom27 g;
     g.W = W; g.H = H; g.b = b; g.side = 2 * b + 1; g.words = (g.side * g.side + 31) / 32; g.maxS = g.side * g.side;
     if (g.words > 32) return hipErrorInvalidValue;
-    if (getenv("BCD_DBG_BAYES")) {
-        if (const char *e = getenv("BCD_DBG_ITEM")) { int v = atoi(e); (void)hipMemcpyToSymbol(HIP_SYMBOL(bcd_dbg_item), &v, sizeof(v)); }
-        hipLaunchKernelGGL(k_bayes27<true>, dim3(blocks), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, d_nlist, d_work, g, min_eig, sum, cnt);
-        long long h[24];
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(bcd_dbg_cycles), sizeof(h));
-        fprintf(stderr, "sweeps off2/dg2 x1e18:"); for (int i = 12; i < 24; ++i) fprintf(stderr, " %lld", h[i]); fprintf(stderr, "\n");
-        fprintf(stderr, "bayes27 dbg n=%lld: decode %lld noise %lld mean %lld cov %lld jacobi %lld rebuild %lld inv1 %lld step2mm %lld inv2 %lld final %lld total %lld\n", h[11], h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5], h[7]-h[6], h[8]-h[7], h[9]-h[8], h[10]-h[9], h[10]-h[0]);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(k_bayes27<false>, dim3(blocks), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, d_nlist, d_work, g, min_eig, sum, cnt);
+    Records27 rec;
+    rec.A = records;
+    rec.V = rec.A + (size_t)nb_items * MSZ;
+    rec.C = rec.V + (size_t)nb_items * MSZ;
+    rec.aux = rec.C + (size_t)nb_items * MSZ;
+    rec.eig = rec.aux + (size_t)nb_items * AUX27;
+    const size_t lds2 = bcd_bayes27_lds_bytes(b), lds1 = lds2 - MSZ * sizeof(float);
+    const int per_cu1 = (int)std::min<size_t>(16, (size_t)160 * 1024 / lds1), per_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / lds2);
+    hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
+                       d_work, g, min_eig, rec, sum, cnt);
+    hipLaunchKernelGGL(k_jacobi27_batch, dim3(std::min((nb_items + 1) / 2, num_cus * 12)), dim3(64), 0, st, rec.A, nb_items, d_work + 1, rec.eig, rec.V);
+    hipLaunchKernelGGL(k_bayes27<2>, dim3(std::min(nb_items, num_cus * per_cu2)), dim3(64), lds2, st, colors, pixcov, mask, list, first_item, nb_items,
+                       d_work + 2, g, min_eig, rec, sum, cnt);
+    return hipGetLastError();
+}
+
+// eigen-decomposition of n symmetric 27 x 27 matrices (28 x 28 zero-padded, row-major): persistent wavefronts, two matrices each
+hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blocks, float *eig, float *V, hipStream_t st)
+{
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_jacobi27_batch, dim3(blocks), dim3(64), 0, st, A, n, d_work, eig, V);
     return hipGetLastError();
 }

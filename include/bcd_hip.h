@@ -196,6 +196,11 @@ int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, con
 int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius,
                                      float *max_rel_dev, int64_t *count_mismatches, int *flags);
 
+/* the eigensolver of the Bayesian steps on its own (Eigen::SelfAdjointEigenSolver of DenoisingUnit.cpp:589,617 for 27 x 27 matrices):
+ * d_A = n symmetric matrices, 28 x 28 floats each, row-major, row / column 27 zero; d_eig[n][28] = eigenvalues (unordered, entry 27 = 0),
+ * d_V[n][28][28] = eigenvectors in columns, same order (rows 0..26 written); *ms = kernel time (may be NULL).  Parity / timing aid. */
+int bcd_hip_eig27_batch(bcd_hip_ctx *ctx, const float *d_A, int n, float *d_eig, float *d_V, float *ms);
+
 /* ---- host utilities (no device work) ----------------------------------------------------------- */
 /* the visiting order implied by (random_order, seed): main-pixel linear indices line*W+col in
  * visiting order, written to h_order[(W-2w)*(H-2w)].  random_order == 0 is the reference's

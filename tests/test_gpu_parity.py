@@ -687,3 +687,31 @@ def test_fast_similarity_path_is_the_default_and_reports_its_borderline_pairs(hi
     st = hipctx.stats(0)
     assert st.similarity_path == 1 and 0 <= st.borderline_pairs < 320 * 200
     assert np.isfinite(out.cpu().numpy()[1:-1, 1:-1]).all()
+
+
+@pytest.mark.gpu
+def test_batched_eigensolver_against_lapack(hipctx):
+    """bcd_hip_eig27_batch (the Jacobi solver of the Bayesian steps on its own, two matrices per wavefront): V diag(lambda) V^T
+    reconstructs the input, V is orthogonal, the eigenvalues are LAPACK's -- for an odd number of matrices (half-empty last pair),
+    an already diagonal matrix and a rank-one matrix"""
+    import torch
+    rng = np.random.default_rng(4)
+    n = 257
+    A = np.zeros((n, 28, 28), np.float32)
+    for i in range(n):
+        X = rng.standard_normal((int(rng.integers(28, 120)), 27)) * (0.02 + rng.random(27))
+        N = np.diag(rng.random(27) * 0.3)
+        A[i, :27, :27] = (np.cov(X.T) - N).astype(np.float32)
+    A[3, :27, :27] = np.diag(np.linspace(-1, 2, 27)).astype(np.float32)
+    v = rng.standard_normal(27).astype(np.float32)
+    A[5, :27, :27] = np.outer(v, v)
+    A = (A + A.transpose(0, 2, 1)) / 2
+    eig, V, _ = hipctx.eig27_batch(torch.from_numpy(A).cuda())
+    eig, V = eig.cpu().numpy().astype(np.float64), V.cpu().numpy().astype(np.float64)
+    for i in range(n):
+        a = A[i, :27, :27].astype(np.float64)
+        nrm = np.linalg.norm(a)
+        Vi = V[i, :27, :27]
+        assert np.linalg.norm((Vi * eig[i, :27]) @ Vi.T - a) / nrm < 1e-5, i
+        assert np.linalg.norm(Vi.T @ Vi - np.eye(27)) < 1e-5, i
+        assert np.max(np.abs(np.sort(eig[i, :27]) - np.linalg.eigvalsh(a))) / nrm < 1e-5, i
