@@ -89,12 +89,13 @@ __device__ inline float half_sum(float v)
 __global__ __launch_bounds__(64, 3) void k_jacobi27_batch(const float *__restrict__ Ain, int n, int *work,
                                                           float *__restrict__ eig, float *__restrict__ Vout)
 {
-    __shared__ float4 lds4[(2 * KP * JLD + 2 * KP) / 4];
+    __shared__ float4 lds4[(2 * KP * JLD + 4 * KP) / 4];
     float *Abuf = reinterpret_cast<float *>(lds4);
-    float *cs = Abuf + 2 * KP * JLD; // [matrix][28]
+    float *cs = Abuf + 2 * KP * JLD;  // [matrix][28]: per slot pair (-beta, alpha) of the current round
+    float *dv = cs + 2 * KP;          // [matrix][28]: scale of every slot (see below)
     const int lane = threadIdx.x, h = lane >> 5, r = lane & 31;
     float *Ah = Abuf + h * KP * JLD;
-    float *cs_h = cs + h * KP;
+    float *cs_h = cs + h * KP, *dv_h = dv + h * KP;
     const bool isRow = r < KP;
     const float *src = Ah + (isRow ? r : 0) * JLD;
     float *dst = Ah + (isRow ? sigma_slot(r) : 0) * JLD;
@@ -113,88 +114,131 @@ __global__ __launch_bounds__(64, 3) void k_jacobi27_batch(const float *__restric
                 if (!live) { const int e0 = 4 * e, rr = e0 / JLD, c0 = e0 - rr * JLD; v = make_float4(rr == c0, rr == c0 + 1, rr == c0 + 2, rr == c0 + 3); }
                 reinterpret_cast<float4 *>(Ah)[e] = v;
             }
+            if (isRow) dv_h[r] = 1.f;
         }
         wave_sync();
+        // Scaled ("fast") rotations: the matrices are kept as A = D A~ D and V = V~ D with a diagonal D (one scale per slot).
+        // J = [[c, s], [-s, c]] = [[1, t], [-t, 1]] diag(c, c), so rotating the slot pair (p, q) is
+        //     x' = x - beta y,  y' = y + alpha x   (beta = t d_q / d_p, alpha = t d_p / d_q)   and   d' = c d
+        // -- two fused multiply-adds per element pair instead of four operations; D is folded back into A~ and V~ at the start of
+        // every sweep (within a sweep a scale cannot fall below 2^(-27/2)).
         float vrow[JLD];
 #pragma unroll
         for (int k = 0; k < JLD; ++k) vrow[k] = (k == r) ? 1.f : 0.f; // V = identity
         for (int sweep = 0; sweep < 12; ++sweep) {
+            // fold the scales: A~ <- D A~ D, V~ <- V~ D, D <- I; off / diagonal norms of the true matrix on the way
             float off = 0.f, dg = 0.f;
-            for (int e = r; e < KP * JLD; e += 32) {
-                const int rr = e / JLD, c = e - rr * JLD;
-                const float v = Ah[e];
-                if (rr == c) dg = fmaf(v, v, dg); else off = fmaf(v, v, off);
-            }
-            off = half_sum(off);
-            dg = half_sum(dg);
-            if (__builtin_amdgcn_ballot_w64(!(off <= 1e-13f * dg)) == 0) break; // both matrices converged
-            for (int round = 0; round < KP - 1; ++round) {
-                // lanes 0..13 of each half: rotation of the slot pair (2 r, 2 r + 1); the other lanes compute on a harmless copy of pair 0
-                float c = 1.f, s_ = 0.f;
-                {
-                    const int p = r < KP / 2 ? 2 * r : 0, q = p + 1;
-                    const float apq = Ah[p * JLD + q], app = Ah[p * JLD + p], aqq = Ah[q * JLD + q];
-                    if (apq != 0.f) {
-                        // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working
-                        // precision (c^2 + s^2 = 1 +- 1e-7), not the exact minimiser
-                        float theta = (aqq - app) * __builtin_amdgcn_rcpf(2.f * apq);
-                        float t = __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.f)));
-                        t = theta < 0.f ? -t : t;
-                        c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
-                        s_ = t * c;
-                        if (!(fabsf(theta) < 1e18f)) { c = 1.f; s_ = 0.f; } // theta^2 overflows: the rotation is the identity to fp32
-                    }
+            {
+                float dk[JLD];
+#pragma unroll
+                for (int q4 = 0; q4 < JLD / 4; ++q4) {
+                    float4 w4 = reinterpret_cast<const float4 *>(dv_h)[q4];
+                    dk[4 * q4] = w4.x; dk[4 * q4 + 1] = w4.y; dk[4 * q4 + 2] = w4.z; dk[4 * q4 + 3] = w4.w;
                 }
+                const float dr = dv_h[isRow ? r : 0];
                 float row[JLD];
 #pragma unroll
                 for (int q4 = 0; q4 < JLD / 4; ++q4) {
                     float4 v = reinterpret_cast<const float4 *>(src)[q4];
                     row[4 * q4] = v.x; row[4 * q4 + 1] = v.y; row[4 * q4 + 2] = v.z; row[4 * q4 + 3] = v.w;
                 }
-                if (r < KP / 2) reinterpret_cast<float2 *>(cs_h)[r] = make_float2(c, s_);
+#pragma unroll
+                for (int k = 0; k < JLD; ++k) {
+                    row[k] *= dr * dk[k];
+                    vrow[k] *= dk[k];
+                    if (isRow) { if (k == r) dg = fmaf(row[k], row[k], dg); else off = fmaf(row[k], row[k], off); }
+                }
+                wave_sync(); // every lane has read the scales and its row
+                if (isRow) {
+#pragma unroll
+                    for (int q4 = 0; q4 < JLD / 4; ++q4)
+                        reinterpret_cast<float4 *>(Ah + r * JLD)[q4] = make_float4(row[4 * q4], row[4 * q4 + 1], row[4 * q4 + 2], row[4 * q4 + 3]);
+                    dv_h[r] = 1.f;
+                }
                 wave_sync();
-                float rot[JLD];
+            }
+            off = half_sum(off);
+            dg = half_sum(dg);
+            if (__builtin_amdgcn_ballot_w64(!(off <= 1e-13f * dg)) == 0) break; // both matrices converged
+            // fully unrolled: the Brent-Luk column move of the rows of V~ (a 27-cycle of the register names) costs no instruction
 #pragma unroll
-                for (int q4 = 0; q4 < JLD / 4; ++q4) {
-                    float4 w4 = reinterpret_cast<const float4 *>(cs_h)[q4];
-                    rot[4 * q4] = w4.x; rot[4 * q4 + 1] = w4.y; rot[4 * q4 + 2] = w4.z; rot[4 * q4 + 3] = w4.w;
-                }
-                const float2 pcs = reinterpret_cast<const float2 *>(cs_h)[isRow ? (r >> 1) : 0];
-                // column rotations of A: (x, y) <- (c x - s y, s x + c y) for every slot pair
-#pragma unroll
-                for (int j = 0; j < KP / 2; ++j) {
-                    const float cj = rot[2 * j], sj = rot[2 * j + 1];
-                    const float x = row[2 * j], y = row[2 * j + 1];
-                    row[2 * j] = fmaf(cj, x, -sj * y);
-                    row[2 * j + 1] = fmaf(sj, x, cj * y);
-                }
-                // row rotations of A: rows (2i, 2i+1) live in lanes (2i, 2i+1) of their half and take the rotation of pair i
+            for (int round = 0; round < KP - 1; ++round) {
+                // lanes 0..13 of each half: rotation of the slot pair (2 r, 2 r + 1); the other lanes compute on a harmless copy of pair 0
+                float mbeta = 0.f, alpha = 0.f;
                 {
-                    const float mc = pcs.x, ms = (r & 1) ? pcs.y : -pcs.y;
-                    float out[JLD];
-#pragma unroll
-                    for (int k = 0; k < JLD; ++k)
-                        out[sigma_slot(k)] = fmaf(mc, row[k], dpp_xor1(row[k]) * ms); // + Brent-Luk column move (register renaming)
-                    if (isRow) {
-#pragma unroll
-                        for (int q4 = 0; q4 < JLD / 4; ++q4)
-                            reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
+                    const int p = r < KP / 2 ? 2 * r : 0, q = p + 1;
+                    const float2 d2 = reinterpret_cast<const float2 *>(dv_h)[p >> 1];
+                    const float apq_s = Ah[p * JLD + q], app_s = Ah[p * JLD + p], aqq_s = Ah[q * JLD + q];
+                    float dp = d2.x, dq = d2.y;
+                    if (apq_s != 0.f) {
+                        const float apq = dp * dq * apq_s, app = dp * dp * app_s, aqq = dq * dq * aqq_s;
+                        // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working
+                        // precision (c^2 + s^2 = 1 +- 1e-7), not the exact minimiser
+                        const float theta = (aqq - app) * __builtin_amdgcn_rcpf(2.f * apq);
+                        if (fabsf(theta) < 1e18f) { // (otherwise theta^2 overflows: the rotation is the identity to fp32)
+                            float t = __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.f)));
+                            t = theta < 0.f ? -t : t;
+                            const float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
+                            const float ratio = dq * __builtin_amdgcn_rcpf(dp);
+                            mbeta = -t * ratio;
+                            alpha = t * __builtin_amdgcn_rcpf(ratio);
+                            dp *= c;
+                            dq *= c;
+                        }
                     }
-                }
-                // the same column rotations (and column move) on the rows of V
-                {
-                    float out[JLD];
+                    float row[JLD];
+#pragma unroll
+                    for (int q4 = 0; q4 < JLD / 4; ++q4) {
+                        float4 v = reinterpret_cast<const float4 *>(src)[q4];
+                        row[4 * q4] = v.x; row[4 * q4 + 1] = v.y; row[4 * q4 + 2] = v.z; row[4 * q4 + 3] = v.w;
+                    }
+                    if (r < KP / 2) {
+                        reinterpret_cast<float2 *>(cs_h)[r] = make_float2(mbeta, alpha);
+                        dv_h[sigma_slot(p)] = dp; // the scales move with their slots
+                        dv_h[sigma_slot(q)] = dq;
+                    }
+                    wave_sync();
+                    float rot[JLD];
+#pragma unroll
+                    for (int q4 = 0; q4 < JLD / 4; ++q4) {
+                        float4 w4 = reinterpret_cast<const float4 *>(cs_h)[q4];
+                        rot[4 * q4] = w4.x; rot[4 * q4 + 1] = w4.y; rot[4 * q4 + 2] = w4.z; rot[4 * q4 + 3] = w4.w;
+                    }
+                    const float2 pcs = reinterpret_cast<const float2 *>(cs_h)[isRow ? (r >> 1) : 0];
+                    // column rotations of A~
 #pragma unroll
                     for (int j = 0; j < KP / 2; ++j) {
-                        const float cj = rot[2 * j], sj = rot[2 * j + 1];
-                        const float x = vrow[2 * j], y = vrow[2 * j + 1];
-                        out[sigma_slot(2 * j)] = fmaf(cj, x, -sj * y);
-                        out[sigma_slot(2 * j + 1)] = fmaf(sj, x, cj * y);
+                        const float x = row[2 * j], y = row[2 * j + 1];
+                        row[2 * j] = fmaf(rot[2 * j], y, x);
+                        row[2 * j + 1] = fmaf(rot[2 * j + 1], x, y);
                     }
+                    // row rotations of A~: rows (2i, 2i+1) live in lanes (2i, 2i+1) of their half and take the rotation of pair i
+                    {
+                        const float ms = (r & 1) ? pcs.y : pcs.x;
+                        float out[JLD];
 #pragma unroll
-                    for (int k = 0; k < JLD; ++k) vrow[k] = out[k];
+                        for (int k = 0; k < JLD; ++k)
+                            out[sigma_slot(k)] = fmaf(ms, dpp_xor1(row[k]), row[k]); // + Brent-Luk column move (register renaming)
+                        if (isRow) {
+#pragma unroll
+                            for (int q4 = 0; q4 < JLD / 4; ++q4)
+                                reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
+                        }
+                    }
+                    // the same column rotations (and column move) on the rows of V~
+                    {
+                        float out[JLD];
+#pragma unroll
+                        for (int j = 0; j < KP / 2; ++j) {
+                            const float x = vrow[2 * j], y = vrow[2 * j + 1];
+                            out[sigma_slot(2 * j)] = fmaf(rot[2 * j], y, x);
+                            out[sigma_slot(2 * j + 1)] = fmaf(rot[2 * j + 1], x, y);
+                        }
+#pragma unroll
+                        for (int k = 0; k < JLD; ++k) vrow[k] = out[k];
+                    }
                 }
-                wave_sync(); // the rows of A are back in LDS before the next round reads its pivots
+                wave_sync(); // the rows of A~ are back in LDS before the next round reads its pivots
             }
         }
         if (live) {
