@@ -53,7 +53,7 @@ def build_hip(verbose=False):
                 print(out)
     so = os.path.join(LIB, "libbcd_hip.so")
     if _newer(so, objs):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-L/opt/rocm/lib", "-lrccl"])
     return so
 
 

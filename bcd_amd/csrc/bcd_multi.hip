@@ -1,0 +1,507 @@
+// bcd_multi.hip -- one frame over several GPUs of a node, native driver behind the C ABI (bcd_hip_multi_*).
+//
+// The reference is single-process and single-device; this is the build's own decomposition, the same one
+// bcd_amd/tiling.py describes and tests/ checks against the single-GPU frame:
+//   * the frame is cut into horizontal bands of main pixels whose boundaries are multiples of 2^(S-1) lines, so every pyramid
+//     level of a band is built from exactly the 2x2 blocks the full frame would use (MultiscaleDenoiser.cpp:256-266);
+//   * a rank (one host thread + one device) holds, per scale, its band plus (b + w) halo lines of INPUT on each interior side
+//     -- no input exchange at run time -- and rebuilds the pyramid for its band;
+//   * per scale (one host thread, HIP stream and engine context each, like the scales of bcd_hip_denoise): similar-patch
+//     masks, the marking fixed point in the visiting order of the WHOLE frame (keys are functions of the global pixel index;
+//     the |S| and the states of the b boundary lines travel between marking batches, one all-reduced integer ends the
+//     iteration), the Bayesian estimate, then the (b + w) accumulator halo lines travel and the band is finalised;
+//   * two lines of every unmerged output and one line of every merged output travel for the merges at the band edges.
+// The result is the single-GPU frame to fp32 round-off for every -m / -r setting.
+//
+// Transport: RCCL point-to-point (ncclSend / ncclRecv grouped per neighbour exchange, one communicator per scale so that the
+// scales' exchanges do not order each other; xGMI links between neighbouring devices) when the ranks sit on distinct devices;
+// ranks that share a device (virtual split, tests on a one-GPU box) exchange through device-to-device copies and host barriers.
+#include "../../include/bcd_hip.h"
+#include "bcd_common.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr int MAX_RANKS = 64;
+constexpr int MAX_S = 8;
+
+// ---- partition bookkeeping (bcd_amd/tiling.py: BandGeometry) -------------------------------------------------------
+struct ScaleBand {
+    int W, H;       // full-frame size at this scale
+    int own0, own1; // owned lines (global, this scale)
+    int loc0, loc1; // locally held lines
+};
+
+struct Geometry {
+    int W, H, S, b, w, world, halo, align;
+    std::vector<int> bounds;
+    bool init(int W_, int H_, int S_, int b_, int w_, int world_, std::string &err)
+    {
+        W = W_; H = H_; S = S_; b = b_; w = w_; world = world_;
+        halo = b + w;
+        align = 1 << (S - 1);
+        const int units = H / align;
+        if (units < world) { err = "frame too small to be split into that many bands"; return false; }
+        bounds.clear();
+        for (int r = 0; r < world; ++r) bounds.push_back((int)((long long)units * r / world) * align);
+        bounds.push_back(H);
+        for (int r = 0; r < world; ++r) {
+            int o0, o1;
+            owned(r, S - 1, o0, o1);
+            if (world > 1 && o1 - o0 < std::max(halo, 2)) { err = "a band owns fewer lines than the halo at the coarsest scale: use fewer devices"; return false; }
+        }
+        return true;
+    }
+    void owned(int rank, int s, int &o0, int &o1) const
+    {
+        o0 = bounds[rank] >> s;
+        o1 = rank == world - 1 ? (H >> s) : bounds[rank + 1] >> s;
+    }
+    void bands(int rank, ScaleBand *out) const
+    {
+        for (int s = S - 1; s >= 0; --s) {
+            int o0, o1;
+            owned(rank, s, o0, o1);
+            const int Hs = H >> s;
+            int l0 = rank > 0 ? std::max(0, o0 - halo) : 0;
+            int l1 = rank < world - 1 ? std::min(Hs, o1 + halo) : Hs;
+            if (s < S - 1) {
+                l0 = std::min(l0, 2 * out[s + 1].loc0);
+                l1 = std::max(l1, std::min(Hs, 2 * out[s + 1].loc1));
+                if (rank == world - 1) l1 = Hs;
+            }
+            if (l0 % 2) --l0; // merges map local line l / 2 to the coarser level
+            out[s] = ScaleBand{ W >> s, Hs, o0, o1, l0, l1 };
+        }
+    }
+};
+
+// ---- reusable host barrier with an abort flag ------------------------------------------------------------------------
+struct HostBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int count = 0, generation = 0, parties = 1;
+    std::atomic<bool> *abort_flag = nullptr;
+    bool wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const int gen = generation;
+        if (++count == parties) {
+            count = 0;
+            ++generation;
+            cv.notify_all();
+            return !abort_flag->load();
+        }
+        while (gen == generation && !abort_flag->load()) cv.wait_for(lk, std::chrono::milliseconds(50));
+        return !abort_flag->load();
+    }
+};
+
+struct DBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int device = 0;
+    bool ensure(size_t n)
+    {
+        if (bytes >= n && p) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        if (hipMalloc(&p, n + 256) != hipSuccess) return false;
+        bytes = n + 256;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+} // namespace
+
+struct bcd_hip_multi {
+    int n = 0;
+    int devices[MAX_RANKS];
+    bool use_rccl = false;
+    std::mutex err_mutex;
+    std::string err;
+    std::atomic<bool> abort_flag{ false };
+    // per rank: one context per scale + one for the pyramid / merges; channel c = scale (c < S) or S (the tail)
+    bcd_hip_ctx *ctx[MAX_RANKS][MAX_S + 1];
+    hipStream_t stream[MAX_RANKS][MAX_S + 1];
+    ncclComm_t comm[MAX_S + 1][MAX_RANKS];
+    bool comm_ready[MAX_S + 1];
+    HostBarrier barrier[MAX_S + 1];
+    // in-process transport: what every rank offers its neighbours in the current exchange, per channel
+    struct Offer { const void *up = nullptr, *down = nullptr; long long value = 0; };
+    Offer offer[MAX_S + 1][MAX_RANKS];
+    // grow-only device buffers: [rank][scale][kind]
+    enum { IN_COL, IN_NS, IN_HIST, IN_COV, OUT, PIXCOV, MASK, NSIM, STATE, SUM, CNT, RX_UP_S, RX_UP_C, RX_DN_S, RX_DN_C, NBUF };
+    DBuf buf[MAX_RANKS][MAX_S][NBUF];
+    long long *d_red[MAX_RANKS][MAX_S + 1]; // all-reduce scratch (RCCL transport)
+    bcd_hip_multi_stats stats;
+};
+
+namespace {
+
+void fail(bcd_hip_multi *m, const std::string &msg)
+{
+    {
+        std::lock_guard<std::mutex> lk(m->err_mutex);
+        if (m->err.empty()) m->err = msg;
+    }
+    m->abort_flag.store(true);
+}
+
+#define MCHK(m, rank, expr)                                                                                            \
+    do {                                                                                                               \
+        hipError_t e__ = (expr);                                                                                       \
+        if (e__ != hipSuccess) { fail((m), std::string("rank ") + std::to_string(rank) + ": " #expr ": " + hipGetErrorString(e__)); return false; } \
+    } while (0)
+#define ECHK(m, rank, c, expr)                                                                                         \
+    do {                                                                                                               \
+        int rc__ = (expr);                                                                                             \
+        if (rc__ != BCD_HIP_OK) { fail((m), std::string("rank ") + std::to_string(rank) + ": " #expr ": " + bcd_hip_last_error(c)); return false; } \
+    } while (0)
+
+// one neighbour exchange on channel `ch`: `bytes_*` to / from the rank above (up) and below (down); null pointers at the borders.
+// The data must have been produced on stream[rank][ch]; on return the received data is ordered before later work of that stream.
+bool exchange(bcd_hip_multi *m, int rank, int ch, const void *send_up, void *recv_up, size_t bytes_up, const void *send_down, void *recv_down,
+              size_t bytes_down)
+{
+    hipStream_t st = m->stream[rank][ch];
+    const bool up = rank > 0, down = rank < m->n - 1;
+    if (m->use_rccl) {
+        ncclResult_t r = ncclGroupStart();
+        if (r == ncclSuccess && up) { r = ncclSend(send_up, bytes_up, ncclChar, rank - 1, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(recv_up, bytes_up, ncclChar, rank - 1, m->comm[ch][rank], st); }
+        if (r == ncclSuccess && down) { r = ncclSend(send_down, bytes_down, ncclChar, rank + 1, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(recv_down, bytes_down, ncclChar, rank + 1, m->comm[ch][rank], st); }
+        const ncclResult_t e = ncclGroupEnd();
+        if (r != ncclSuccess || e != ncclSuccess) { fail(m, std::string("RCCL exchange failed: ") + ncclGetErrorString(r != ncclSuccess ? r : e)); return false; }
+        return true;
+    }
+    // in-process transport: publish, rendezvous, copy from the neighbours' buffers, rendezvous (buffers may be reused afterwards)
+    MCHK(m, rank, hipStreamSynchronize(st));
+    m->offer[ch][rank].up = send_up;
+    m->offer[ch][rank].down = send_down;
+    if (!m->barrier[ch].wait()) return false;
+    if (up) MCHK(m, rank, hipMemcpyAsync(recv_up, m->offer[ch][rank - 1].down, bytes_up, hipMemcpyDefault, st));
+    if (down) MCHK(m, rank, hipMemcpyAsync(recv_down, m->offer[ch][rank + 1].up, bytes_down, hipMemcpyDefault, st));
+    MCHK(m, rank, hipStreamSynchronize(st));
+    return m->barrier[ch].wait();
+}
+
+// sum of one integer over all ranks (channel ch); every rank gets the total
+bool allreduce(bcd_hip_multi *m, int rank, int ch, long long *value)
+{
+    if (m->use_rccl) {
+        hipStream_t st = m->stream[rank][ch];
+        MCHK(m, rank, hipMemcpyAsync(m->d_red[rank][ch], value, sizeof(long long), hipMemcpyHostToDevice, st));
+        const ncclResult_t r = ncclAllReduce(m->d_red[rank][ch], m->d_red[rank][ch], 1, ncclInt64, ncclSum, m->comm[ch][rank], st);
+        if (r != ncclSuccess) { fail(m, std::string("RCCL all-reduce failed: ") + ncclGetErrorString(r)); return false; }
+        MCHK(m, rank, hipMemcpyAsync(value, m->d_red[rank][ch], sizeof(long long), hipMemcpyDeviceToHost, st));
+        MCHK(m, rank, hipStreamSynchronize(st));
+        return true;
+    }
+    m->offer[ch][rank].value = *value;
+    if (!m->barrier[ch].wait()) return false;
+    long long total = 0;
+    for (int r = 0; r < m->n; ++r) total += m->offer[ch][r].value;
+    if (!m->barrier[ch].wait()) return false;
+    *value = total;
+    return true;
+}
+
+struct Job {
+    bcd_hip_multi *m;
+    const float *h_col, *h_ns, *h_hist, *h_cov;
+    float *h_out;
+    int W, H, D, S;
+    bcd_hip_params prm;
+    Geometry geom;
+};
+
+// ---- one scale of one rank: masks, frame-ordered marking, estimate, accumulator halos, finalisation -----------------------
+bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
+{
+    bcd_hip_multi *m = job.m;
+    if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
+    bcd_hip_ctx *c = m->ctx[rank][s];
+    hipStream_t st = m->stream[rank][s];
+    const Geometry &g = job.geom;
+    const ScaleBand &sb = bands[s];
+    const bool up = rank > 0, down = rank < g.world - 1;
+    const int W = sb.W, D = job.D, b = g.b, w = g.w, halo = g.halo;
+    const int o0 = sb.own0 - sb.loc0, o1 = sb.own1 - sb.loc0; // owned lines, local indices
+    const int a0 = up ? o0 - halo : 0, a1 = down ? o1 + halo : sb.loc1 - sb.loc0; // the sub-band this scale works on
+    const int rows = a1 - a0, r0 = o0 - a0, r1 = o1 - a0;
+    const int row_offset = sb.loc0 + a0;
+    const uint32_t seed = bcd_hip_scale_seed(job.prm.order_seed, s);
+    auto B = [&](int kind) -> DBuf & { return m->buf[rank][s][kind]; };
+    const size_t npix = (size_t)rows * W;
+    const int side = 2 * b + 1, words = (side * side + 31) / 32;
+    for (int k : { (int)bcd_hip_multi::PIXCOV, (int)bcd_hip_multi::MASK, (int)bcd_hip_multi::NSIM, (int)bcd_hip_multi::STATE, (int)bcd_hip_multi::SUM,
+                   (int)bcd_hip_multi::CNT, (int)bcd_hip_multi::RX_UP_S, (int)bcd_hip_multi::RX_UP_C, (int)bcd_hip_multi::RX_DN_S, (int)bcd_hip_multi::RX_DN_C }) {
+        size_t bytes = 0;
+        switch (k) {
+        case bcd_hip_multi::PIXCOV: bytes = npix * 6 * 4; break;
+        case bcd_hip_multi::MASK: bytes = npix * words * 4; break;
+        case bcd_hip_multi::NSIM: bytes = npix * 4; break;
+        case bcd_hip_multi::STATE: bytes = npix; break;
+        case bcd_hip_multi::SUM: bytes = npix * 12; break;
+        case bcd_hip_multi::CNT: bytes = npix * 4; break;
+        case bcd_hip_multi::RX_UP_S: case bcd_hip_multi::RX_DN_S: bytes = (size_t)halo * W * 12; break;
+        default: bytes = (size_t)halo * W * 4; break;
+        }
+        if (!B(k).ensure(bytes)) { fail(m, "out of device memory"); return false; }
+    }
+    const float *col = (const float *)B(bcd_hip_multi::IN_COL).p + (size_t)a0 * W * 3;
+    const float *ns = (const float *)B(bcd_hip_multi::IN_NS).p + (size_t)a0 * W;
+    const float *hist = (const float *)B(bcd_hip_multi::IN_HIST).p + (size_t)a0 * W * D;
+    const float *cov = (const float *)B(bcd_hip_multi::IN_COV).p + (size_t)a0 * W * 6;
+    float *pixcov = (float *)B(bcd_hip_multi::PIXCOV).p;
+    uint32_t *mask = (uint32_t *)B(bcd_hip_multi::MASK).p;
+    int32_t *nsim = (int32_t *)B(bcd_hip_multi::NSIM).p;
+    uint8_t *state = (uint8_t *)B(bcd_hip_multi::STATE).p;
+    float *sum = (float *)B(bcd_hip_multi::SUM).p;
+    int32_t *cnt = (int32_t *)B(bcd_hip_multi::CNT).p;
+
+    ECHK(m, rank, c, bcd_hip_pixel_cov(c, cov, ns, W, rows, pixcov));
+    ECHK(m, rank, c, bcd_hip_similarity_masks(c, hist, ns, W, rows, D, w, b, job.prm.hist_dist_threshold, mask, nsim));
+    if (job.prm.marked_skip_probability > 0.f && g.world > 1) {
+        // |S| of the b boundary lines comes from their owner (locally their windows are cut by the band edge)
+        if (!exchange(m, rank, s, nsim + (size_t)r0 * W, up ? nsim + (size_t)(r0 - b) * W : nullptr, (size_t)b * W * 4,
+                      nsim + (size_t)(r1 - b) * W, down ? nsim + (size_t)r1 * W : nullptr, (size_t)b * W * 4)) return false;
+    }
+    ECHK(m, rank, c, bcd_hip_active_init(c, nsim, W, rows, w, r0, r1, job.prm.marked_skip_probability, seed, row_offset, state));
+    int rounds = 0;
+    if (job.prm.marked_skip_probability > 0.f) {
+        long long before = -1;
+        for (;;) {
+            if (g.world > 1 && !exchange(m, rank, s, state + (size_t)r0 * W, up ? state + (size_t)(r0 - b) * W : nullptr, (size_t)b * W,
+                                         state + (size_t)(r1 - b) * W, down ? state + (size_t)r1 * W : nullptr, (size_t)b * W)) return false;
+            int32_t undecided = 0;
+            ECHK(m, rank, c, bcd_hip_active_step(c, mask, nsim, W, rows, w, b, r0, r1, job.prm.use_random_pixel_order, seed, row_offset,
+                                                  rounds == 0 && job.prm.marked_skip_probability >= 1.f, state, &undecided));
+            ++rounds;
+            long long total = undecided;
+            if (g.world > 1 && !allreduce(m, rank, s, &total)) return false;
+            if (total == 0) break;
+            if (before >= 0 && total >= before && rounds > 4 * (W + sb.H) + 64) { fail(m, "marking fixed point made no progress"); return false; }
+            before = total;
+        }
+    }
+    // halo lines are processed by their owner
+    if (r0 > 0) MCHK(m, rank, hipMemsetAsync(state, 0, (size_t)r0 * W, st));
+    if (r1 < rows) MCHK(m, rank, hipMemsetAsync(state + (size_t)r1 * W, 0, (size_t)(rows - r1) * W, st));
+    MCHK(m, rank, hipMemsetAsync(sum, 0, npix * 12, st));
+    MCHK(m, rank, hipMemsetAsync(cnt, 0, npix * 4, st));
+    ECHK(m, rank, c, bcd_hip_bayes_accumulate(c, col, pixcov, mask, nsim, state, W, rows, w, b, job.prm.min_eigen_value, sum, cnt));
+    // accumulator halos: the (b + w) lines written outside the owned band belong to the neighbours
+    float *rx_us = (float *)B(bcd_hip_multi::RX_UP_S).p, *rx_ds = (float *)B(bcd_hip_multi::RX_DN_S).p;
+    int32_t *rx_uc = (int32_t *)B(bcd_hip_multi::RX_UP_C).p, *rx_dc = (int32_t *)B(bcd_hip_multi::RX_DN_C).p;
+    if (g.world > 1) {
+        if (!exchange(m, rank, s, sum, rx_us, (size_t)halo * W * 12, sum + (size_t)(rows - halo) * W * 3, rx_ds, (size_t)halo * W * 12)) return false;
+        if (!exchange(m, rank, s, cnt, rx_uc, (size_t)halo * W * 4, cnt + (size_t)(rows - halo) * W, rx_dc, (size_t)halo * W * 4)) return false;
+    }
+    float *out = (float *)B(bcd_hip_multi::OUT).p;
+    ECHK(m, rank, c, bcd_hip_finalize_band(c, sum + (size_t)r0 * W * 3, cnt + (size_t)r0 * W, W, r1 - r0, halo, up ? rx_us : nullptr, up ? rx_uc : nullptr,
+                                           down ? rx_ds : nullptr, down ? rx_dc : nullptr, out + (size_t)o0 * W * 3));
+    MCHK(m, rank, hipStreamSynchronize(st));
+    if (rank == 0) m->stats.marking_rounds[s] = rounds;
+    return true;
+}
+
+// ---- one rank: inputs, pyramid, the scales (concurrently), output halos and merges, result ---------------------------------
+bool rank_worker(const Job &job, int rank)
+{
+    bcd_hip_multi *m = job.m;
+    if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
+    const Geometry &g = job.geom;
+    const int S = g.S, D = job.D;
+    ScaleBand bands[MAX_S];
+    g.bands(rank, bands);
+    const bool up = rank > 0, down = rank < g.world - 1;
+    bcd_hip_ctx *cm = m->ctx[rank][S];
+    hipStream_t sm = m->stream[rank][S];
+    auto B = [&](int s, int kind) -> DBuf & { return m->buf[rank][s][kind]; };
+    // ---- inputs of the band (host -> device) and local pyramid (MultiscaleDenoiser.cpp:41-53)
+    for (int s = 0; s < S; ++s) {
+        const size_t np = (size_t)(bands[s].loc1 - bands[s].loc0) * bands[s].W;
+        if (!B(s, bcd_hip_multi::IN_COL).ensure(np * 12) || !B(s, bcd_hip_multi::IN_NS).ensure(np * 4) || !B(s, bcd_hip_multi::IN_HIST).ensure(np * D * 4) ||
+            !B(s, bcd_hip_multi::IN_COV).ensure(np * 24) || !B(s, bcd_hip_multi::OUT).ensure(np * 12)) { fail(m, "out of device memory"); return false; }
+    }
+    {
+        const size_t first = (size_t)bands[0].loc0 * job.W, np = (size_t)(bands[0].loc1 - bands[0].loc0) * job.W;
+        MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_COL).p, job.h_col + first * 3, np * 12, hipMemcpyHostToDevice, sm));
+        MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_NS).p, job.h_ns + first, np * 4, hipMemcpyHostToDevice, sm));
+        MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_HIST).p, job.h_hist + first * D, np * D * 4, hipMemcpyHostToDevice, sm));
+        MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_COV).p, job.h_cov + first * 6, np * 24, hipMemcpyHostToDevice, sm));
+    }
+    for (int s = 1; s < S; ++s) {
+        const ScaleBand &prev = bands[s - 1], &cur = bands[s];
+        const int a = 2 * cur.loc0 - prev.loc0, rows = 2 * (cur.loc1 - cur.loc0);
+        const float *pc = (const float *)B(s - 1, bcd_hip_multi::IN_COL).p + (size_t)a * prev.W * 3;
+        const float *pn = (const float *)B(s - 1, bcd_hip_multi::IN_NS).p + (size_t)a * prev.W;
+        const float *ph = (const float *)B(s - 1, bcd_hip_multi::IN_HIST).p + (size_t)a * prev.W * D;
+        const float *pv = (const float *)B(s - 1, bcd_hip_multi::IN_COV).p + (size_t)a * prev.W * 6;
+        ECHK(m, rank, cm, bcd_hip_downscale_avg(cm, pc, prev.W, rows, 3, (float *)B(s, bcd_hip_multi::IN_COL).p));
+        ECHK(m, rank, cm, bcd_hip_downscale_sum(cm, pn, prev.W, rows, 1, (float *)B(s, bcd_hip_multi::IN_NS).p));
+        ECHK(m, rank, cm, bcd_hip_downscale_sum(cm, ph, prev.W, rows, D, (float *)B(s, bcd_hip_multi::IN_HIST).p));
+        ECHK(m, rank, cm, bcd_hip_downscale_cov(cm, pv, pn, prev.W, rows, (float *)B(s, bcd_hip_multi::IN_COV).p));
+    }
+    MCHK(m, rank, hipStreamSynchronize(sm));
+    // ---- the scales are independent until the merges: one thread, stream and context each
+    {
+        std::vector<std::thread> th;
+        std::vector<char> ok(S, 1);
+        for (int s = 1; s < S; ++s) th.emplace_back([&, s]() { ok[s] = scale_worker(job, rank, s, bands) ? 1 : 0; });
+        ok[0] = scale_worker(job, rank, 0, bands) ? 1 : 0;
+        for (auto &t : th) t.join();
+        if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
+        for (int s = 0; s < S; ++s)
+            if (!ok[s]) { m->abort_flag.store(true); return false; }
+    }
+    // ---- two lines of every unmerged finer output (hi - up(down(hi)) at the band edge), one line of the coarsest (up(lo))
+    auto out_rows = [&](int s, int local_line) { return (float *)B(s, bcd_hip_multi::OUT).p + (size_t)local_line * bands[s].W * 3; };
+    if (S > 1 && g.world > 1) {
+        for (int s = 0; s < S; ++s) {
+            const int n = s < S - 1 ? 2 : 1, o0 = bands[s].own0 - bands[s].loc0, o1 = bands[s].own1 - bands[s].loc0;
+            const size_t bytes = (size_t)n * bands[s].W * 12;
+            if (!exchange(m, rank, S, out_rows(s, o0), up ? out_rows(s, o0 - n) : nullptr, bytes, out_rows(s, o1 - n), down ? out_rows(s, o1) : nullptr, bytes)) return false;
+        }
+    }
+    // ---- merges coarse to fine (MultiscaleDenoiser.cpp:453-466); between two merges one line of the merged output travels
+    for (int s = S - 2; s >= 0; --s) {
+        const ScaleBand &sb = bands[s], &nb = bands[s + 1];
+        const int o0 = sb.own0 - sb.loc0, o1 = sb.own1 - sb.loc0;
+        const int m0 = up ? o0 - 2 : o0, m1 = down ? o1 + 2 : o1;
+        const int lo0 = (sb.loc0 + m0) / 2 - nb.loc0;
+        ECHK(m, rank, cm, bcd_hip_merge(cm, out_rows(s, m0), sb.W, m1 - m0, out_rows(s + 1, lo0), 3));
+        if (s > 0 && g.world > 1) {
+            const size_t bytes = (size_t)sb.W * 12;
+            if (!exchange(m, rank, S, out_rows(s, o0), up ? out_rows(s, o0 - 1) : nullptr, bytes, out_rows(s, o1 - 1), down ? out_rows(s, o1) : nullptr, bytes)) return false;
+        }
+    }
+    // ---- owned lines of the result
+    {
+        const int o0 = bands[0].own0 - bands[0].loc0;
+        MCHK(m, rank, hipMemcpyAsync(job.h_out + (size_t)bands[0].own0 * job.W * 3, out_rows(0, o0), (size_t)(bands[0].own1 - bands[0].own0) * job.W * 12,
+                                     hipMemcpyDeviceToHost, sm));
+        MCHK(m, rank, hipStreamSynchronize(sm));
+    }
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+int bcd_hip_multi_create(bcd_hip_multi **out, const int *devices, int n_ranks)
+{
+    if (!out || !devices || n_ranks < 1 || n_ranks > MAX_RANKS) return BCD_HIP_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BCD_HIP_EDEVICE;
+    bcd_hip_multi *m = new (std::nothrow) bcd_hip_multi();
+    if (!m) return BCD_HIP_ENOMEM;
+    m->n = n_ranks;
+    bool distinct = true;
+    for (int r = 0; r < n_ranks; ++r) {
+        if (devices[r] < 0 || devices[r] >= ndev) { delete m; return BCD_HIP_EINVAL; }
+        m->devices[r] = devices[r];
+        for (int q = 0; q < r; ++q) distinct = distinct && devices[q] != devices[r];
+    }
+    m->use_rccl = distinct && n_ranks > 1;
+    memset(m->ctx, 0, sizeof(m->ctx));
+    memset(m->stream, 0, sizeof(m->stream));
+    memset(m->d_red, 0, sizeof(m->d_red));
+    memset(m->comm_ready, 0, sizeof(m->comm_ready));
+    memset(&m->stats, 0, sizeof(m->stats));
+    for (int c = 0; c <= MAX_S; ++c) { m->barrier[c].parties = n_ranks; m->barrier[c].abort_flag = &m->abort_flag; }
+    m->stats.n_ranks = n_ranks;
+    m->stats.transport = m->use_rccl ? 1 : 0;
+    *out = m;
+    return BCD_HIP_OK;
+}
+
+void bcd_hip_multi_destroy(bcd_hip_multi *m)
+{
+    if (!m) return;
+    for (int c = 0; c <= MAX_S; ++c)
+        if (m->comm_ready[c])
+            for (int r = 0; r < m->n; ++r) (void)ncclCommDestroy(m->comm[c][r]);
+    for (int r = 0; r < m->n; ++r) {
+        (void)hipSetDevice(m->devices[r]);
+        for (int s = 0; s < MAX_S; ++s)
+            for (int k = 0; k < bcd_hip_multi::NBUF; ++k) m->buf[r][s][k].release();
+        for (int c = 0; c <= MAX_S; ++c) {
+            if (m->d_red[r][c]) (void)hipFree(m->d_red[r][c]);
+            if (m->ctx[r][c]) bcd_hip_ctx_destroy(m->ctx[r][c]);
+            if (m->stream[r][c]) (void)hipStreamDestroy(m->stream[r][c]);
+        }
+    }
+    delete m;
+}
+
+const char *bcd_hip_multi_last_error(const bcd_hip_multi *m) { return m ? m->err.c_str() : "null handle"; }
+
+int bcd_hip_multi_get_stats(const bcd_hip_multi *m, bcd_hip_multi_stats *out)
+{
+    if (!m || !out) return BCD_HIP_EINVAL;
+    *out = m->stats;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const float *h_ns, const float *h_hist, const float *h_cov, int W, int H, int D,
+                               int nb_scales, const bcd_hip_params *prm, float *h_out)
+{
+    if (!m) return BCD_HIP_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(m->err_mutex);
+        m->err.clear();
+    }
+    m->abort_flag.store(false);
+    if (!h_colors || !h_ns || !h_hist || !h_cov || !h_out || !prm) { fail(m, "null pointer"); return BCD_HIP_EINVAL; }
+    if (W <= 0 || H <= 0 || D <= 0 || nb_scales < 1 || nb_scales > MAX_S) { fail(m, "bad image size or number of scales"); return BCD_HIP_EINVAL; }
+    Job job;
+    job.m = m; job.h_col = h_colors; job.h_ns = h_ns; job.h_hist = h_hist; job.h_cov = h_cov; job.h_out = h_out;
+    job.W = W; job.H = H; job.D = D; job.S = nb_scales; job.prm = *prm;
+    std::string err;
+    if (!job.geom.init(W, H, nb_scales, prm->search_radius, prm->patch_radius, m->n, err)) { fail(m, err); return BCD_HIP_EINVAL; }
+    if ((W >> (nb_scales - 1)) < 2 * prm->patch_radius + 1) { fail(m, "too many scales for this image size"); return BCD_HIP_EINVAL; }
+    // ---- lazily: contexts / streams per rank and channel, communicators per channel
+    const int S = nb_scales;
+    for (int r = 0; r < m->n; ++r) {
+        if (hipSetDevice(m->devices[r]) != hipSuccess) { fail(m, "hipSetDevice failed"); return BCD_HIP_EDEVICE; }
+        for (int c = 0; c <= S; ++c) {
+            if (m->ctx[r][c]) continue;
+            if (hipStreamCreateWithFlags(&m->stream[r][c], hipStreamNonBlocking) != hipSuccess ||
+                bcd_hip_ctx_create(&m->ctx[r][c], m->devices[r], m->stream[r][c]) != BCD_HIP_OK) { fail(m, "cannot create an engine context"); return BCD_HIP_EDEVICE; }
+            if (m->use_rccl && hipMalloc((void **)&m->d_red[r][c], 64) != hipSuccess) { fail(m, "hipMalloc failed"); return BCD_HIP_ENOMEM; }
+        }
+    }
+    if (m->use_rccl)
+        for (int c = 0; c <= S; ++c) {
+            if (m->comm_ready[c]) continue;
+            const ncclResult_t r = ncclCommInitAll(m->comm[c], m->n, m->devices);
+            if (r != ncclSuccess) { fail(m, std::string("ncclCommInitAll failed: ") + ncclGetErrorString(r)); return BCD_HIP_EDEVICE; }
+            m->comm_ready[c] = true;
+        }
+    std::vector<std::thread> th;
+    std::vector<char> ok(m->n, 1);
+    for (int r = 1; r < m->n; ++r) th.emplace_back([&, r]() { ok[r] = rank_worker(job, r) ? 1 : 0; });
+    ok[0] = rank_worker(job, 0) ? 1 : 0;
+    for (auto &t : th) t.join();
+    for (int r = 0; r < m->n; ++r)
+        if (!ok[r]) { fail(m, "a rank failed"); return BCD_HIP_EDEVICE; }
+    m->stats.frames += 1;
+    return BCD_HIP_OK;
+}
+
+} // extern "C"

@@ -34,6 +34,7 @@ SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
     "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host",
+    "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_denoise_host",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
@@ -320,6 +321,52 @@ class Context:
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
+
+
+class MultiStats(C.Structure):
+    _fields_ = [("n_ranks", C.c_int32), ("transport", C.c_int32), ("frames", C.c_int64), ("marking_rounds", C.c_int32 * 8)]
+
+
+class MultiDenoiser:
+    """bcd_hip_multi: one frame over several GPUs (or several virtual ranks on one GPU); host buffers in and out"""
+
+    def __init__(self, devices):
+        h = _VP()
+        arr = (C.c_int * len(devices))(*devices)
+        lib().bcd_hip_multi_last_error.restype = C.c_char_p
+        lib().bcd_hip_multi_last_error.argtypes = [_VP]
+        lib().bcd_hip_multi_destroy.argtypes = [_VP]
+        lib().bcd_hip_multi_destroy.restype = None
+        rc = lib().bcd_hip_multi_create(C.byref(h), arr, len(devices))
+        if rc != 0:
+            raise BcdHipError("bcd_hip_multi_create failed: rc=%d" % rc)
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().bcd_hip_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def denoise_host(self, col, ns, hist, cov, nscales, prm):
+        import numpy as np
+        H, W, D = hist.shape
+        out = np.empty((H, W, 3), np.float32)
+        f = lambda a: a.ctypes.data_as(_F)
+        rc = lib().bcd_hip_multi_denoise_host(self.h, f(col), f(ns), f(hist), f(cov), W, H, D, nscales, C.byref(prm), f(out))
+        if rc != 0:
+            raise BcdHipError("rc=%d: %s" % (rc, lib().bcd_hip_multi_last_error(self.h).decode()))
+        return out
+
+    def stats(self):
+        s = MultiStats()
+        lib().bcd_hip_multi_get_stats(self.h, C.byref(s))
+        return s
 
 
 def visit_order(W, H, w, random_order, seed):

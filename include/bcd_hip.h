@@ -114,6 +114,27 @@ typedef struct bcd_hip_band_job {
 } bcd_hip_band_job;
 int bcd_hip_denoise_bands(bcd_hip_ctx *ctx, const bcd_hip_band_job *jobs, int njobs, const bcd_hip_params *prm);
 
+/* ---- one frame over several GPUs of a node (what bcd::Denoiser::setDevices / bcd_cli --devices use) ------------------
+ * Row-band partition: rank r (one host thread + device devices[r]) owns a band of main pixels aligned to 2^(S-1) lines, holds
+ * (b + w) halo lines of input per scale, rebuilds the pyramid for its band, and exchanges with its two neighbours only: |S| and
+ * marking states of b boundary lines between marking batches (the visiting order is the whole frame's, so the result is the
+ * single-GPU frame for every -m / -r setting), (b + w) accumulator halo lines, and 2 + 1 output lines for the merges.
+ * Transport: RCCL point-to-point over xGMI (ncclSend / ncclRecv, one communicator per scale) when the ranks are distinct devices;
+ * several ranks on ONE device (tests, debugging) exchange through device copies.  Host buffers in, host buffer out. */
+typedef struct bcd_hip_multi bcd_hip_multi;
+typedef struct bcd_hip_multi_stats {
+    int32_t n_ranks;
+    int32_t transport;          /* 1 = RCCL, 0 = in-process copies (ranks share a device) */
+    int64_t frames;
+    int32_t marking_rounds[8];  /* exchange + marking batches per scale of the last frame */
+} bcd_hip_multi_stats;
+int  bcd_hip_multi_create(bcd_hip_multi **m, const int *devices, int n_ranks);
+void bcd_hip_multi_destroy(bcd_hip_multi *m);
+const char *bcd_hip_multi_last_error(const bcd_hip_multi *m);
+int  bcd_hip_multi_get_stats(const bcd_hip_multi *m, bcd_hip_multi_stats *out);
+int  bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const float *h_nsamples, const float *h_histograms,
+                                const float *h_covariances, int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out);
+
 /* ---- whole path, host buffers (what bcd::Denoiser / bcd_cli call): H2D + denoise + D2H -------- */
 int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_nsamples,
                          const float *h_histograms, const float *h_covariances,

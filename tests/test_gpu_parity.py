@@ -715,3 +715,61 @@ def test_batched_eigensolver_against_lapack(hipctx):
         assert np.linalg.norm((Vi * eig[i, :27]) @ Vi.T - a) / nrm < 1e-5, i
         assert np.linalg.norm(Vi.T @ Vi - np.eye(27)) < 1e-5, i
         assert np.max(np.abs(np.sort(eig[i, :27]) - np.linalg.eigvalsh(a))) / nrm < 1e-5, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,S,ranks,m,random_order,b", [(256, 288, 3, 2, 1.0, 1, 6), (256, 288, 3, 4, 1.0, 1, 6), (256, 288, 3, 4, 0.0, 0, 6),
+                                                          (96, 80, 3, 2, 1.0, 0, 3), (70, 66, 2, 3, 0.5, 1, 6), (64, 48, 1, 1, 1.0, 1, 6)])
+def test_native_multi_rank_driver_equals_single_gpu(hipctx, W, H, S, ranks, m, random_order, b):
+    """bcd_hip_multi_denoise_host (C++ driver of the row-band partition: per-band pyramid, frame-ordered marking with boundary
+    state exchange, accumulator / output halo exchange, merges at the band edges) with several ranks on ONE device (in-process
+    transport; distinct devices use RCCL) reproduces the single-GPU frame -- BASELINE configs[3]'s geometry (3 scales, b = 6) at a
+    reduced size, for -m 1 (both orders), a fractional -m and -m 0"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 21, 0.12, 0.005)
+    prm = bh.default_params(m=m, random_order=random_order, seed=9, b=b)
+    want = hipctx.denoise_host(col, ns, hist, cov, S, prm)
+    md = bh.MultiDenoiser([0] * ranks)
+    try:
+        got = md.denoise_host(col, ns, hist, cov, S, prm)
+        st = md.stats()
+        again = md.denoise_host(col, ns, hist, cov, S, prm)   # buffers / contexts are reused
+    finally:
+        md.close()
+    assert st.n_ranks == ranks and st.transport == 0
+    assert rel_linf(got, want) < 1e-5
+    assert rel_linf(again, want) < 1e-5
+
+
+@pytest.mark.gpu
+def test_native_multi_rank_driver_large_window_prefilter_random_order(hipctx):
+    """BASELINE configs[4] through the band path at a reduced size: b = 12, spike prefilter (-p 1) and random order (-r 1), 3 scales"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    W, H, S = 160, 224, 3
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 5, 0.3, 0.02)
+    col, ns, hist, cov = core.spike_filter(col, ns, hist, cov, 2.0)
+    prm = bh.default_params(m=1.0, random_order=1, seed=77, b=12)
+    want = hipctx.denoise_host(col, ns, hist, cov, S, prm)
+    md = bh.MultiDenoiser([0, 0])
+    try:
+        got = md.denoise_host(col, ns, hist, cov, S, prm)
+    finally:
+        md.close()
+    assert rel_linf(got, want) < 1e-5
+
+
+@pytest.mark.gpu
+def test_native_multi_rank_driver_reports_errors(hipctx):
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    col, ns, hist, cov = core.synthetic_scene(64, 40, 8, 5, 0.3, 0.0)
+    md = bh.MultiDenoiser([0] * 8)
+    try:
+        with pytest.raises(bh.BcdHipError, match="band"):
+            md.denoise_host(col, ns, hist, cov, 3, bh.default_params())   # 40 lines cannot feed 8 bands of a 3-scale pyramid
+    finally:
+        md.close()
+    with pytest.raises(bh.BcdHipError):
+        bh.MultiDenoiser([0, 99])
