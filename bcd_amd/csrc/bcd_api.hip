@@ -105,7 +105,14 @@ struct bcd_hip_ctx {
     Work extra[MAX_SCALES];  // lazily created streams for scales 1.. of a multiscale run
     DevBuf tmp_lo;
     DevBuf pyr[MAX_SCALES][5]; // colours, nsamples, hist, cov, out
+    DevBuf host_stage[9];      // host-buffer entry points: device copies of the four inputs, the output, the prefiltered inputs (grow-only)
     hipEvent_t ev_pyramid = nullptr;
+    // progress reporting (IDenoiser::setProgressCallback; Denoiser.cpp:181-192 of the reference): every scale adds its share when
+    // its marking is done and when its estimate is done; calls are serialised and monotone
+    bcd_hip_progress_fn progress_fn = nullptr;
+    void *progress_user = nullptr;
+    std::mutex progress_mutex;
+    double progress_done = 0.0, progress_total = 0.0;
 };
 
 namespace {
@@ -160,6 +167,15 @@ int ensure(bcd_hip_ctx *ctx, DevBuf &b, size_t bytes)
     if (e != hipSuccess) { set_err(ctx, "hipMalloc failed: " + std::string(hipGetErrorString(e))); b.p = nullptr; return BCD_HIP_ENOMEM; }
     b.bytes = want;
     return BCD_HIP_OK;
+}
+
+// `share` of the frame's work (pixels of a scale, weighted) is done
+void progress_add(bcd_hip_ctx *ctx, double share)
+{
+    if (!ctx->progress_fn || !(ctx->progress_total > 0.0)) return;
+    std::lock_guard<std::mutex> lock(ctx->progress_mutex);
+    ctx->progress_done = std::min(ctx->progress_total, ctx->progress_done + share);
+    ctx->progress_fn((float)(ctx->progress_done / ctx->progress_total), ctx->progress_user);
 }
 
 int bad(bcd_hip_ctx *ctx, const char *msg)
@@ -434,6 +450,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
         if (!(prm->marked_skip_probability > 0.f)) HIPCHK(ctx, hipStreamSynchronize(wk.stream)); // no marking batch brought the flag back
         if (!similarity_needs_redo(wk)) break; // inputs inside the guarded range, borderline list not overflowed
     }
+    progress_add(ctx, 0.5 * (double)npix); // similar patches selected, processed set known
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
     HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.stream));
     HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), wk.stream));
@@ -442,6 +459,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[3], wk.stream));
     if (d_out) HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, (int64_t)npix, d_out, wk.stream));
     HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    progress_add(ctx, 0.5 * (double)npix);
     int64_t ns = 0, nw = 0, tot = 0;
     bayes_counts(wk, &ns, &nw, &tot);
     st.processed = ns + nw; st.fallback = nw; st.similar_total = tot;
@@ -588,6 +606,7 @@ void bcd_hip_ctx_destroy(bcd_hip_ctx *ctx)
     work_destroy(ctx->main);
     for (int s = 0; s < MAX_SCALES; ++s) work_destroy(ctx->extra[s]);
     if (ctx->tmp_lo.p) (void)hipFree(ctx->tmp_lo.p);
+    for (DevBuf &hb : ctx->host_stage) if (hb.p) (void)hipFree(hb.p);
     for (int s = 0; s < MAX_SCALES; ++s)
         for (int k = 0; k < 5; ++k) if (ctx->pyr[s][k].p) (void)hipFree(ctx->pyr[s][k].p);
     if (ctx->ev_pyramid) (void)hipEventDestroy(ctx->ev_pyramid);
@@ -666,6 +685,12 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
     RCCHK(check_params(ctx, W, H, D, prm));
     if (nb_scales < 1 || nb_scales > MAX_SCALES) return bad(ctx, "bad number of scales");
     DEVICE_GUARD(ctx);
+    {
+        std::lock_guard<std::mutex> lock(ctx->progress_mutex);
+        ctx->progress_done = 0.0;
+        ctx->progress_total = 0.0;
+        for (int s = 0; s < nb_scales; ++s) ctx->progress_total += (double)(W >> s) * (double)(H >> s);
+    }
     if (nb_scales == 1) return mono(ctx, ctx->main, d_colors, d_ns, d_hist, d_cov, W, H, D, prm, bcd_hip_scale_seed(prm->order_seed, 0), 0, d_out);
 
     // ---- pyramids (MultiscaleDenoiser.cpp:41-53): level s has dims of level s-1 // 2
@@ -803,27 +828,49 @@ int bcd_hip_denoise_bands(bcd_hip_ctx *ctx, const bcd_hip_band_job *jobs, int nj
     return BCD_HIP_OK;
 }
 
-int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_ns, const float *h_hist, const float *h_cov,
-                         int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out)
+int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float *h_ns, const float *h_hist, const float *h_cov,
+                            int W, int H, int D, int nb_scales, const bcd_hip_params *prm, const bcd_hip_host_options *opt, float *h_out)
 {
     if (!ctx) return BCD_HIP_EINVAL;
     if (!h_colors || !h_ns || !h_hist || !h_cov || !h_out) return bad(ctx, "null image pointer");
     RCCHK(check_params(ctx, W, H, D, prm));
     DEVICE_GUARD(ctx);
     const size_t np = (size_t)W * H;
-    float *d[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     const size_t sz[5] = { np * 3, np, np * D, np * 6, np * 3 };
     const float *src[4] = { h_colors, h_ns, h_hist, h_cov };
-    int rc = BCD_HIP_OK;
-    for (int i = 0; i < 5 && rc == BCD_HIP_OK; ++i)
-        if (hipMalloc((void **)&d[i], sz[i] * sizeof(float)) != hipSuccess) { set_err(ctx, "hipMalloc failed for host-path staging"); rc = BCD_HIP_ENOMEM; }
-    for (int i = 0; i < 4 && rc == BCD_HIP_OK; ++i)
-        if (hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { set_err(ctx, "H2D copy failed"); rc = BCD_HIP_EDEVICE; }
-    if (rc == BCD_HIP_OK) rc = bcd_hip_denoise(ctx, d[0], d[1], d[2], d[3], W, H, D, nb_scales, prm, d[4]);
-    if (rc == BCD_HIP_OK && hipMemcpyAsync(h_out, d[4], sz[4] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { set_err(ctx, "D2H copy failed"); rc = BCD_HIP_EDEVICE; }
-    hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 5; ++i) if (d[i]) hipFree(d[i]);
-    return rc;
+    const bool prefilter = opt && opt->spike_factor > 0.f;
+    if (prefilter && (W < 3 || H < 3)) return bad(ctx, "image smaller than 3x3");
+    // device copies live in the context (grow-only): a sequence of frames pays for the allocations once
+    float *d[9];
+    for (int i = 0; i < 5; ++i) { RCCHK(ensure(ctx, ctx->host_stage[i], sz[i] * sizeof(float))); d[i] = (float *)ctx->host_stage[i].p; }
+    for (int i = 0; i < 4; ++i) {
+        d[5 + i] = d[i];
+        if (prefilter) { RCCHK(ensure(ctx, ctx->host_stage[5 + i], sz[i] * sizeof(float))); d[5 + i] = (float *)ctx->host_stage[5 + i].p; }
+    }
+    for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // SpikeRemovalFilter::filter (src/cli/main.cpp:428-441) on the device copies: no second trip over PCIe
+    if (prefilter) HIPCHK(ctx, bcd_launch_spike(d[0], d[1], d[2], d[3], W, H, D, opt->spike_factor, d[5], d[6], d[7], d[8], ctx->stream));
+    RCCHK(bcd_hip_denoise(ctx, d[5], d[6], d[7], d[8], W, H, D, nb_scales, prm, d[4]));
+    // checkAndPutToZeroNegativeInfNaNValues (src/cli/main.cpp:389-420, 470)
+    if (opt && opt->zero_bad_values) HIPCHK(ctx, bcd_launch_zero_bad(d[4], (int64_t)np * 3, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_out, d[4], sz[4] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_ns, const float *h_hist, const float *h_cov,
+                         int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out)
+{
+    return bcd_hip_denoise_host_ex(ctx, h_colors, h_ns, h_hist, h_cov, W, H, D, nb_scales, prm, nullptr, h_out);
+}
+
+int bcd_hip_set_progress_callback(bcd_hip_ctx *ctx, bcd_hip_progress_fn fn, void *user)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    std::lock_guard<std::mutex> lock(ctx->progress_mutex);
+    ctx->progress_fn = fn;
+    ctx->progress_user = user;
+    return BCD_HIP_OK;
 }
 
 // ---- stages -------------------------------------------------------------------------------------------

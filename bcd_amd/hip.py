@@ -22,6 +22,13 @@ class BandJob(C.Structure):
                 ("order_seed", C.c_uint32), ("d_sum", C.c_void_p), ("d_count", C.c_void_p)]
 
 
+class HostOptions(C.Structure):
+    _fields_ = [("spike_factor", C.c_float), ("zero_bad_values", C.c_int32)]
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_float, C.c_void_p)
+
+
 class ScaleStats(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("main_pixels", C.c_int64), ("processed", C.c_int64),
                 ("fallback", C.c_int64), ("similar_total", C.c_int64), ("active_rounds", C.c_int32),
@@ -33,7 +40,7 @@ class ScaleStats(C.Structure):
 SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
     "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
-    "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host",
+    "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_set_progress_callback",
     "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_denoise_host",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
@@ -133,13 +140,19 @@ class Context:
             arr[i] = BandJob(_dp(col).value, _dp(ns).value, _dp(hist).value, _dp(cov).value, W, H, D, r0, r1, seed, _dp(s).value, _dp(c).value)
         self._chk(lib().bcd_hip_denoise_bands(self.h, arr, len(jobs), C.byref(prm)))
 
-    def denoise_host(self, col, ns, hist, cov, nscales, prm):
+    def denoise_host(self, col, ns, hist, cov, nscales, prm, spike_factor=0.0, zero_bad_values=False):
         import numpy as np
         H, W, D = hist.shape
         out = np.empty((H, W, 3), np.float32)
         f = lambda a: a.ctypes.data_as(_F)
-        self._chk(lib().bcd_hip_denoise_host(self.h, f(col), f(ns), f(hist), f(cov), W, H, D, nscales, C.byref(prm), f(out)))
+        opt = HostOptions(spike_factor, 1 if zero_bad_values else 0)
+        self._chk(lib().bcd_hip_denoise_host_ex(self.h, f(col), f(ns), f(hist), f(cov), W, H, D, nscales, C.byref(prm), C.byref(opt), f(out)))
         return out
+
+    def set_progress_callback(self, fn):
+        """fn(progress) or None; the ctypes thunk is kept alive on the context"""
+        self._progress = PROGRESS_FN(lambda v, user: fn(v)) if fn else C.cast(None, PROGRESS_FN)
+        self._chk(lib().bcd_hip_set_progress_callback(self.h, self._progress, None))
 
     # ---- stages
     def pixel_cov(self, cov, ns):

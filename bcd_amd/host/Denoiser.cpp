@@ -6,7 +6,13 @@
 
 #include "bcd_hip.h"
 
+#include <functional>
 #include <iostream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
 
 using namespace std;
 
@@ -57,6 +63,35 @@ namespace bcd
 		return true;
 	}
 
+	namespace
+	{
+		/// Engine handles are kept for the life of the process, one per device (and one per device list): workspace, pyramid
+		/// and staging buffers of the engine are grow-only, so a sequence of frames pays for them once.  A mutex per handle
+		/// serialises callers (the reference's denoise() is not re-entrant either, src/core/Denoiser.cpp:114).
+		struct EngineSlot
+		{
+			std::mutex m_mutex;
+			bcd_hip_ctx* m_pCtx = nullptr;
+			bcd_hip_multi* m_pMulti = nullptr;
+		};
+		std::mutex g_registryMutex;
+		std::map< std::vector<int>, std::unique_ptr<EngineSlot> > g_registry;
+
+		EngineSlot& engineSlot(const std::vector<int>& i_rDevices)
+		{
+			std::lock_guard<std::mutex> lock(g_registryMutex);
+			std::unique_ptr<EngineSlot>& rSlot = g_registry[i_rDevices];
+			if(!rSlot)
+				rSlot.reset(new EngineSlot());
+			return *rSlot;
+		}
+
+		void forwardProgress(float i_progress, void* i_pUser)
+		{
+			(*static_cast< std::function<void(float)>* >(i_pUser))(i_progress);
+		}
+	}
+
 	bool Denoiser::denoiseWithNbOfScales(int i_nbOfScales)
 	{
 		if(!inputsOutputsAreOk())
@@ -64,14 +99,11 @@ namespace bcd
 		m_width = m_inputs.m_pColors->getWidth();
 		m_height = m_inputs.m_pColors->getHeight();
 		m_nbOfPixels = m_width * m_height;
+		// src/core/Denoiser.cpp:99-121: the flags are requests; this build has one path (the HIP device) and says so
+		if(!m_parameters.m_useCuda)
+			cout << "Note: --use-cuda 0 / m_useCuda = false requests the CPU path, which this build does not have; running on the HIP device" << endl;
+		m_parameters.m_nbOfCores = 1 + (i_nbOfScales - 1); // host threads that drive the device: one per scale (reference: actual OpenMP thread count)
 
-		bcd_hip_ctx* pCtx = nullptr;
-		int rc = bcd_hip_ctx_create(&pCtx, m_device, nullptr);
-		if(rc != BCD_HIP_OK)
-		{
-			cerr << "Aborting denoising: no usable HIP device " << m_device << " (this build has no CPU path)" << endl;
-			return false;
-		}
 		bcd_hip_params prm;
 		bcd_hip_default_params(&prm);
 		prm.hist_dist_threshold = m_parameters.m_histogramDistanceThreshold;
@@ -82,15 +114,53 @@ namespace bcd
 		prm.marked_skip_probability = m_parameters.m_markedPixelsSkippingProbability;
 		prm.order_seed = m_orderSeed;
 
+		EngineSlot& rSlot = engineSlot(m_devices);
+		std::lock_guard<std::mutex> lock(rSlot.m_mutex);
 		m_progressCallback(0.f);
 		Deepimf result(m_width, m_height, 3); // inputs may alias the output image (the CLI pre-copies colours into it)
-		rc = bcd_hip_denoise_host(pCtx,
-				m_inputs.m_pColors->getDataPtr(), m_inputs.m_pNbOfSamples->getDataPtr(),
-				m_inputs.m_pHistograms->getDataPtr(), m_inputs.m_pSampleCovariances->getDataPtr(),
-				m_width, m_height, m_inputs.m_pHistograms->getDepth(), i_nbOfScales, &prm, result.getDataPtr());
-		if(rc != BCD_HIP_OK)
-			cerr << "Aborting denoising: " << bcd_hip_last_error(pCtx) << endl;
-		bcd_hip_ctx_destroy(pCtx);
+		const float* pIn[4] = { m_inputs.m_pColors->getDataPtr(), m_inputs.m_pNbOfSamples->getDataPtr(), m_inputs.m_pHistograms->getDataPtr(),
+				m_inputs.m_pSampleCovariances->getDataPtr() };
+		const int depth = m_inputs.m_pHistograms->getDepth();
+		int rc = BCD_HIP_OK;
+		if(m_devices.size() > 1)
+		{
+			if(m_prefilterThresholdStDevFactor > 0.f)
+			{
+				cerr << "Aborting denoising: the device-side spike prefilter is only available on a single device (filter on the host first)" << endl;
+				return false;
+			}
+			if(!rSlot.m_pMulti && bcd_hip_multi_create(&rSlot.m_pMulti, m_devices.data(), int(m_devices.size())) != BCD_HIP_OK)
+			{
+				cerr << "Aborting denoising: unusable HIP device list (this build has no CPU path)" << endl;
+				return false;
+			}
+			rc = bcd_hip_multi_denoise_host(rSlot.m_pMulti, pIn[0], pIn[1], pIn[2], pIn[3], m_width, m_height, depth, i_nbOfScales, &prm, result.getDataPtr());
+			if(rc != BCD_HIP_OK)
+				cerr << "Aborting denoising: " << bcd_hip_multi_last_error(rSlot.m_pMulti) << endl;
+			else if(m_zeroBadOutputValues)
+			{
+				float* p = result.getDataPtr();
+				for(size_t i = 0, n = size_t(m_nbOfPixels) * 3; i < n; ++i)
+					if(!(p[i] >= 0.f) || !(p[i] <= std::numeric_limits<float>::max()))
+						p[i] = 0.f;
+			}
+		}
+		else
+		{
+			if(!rSlot.m_pCtx && bcd_hip_ctx_create(&rSlot.m_pCtx, m_devices[0], nullptr) != BCD_HIP_OK)
+			{
+				cerr << "Aborting denoising: no usable HIP device " << m_devices[0] << " (this build has no CPU path)" << endl;
+				return false;
+			}
+			bcd_hip_set_progress_callback(rSlot.m_pCtx, &forwardProgress, &m_progressCallback);
+			bcd_hip_host_options opt;
+			opt.spike_factor = m_prefilterThresholdStDevFactor;
+			opt.zero_bad_values = m_zeroBadOutputValues ? 1 : 0;
+			rc = bcd_hip_denoise_host_ex(rSlot.m_pCtx, pIn[0], pIn[1], pIn[2], pIn[3], m_width, m_height, depth, i_nbOfScales, &prm, &opt, result.getDataPtr());
+			bcd_hip_set_progress_callback(rSlot.m_pCtx, nullptr, nullptr);
+			if(rc != BCD_HIP_OK)
+				cerr << "Aborting denoising: " << bcd_hip_last_error(rSlot.m_pCtx) << endl;
+		}
 		if(rc != BCD_HIP_OK)
 			return false;
 		*m_outputs.m_pDenoisedColors = std::move(result); // resized to W x H x 3 and overwritten (Denoiser.cpp:207-208)
@@ -110,7 +180,20 @@ namespace bcd
 			cerr << "Aborting denoising: number of scales must be >= 1" << endl;
 			return false;
 		}
-		return denoiseWithNbOfScales(m_nbOfScales);
+		// the pyramid (MultiscaleDenoiser.cpp:41-53), the per-scale denoisers (:79-134) and the merges (:453-466) are one engine
+		// call; a Denoiser configured like this object makes it
+		Denoiser engine;
+		engine.setInputs(m_inputs);
+		engine.setOutputs(m_outputs);
+		engine.setParameters(m_parameters);
+		engine.setProgressCallback(m_progressCallback);
+		engine.setOrderSeed(m_orderSeed);
+		engine.setDevices(m_devices);
+		engine.setSpikePrefilter(m_prefilterThresholdStDevFactor);
+		engine.setZeroBadOutputValues(m_zeroBadOutputValues);
+		const bool ok = engine.denoiseWithNbOfScales(m_nbOfScales);
+		m_parameters.m_nbOfCores = engine.getParameters().m_nbOfCores;
+		return ok;
 	}
 
 } // namespace bcd

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <vector>
 #include <memory>
 #include <string>
 
@@ -42,7 +43,7 @@ namespace
 		int m_nbOfCores = 0;
 		bool m_useCuda = true;
 		unsigned m_orderSeed = 1234u;
-		int m_device = 0;
+		std::vector<int> m_devices = std::vector<int>(1, 0);
 	};
 
 	const char* g_pProgramPath = "bcd_cli";
@@ -73,6 +74,7 @@ namespace
 		cout << "    -e <float>           Minimum eigen value for matrix inversion (default: " << d.m_minEigenValue << ")" << endl;
 		cout << "    --seed <int>         Seed of the random pixel order (default: " << d.m_orderSeed << ")" << endl;
 		cout << "    --device <int>       HIP device index (default: 0)" << endl;
+		cout << "    --devices <list>     several HIP devices, e.g. 0-7 or 0,2,4: the frame is split into row bands (RCCL halo exchange)" << endl;
 	}
 
 	bool badValue(const char* flag, const char* what)
@@ -159,7 +161,25 @@ namespace
 			else if(flag == "--ncores") { a.m_nbOfCores = atoi(value); }
 			else if(flag == "--use-cuda") { a.m_useCuda = atoi(value) == 1; }
 			else if(flag == "--seed") { a.m_orderSeed = unsigned(strtoul(value, nullptr, 10)); }
-			else if(flag == "--device") { a.m_device = atoi(value); }
+			else if(flag == "--device") { a.m_devices.assign(1, atoi(value)); }
+			else if(flag == "--devices")
+			{	// "0-7", "0,1,2", "0-3,6"
+				a.m_devices.clear();
+				const string list(value);
+				size_t pos = 0;
+				while(pos < list.size())
+				{
+					size_t end = list.find(',', pos);
+					if(end == string::npos) end = list.size();
+					const string item = list.substr(pos, end - pos);
+					const size_t dash = item.find('-');
+					const int first = atoi(item.substr(0, dash).c_str()), last = dash == string::npos ? first : atoi(item.substr(dash + 1).c_str());
+					if(item.empty() || first < 0 || last < first) return badValue("--devices", "expecting a list like 0-7 or 0,2,4");
+					for(int d = first; d <= last; ++d) a.m_devices.push_back(d);
+					pos = end + 1;
+				}
+				if(a.m_devices.empty()) return badValue("--devices", "expecting a list like 0-7 or 0,2,4");
+			}
 			else { cout << "ERROR in program arguments: unknown argument " << flag << endl << endl; printUsage(); return false; }
 		}
 		if(!missingColor && inputColorFilePath.length() > 4)
@@ -217,7 +237,10 @@ namespace
 				rgb.get(3 * i) = rgb.get(3 * i + 1) = rgb.get(3 * i + 2) = args.m_colorImage.get(i);
 			args.m_colorImage = std::move(rgb);
 		}
-		if(args.m_prefilterSpikes)
+		// -p 1 (src/cli/main.cpp:428-441): on one device the prefilter runs on the uploaded copies, right before the denoiser (one trip
+		// over PCIe for everything); with several devices it runs first, as in the reference
+		const bool prefilterOnDevice = args.m_prefilterSpikes && args.m_devices.size() == 1;
+		if(args.m_prefilterSpikes && !prefilterOnDevice)
 			SpikeRemovalFilter::filter(args.m_colorImage, args.m_nbOfSamplesImage, args.m_histogramImage, args.m_covarianceImage, args.m_prefilterThresholdStDevFactor);
 
 		DenoiserInputs inputs;
@@ -238,16 +261,22 @@ namespace
 		parameters.m_nbOfCores = args.m_nbOfCores;
 		parameters.m_useCuda = args.m_useCuda;
 
-		unique_ptr<Denoiser> uDenoiser(args.m_nbOfScales > 1 ? new MultiscaleDenoiser(args.m_nbOfScales) : new Denoiser());
-		uDenoiser->setOrderSeed(args.m_orderSeed);
-		uDenoiser->setDevice(args.m_device);
+		unique_ptr<IDenoiser> uDenoiser;
+		HipEngineSettings* pSettings = nullptr;
+		if(args.m_nbOfScales > 1) { MultiscaleDenoiser* p = new MultiscaleDenoiser(args.m_nbOfScales); uDenoiser.reset(p); pSettings = p; }
+		else { Denoiser* p = new Denoiser(); uDenoiser.reset(p); pSettings = p; }
+		pSettings->setOrderSeed(args.m_orderSeed);
+		pSettings->setDevices(args.m_devices);
+		if(prefilterOnDevice)
+			pSettings->setSpikePrefilter(args.m_prefilterThresholdStDevFactor);
+		pSettings->setZeroBadOutputValues(true); // checkAndPutToZeroNegativeInfNaNValues (src/cli/main.cpp:470) before the download
 		uDenoiser->setInputs(inputs);
 		uDenoiser->setOutputs(outputs);
 		uDenoiser->setParameters(parameters);
 		if(!uDenoiser->denoise())
 			return 2;
 
-		checkAndPutToZeroNegativeInfNaNValues(outputDenoisedColorImage);
+		checkAndPutToZeroNegativeInfNaNValues(outputDenoisedColorImage); // (already clean: kept as the reference's last line of defence)
 		if(!ImageIO::writeEXR(outputDenoisedColorImage, args.m_denoisedOutputFilePath.c_str()))
 		{
 			cerr << "Couldn't write " << args.m_denoisedOutputFilePath << ": " << ImageIO::lastError() << endl;

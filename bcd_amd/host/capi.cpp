@@ -47,6 +47,10 @@ int bcdcore_accumulate(const float* s, long long n, int W, int H, int nbins, flo
 
 // runs bcd::Denoiser (nscales == 1) or bcd::MultiscaleDenoiser through the IDenoiser interface; returns denoise()'s bool.
 // Null pointers are forwarded as null images to exercise the validation path.
+static int g_lastProgressValues = 0;
+/// number of distinct progress values the last bcdcore_denoise reported
+int bcdcore_last_progress_values() { return g_lastProgressValues; }
+
 int bcdcore_denoise(const float* col, const float* ns, const float* hist, const float* cov, int W, int H, int D, int nscales,
 		float tau, int w, int b, float minEig, int randomOrder, float skipProbability, unsigned seed, float* out, int histWidthOverride)
 {
@@ -62,17 +66,20 @@ int bcdcore_denoise(const float* col, const float* ns, const float* hist, const 
 	DenoiserParameters p;
 	p.m_histogramDistanceThreshold = tau; p.m_patchRadius = w; p.m_searchWindowRadius = b; p.m_minEigenValue = minEig;
 	p.m_useRandomPixelOrder = randomOrder != 0; p.m_markedPixelsSkippingProbability = skipProbability;
-	std::unique_ptr<Denoiser> d(nscales > 1 ? new MultiscaleDenoiser(nscales) : new Denoiser());
-	d->setOrderSeed(seed);
+	std::unique_ptr<IDenoiser> d;
+	if(nscales > 1) { MultiscaleDenoiser* m = new MultiscaleDenoiser(nscales); m->setOrderSeed(seed); d.reset(m); }
+	else { Denoiser* m = new Denoiser(); m->setOrderSeed(seed); d.reset(m); }
 	IDenoiser* pDenoiser = d.get();
 	pDenoiser->setInputs(in);
 	pDenoiser->setOutputs(o);
 	pDenoiser->setParameters(p);
 	float last = -1.f;
 	bool monotone = true;
-	pDenoiser->setProgressCallback([&](float f) { if(f < last) monotone = false; last = f; });
+	int distinct = 0;
+	pDenoiser->setProgressCallback([&](float f) { if(f < last) monotone = false; if(f != last) ++distinct; last = f; });
 	const bool ok = pDenoiser->denoise();
 	if(ok && out) oImg.copyDataTo(out);
+	g_lastProgressValues = distinct;
 	return ok ? (monotone ? 1 : 2) : 0;
 }
 

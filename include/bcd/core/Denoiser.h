@@ -9,14 +9,41 @@
 #include "DeepImage.h"
 
 #include <cstdint>
+#include <vector>
 
 namespace bcd
 {
 
-	class Denoiser : public IDenoiser
+	/// Settings of this build that the reference's API has no place for.  Both denoiser classes expose them through the same
+	/// setters; defaults reproduce the reference's behaviour on device 0.
+	class HipEngineSettings
 	{
 	public:
-		Denoiser() : IDenoiser(), m_width(0), m_height(0), m_nbOfPixels(0), m_orderSeed(1234u), m_device(0) {}
+		HipEngineSettings() : m_orderSeed(1234u), m_devices(1, 0), m_prefilterThresholdStDevFactor(0.f), m_zeroBadOutputValues(false) {}
+
+		/// seed of the visiting order of -r 1 (the reference seeds its shuffle from the wall clock, src/core/Denoiser.cpp:418)
+		void setOrderSeed(uint32_t i_seed) { m_orderSeed = i_seed; }
+		/// HIP device; several devices split the frame into row bands (bcd_hip_multi_*, RCCL over xGMI between neighbours)
+		void setDevice(int i_device) { m_devices.assign(1, i_device); }
+		void setDevices(const std::vector<int>& i_rDevices) { if(!i_rDevices.empty()) m_devices = i_rDevices; }
+		const std::vector<int>& getDevices() const { return m_devices; }
+		/// > 0: run SpikeRemovalFilter::filter on the uploaded copies of the inputs before denoising (what bcd_cli -p 1 does on
+		/// the host, src/cli/main.cpp:428-441); the caller's images are not modified.  One device only.
+		void setSpikePrefilter(float i_thresholdStDevFactor) { m_prefilterThresholdStDevFactor = i_thresholdStDevFactor; }
+		/// put negative / infinite / NaN output values to zero on the device (src/cli/main.cpp:389-420)
+		void setZeroBadOutputValues(bool i_enabled) { m_zeroBadOutputValues = i_enabled; }
+
+	protected:
+		uint32_t m_orderSeed;
+		std::vector<int> m_devices;
+		float m_prefilterThresholdStDevFactor;
+		bool m_zeroBadOutputValues;
+	};
+
+	class Denoiser : public IDenoiser, public HipEngineSettings
+	{
+	public:
+		Denoiser() : IDenoiser(), m_width(0), m_height(0), m_nbOfPixels(0) {}
 		virtual ~Denoiser() {}
 
 	public:
@@ -28,19 +55,14 @@ namespace bcd
 		int getImagesWidth() const { return m_width; }
 		int getImagesHeight() const { return m_height; }
 
-		/// extensions of this build: seed of the visiting order (the reference uses the wall clock) and HIP device index
-		void setOrderSeed(uint32_t i_seed) { m_orderSeed = i_seed; }
-		void setDevice(int i_device) { m_device = i_device; }
-
-	protected:
+		/// the whole path for 1..n scales (MultiscaleDenoiser forwards here: the pyramid, the scales and the merges are one call
+		/// into the engine)
 		bool denoiseWithNbOfScales(int i_nbOfScales);
 
 	private:
 		int m_width;
 		int m_height;
 		int m_nbOfPixels;
-		uint32_t m_orderSeed;
-		int m_device;
 	};
 
 } // namespace bcd

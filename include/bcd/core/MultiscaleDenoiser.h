@@ -1,5 +1,5 @@
 // MultiscaleDenoiser.h -- multiscale driver (pyramid, per-scale denoising, merge), MI355X build.
-// Public surface of the reference's include/bcd/core/MultiscaleDenoiser.h:23-31.
+// Public surface of the reference's include/bcd/core/MultiscaleDenoiser.h:23-31: an IDenoiser, like the reference's.
 #ifndef MULTISCALE_DENOISER_H
 #define MULTISCALE_DENOISER_H
 
@@ -8,10 +8,10 @@
 namespace bcd
 {
 
-	class MultiscaleDenoiser : public Denoiser
+	class MultiscaleDenoiser : public IDenoiser, public HipEngineSettings
 	{
 	public:
-		MultiscaleDenoiser(int i_nbOfScales) : Denoiser(), m_nbOfScales(i_nbOfScales) {}
+		MultiscaleDenoiser(int i_nbOfScales) : IDenoiser(), m_nbOfScales(i_nbOfScales) {}
 		virtual ~MultiscaleDenoiser() {}
 
 	public:

@@ -37,6 +37,11 @@ extern "C" {
 
 typedef struct bcd_hip_ctx bcd_hip_ctx;
 
+/* IDenoiser::setProgressCallback (include/bcd/core/IDenoiser.h:91, fired from src/core/Denoiser.cpp:181-192): called from the
+ * engine's host threads, serialised, with monotone values in (0, 1] -- every scale reports when its processed set is known and
+ * when its estimate is complete, weighted by its share of the pixels */
+typedef void (*bcd_hip_progress_fn)(float progress, void *user);
+
 /* mirrors bcd::DenoiserParameters (include/bcd/core/IDenoiser.h:20-44) */
 typedef struct bcd_hip_params {
     float    hist_dist_threshold;     /* m_histogramDistanceThreshold          default 1     */
@@ -81,6 +86,7 @@ int  bcd_hip_set_concurrent_scales(bcd_hip_ctx *ctx, int enabled);
  * tau (1 +- 2^-14) (default on for w = 1 and D in {24, 36, 60}; also disabled by BCD_HIP_EXACT_SIMILARITY=1).  The masks are
  * bit-identical either way; 0 forces the exact kernels. */
 int  bcd_hip_set_fast_similarity(bcd_hip_ctx *ctx, int enabled);
+int  bcd_hip_set_progress_callback(bcd_hip_ctx *ctx, bcd_hip_progress_fn fn, void *user);
 int  bcd_hip_get_stats(const bcd_hip_ctx *ctx, int scale, bcd_hip_scale_stats *out);
 /* duration (ms, HIP events on the context's stream) and launch count of the pair-distance kernel
  * accumulated since the last reset -- the dominant kernel measured by bench.py's roofline */
@@ -139,6 +145,16 @@ int  bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const f
 int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_nsamples,
                          const float *h_histograms, const float *h_covariances,
                          int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out);
+/* the same with the steps either side of the path kept on the device (one upload, one download): the spike prefilter of
+ * bcd_cli -p 1 (SpikeRemovalFilter::filter, src/cli/main.cpp:428-441) on the uploaded copies -- the host images are NOT modified --
+ * and the clean-up of the result (checkAndPutToZeroNegativeInfNaNValues, :389-420).  The device copies stay in the context. */
+typedef struct bcd_hip_host_options {
+    float   spike_factor;     /* > 0: prefilter with this standard-deviation factor (--p-factor); <= 0: off */
+    int32_t zero_bad_values;  /* != 0: negative / infinite / NaN output values become 0 */
+} bcd_hip_host_options;
+int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float *h_nsamples,
+                            const float *h_histograms, const float *h_covariances,
+                            int W, int H, int D, int nb_scales, const bcd_hip_params *prm, const bcd_hip_host_options *opt, float *h_out);
 
 /* ---- stages (device pointers) -- exposed for parity tests and multi-GPU composition ------------ */
 /* Denoiser::computePixelCovFromSampleCov   src/core/Denoiser.cpp:357-373 */

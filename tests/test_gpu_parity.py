@@ -773,3 +773,63 @@ def test_native_multi_rank_driver_reports_errors(hipctx):
         md.close()
     with pytest.raises(bh.BcdHipError):
         bh.MultiDenoiser([0, 99])
+
+
+@pytest.mark.gpu
+def test_progress_callback_is_monotone_and_fires_inside_the_loop(hipctx):
+    """IDenoiser::setProgressCallback (Denoiser.cpp:181-192 of the reference fires it inside the loop): here every scale reports
+    twice, weighted by its pixels -- more than the two end values, never decreasing, ending at 1"""
+    import bcd_amd.core as core
+    col, ns, hist, cov = core.synthetic_scene(96, 80, 16, 3, 0.15, 0.0)
+    seen = []
+    hipctx.set_progress_callback(seen.append)
+    try:
+        import bcd_amd.hip as bh
+        hipctx.denoise_host(col, ns, hist, cov, 3, bh.default_params(m=1.0))
+    finally:
+        hipctx.set_progress_callback(None)
+    assert len(seen) == 6 and all(b >= a for a, b in zip(seen, seen[1:])) and 0 < seen[0] < 1 and abs(seen[-1] - 1.0) < 1e-6
+    # through the C++ classes: 0, the engine's values, 1
+    ok, out, monotone = core.denoise(col, ns, hist, cov, nscales=3, m=1.0)
+    assert ok and monotone and core.lib().bcdcore_last_progress_values() > 4
+
+
+@pytest.mark.gpu
+def test_device_resident_prefilter_and_cleanup_chain(hipctx):
+    """bcd_hip_denoise_host_ex: spike prefilter on the uploaded copies + denoise + bad-value clean-up == the three separate steps;
+    the caller's images are not modified"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    col, ns, hist, cov = core.synthetic_scene(80, 60, 16, 21, 0.2, 0.03)
+    keep = [a.copy() for a in (col, ns, hist, cov)]
+    prm = bh.default_params(b=4, m=0.0, seed=5)
+    got = hipctx.denoise_host(col, ns, hist, cov, 2, prm, spike_factor=2.0, zero_bad_values=True)
+    assert all(np.array_equal(a, b) for a, b in zip(keep, (col, ns, hist, cov)))
+    d = hipctx.spike_filter(*dev(col, ns, hist, cov), 2.0)
+    want = hipctx.zero_bad_values(hipctx.denoise(*d, 2, prm)).cpu().numpy()
+    assert rel_linf(got, want) < 1e-5   # (the aggregation's float atomics are order-dependent at ~1e-7)
+
+
+@pytest.mark.gpu
+def test_bcd_cli_devices_list(hipctx, tmp_path):
+    """bcd_cli --devices a,b: the frame goes through the native multi-rank driver (two ranks on device 0 here) and must give the
+    single-device file"""
+    import subprocess
+    import bcd_amd.core as core
+    W, H = 96, 72
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 21, 0.15, 0.02)
+    stem = str(tmp_path / "frame")
+    core.write_exr(stem + ".exr", col, False)
+    core.write_exr(stem + "_hist.exr", core.merge_hist_ns(hist, ns), True)
+    core.write_exr(stem + "_cov.exr", cov, True)
+    exe = _os.path.join(_os.path.dirname(core.LIB_PATH), "bcd_cli")
+    outs = []
+    for devs in ("0", "0,0"):
+        out_path = str(tmp_path / ("out_%s.exr" % devs.replace(",", "_")))
+        r = subprocess.run([exe, "-i", stem + ".exr", "-o", out_path, "-p", "1", "-s", "2", "-b", "4", "--seed", "5", "--devices", devs],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(core.read_exr(out_path, False))
+    assert np.max(np.abs(outs[0] - outs[1])) <= 2e-3 * np.max(outs[0])   # both files are half precision
+    r = subprocess.run([exe, "-i", stem + ".exr", "-o", str(tmp_path / "x.exr"), "--devices", "3-1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--devices" in r.stdout
