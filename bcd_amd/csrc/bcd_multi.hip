@@ -146,6 +146,11 @@ struct bcd_hip_multi {
     DBuf buf[MAX_RANKS][MAX_S][NBUF];
     long long *d_red[MAX_RANKS][MAX_S + 1]; // all-reduce scratch (RCCL transport)
     bcd_hip_multi_stats stats;
+    // one-process-per-GPU use (bcd_hip_multi_create_rank): only `local_rank` lives in this process; its communicators are built
+    // with ncclCommInitRank from the ids all processes share
+    int local_rank = -1;
+    std::vector<ncclUniqueId> ids;
+    struct Frame { int W = 0, H = 0, D = 0, S = 0; bcd_hip_params prm; bool set = false; } frame;
 };
 
 namespace {
@@ -318,7 +323,33 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
 }
 
 // ---- one rank: inputs, pyramid, the scales (concurrently), output halos and merges, result ---------------------------------
-bool rank_worker(const Job &job, int rank)
+// h_* point at the first LOCAL line of the band when `local_band` is set (one process per GPU), else at line 0 of the frame
+bool rank_upload(const Job &job, int rank, bool local_band)
+{
+    bcd_hip_multi *m = job.m;
+    if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
+    const Geometry &g = job.geom;
+    const int S = g.S, D = job.D;
+    ScaleBand bands[MAX_S];
+    g.bands(rank, bands);
+    hipStream_t sm = m->stream[rank][S];
+    auto B = [&](int s, int kind) -> DBuf & { return m->buf[rank][s][kind]; };
+    for (int s = 0; s < S; ++s) {
+        const size_t np = (size_t)(bands[s].loc1 - bands[s].loc0) * bands[s].W;
+        if (!B(s, bcd_hip_multi::IN_COL).ensure(np * 12) || !B(s, bcd_hip_multi::IN_NS).ensure(np * 4) || !B(s, bcd_hip_multi::IN_HIST).ensure(np * D * 4) ||
+            !B(s, bcd_hip_multi::IN_COV).ensure(np * 24) || !B(s, bcd_hip_multi::OUT).ensure(np * 12)) { fail(m, "out of device memory"); return false; }
+    }
+    const size_t first = local_band ? 0 : (size_t)bands[0].loc0 * job.W, np = (size_t)(bands[0].loc1 - bands[0].loc0) * job.W;
+    MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_COL).p, job.h_col + first * 3, np * 12, hipMemcpyHostToDevice, sm));
+    MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_NS).p, job.h_ns + first, np * 4, hipMemcpyHostToDevice, sm));
+    MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_HIST).p, job.h_hist + first * D, np * D * 4, hipMemcpyHostToDevice, sm));
+    MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_COV).p, job.h_cov + first * 6, np * 24, hipMemcpyHostToDevice, sm));
+    MCHK(m, rank, hipStreamSynchronize(sm));
+    return true;
+}
+
+// everything between the resident inputs and the resident result of the band (what bench.py times at N > 1)
+bool rank_compute(const Job &job, int rank)
 {
     bcd_hip_multi *m = job.m;
     if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
@@ -330,19 +361,7 @@ bool rank_worker(const Job &job, int rank)
     bcd_hip_ctx *cm = m->ctx[rank][S];
     hipStream_t sm = m->stream[rank][S];
     auto B = [&](int s, int kind) -> DBuf & { return m->buf[rank][s][kind]; };
-    // ---- inputs of the band (host -> device) and local pyramid (MultiscaleDenoiser.cpp:41-53)
-    for (int s = 0; s < S; ++s) {
-        const size_t np = (size_t)(bands[s].loc1 - bands[s].loc0) * bands[s].W;
-        if (!B(s, bcd_hip_multi::IN_COL).ensure(np * 12) || !B(s, bcd_hip_multi::IN_NS).ensure(np * 4) || !B(s, bcd_hip_multi::IN_HIST).ensure(np * D * 4) ||
-            !B(s, bcd_hip_multi::IN_COV).ensure(np * 24) || !B(s, bcd_hip_multi::OUT).ensure(np * 12)) { fail(m, "out of device memory"); return false; }
-    }
-    {
-        const size_t first = (size_t)bands[0].loc0 * job.W, np = (size_t)(bands[0].loc1 - bands[0].loc0) * job.W;
-        MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_COL).p, job.h_col + first * 3, np * 12, hipMemcpyHostToDevice, sm));
-        MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_NS).p, job.h_ns + first, np * 4, hipMemcpyHostToDevice, sm));
-        MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_HIST).p, job.h_hist + first * D, np * D * 4, hipMemcpyHostToDevice, sm));
-        MCHK(m, rank, hipMemcpyAsync(B(0, bcd_hip_multi::IN_COV).p, job.h_cov + first * 6, np * 24, hipMemcpyHostToDevice, sm));
-    }
+    // ---- local pyramid (MultiscaleDenoiser.cpp:41-53)
     for (int s = 1; s < S; ++s) {
         const ScaleBand &prev = bands[s - 1], &cur = bands[s];
         const int a = 2 * cur.loc0 - prev.loc0, rows = 2 * (cur.loc1 - cur.loc0);
@@ -388,14 +407,73 @@ bool rank_worker(const Job &job, int rank)
             if (!exchange(m, rank, S, out_rows(s, o0), up ? out_rows(s, o0 - 1) : nullptr, bytes, out_rows(s, o1 - 1), down ? out_rows(s, o1) : nullptr, bytes)) return false;
         }
     }
-    // ---- owned lines of the result
-    {
-        const int o0 = bands[0].own0 - bands[0].loc0;
-        MCHK(m, rank, hipMemcpyAsync(job.h_out + (size_t)bands[0].own0 * job.W * 3, out_rows(0, o0), (size_t)(bands[0].own1 - bands[0].own0) * job.W * 12,
-                                     hipMemcpyDeviceToHost, sm));
-        MCHK(m, rank, hipStreamSynchronize(sm));
-    }
+    MCHK(m, rank, hipStreamSynchronize(sm));
     return true;
+}
+
+// owned lines of the result; h_out points at line 0 of the frame, or (local_band) at the first OWNED line
+bool rank_download(const Job &job, int rank, bool local_band)
+{
+    bcd_hip_multi *m = job.m;
+    if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
+    ScaleBand bands[MAX_S];
+    job.geom.bands(rank, bands);
+    hipStream_t sm = m->stream[rank][job.geom.S];
+    const int o0 = bands[0].own0 - bands[0].loc0;
+    const float *src = (const float *)m->buf[rank][0][bcd_hip_multi::OUT].p + (size_t)o0 * job.W * 3;
+    MCHK(m, rank, hipMemcpyAsync(job.h_out + (local_band ? 0 : (size_t)bands[0].own0 * job.W * 3), src, (size_t)(bands[0].own1 - bands[0].own0) * job.W * 12,
+                                 hipMemcpyDeviceToHost, sm));
+    MCHK(m, rank, hipStreamSynchronize(sm));
+    return true;
+}
+
+bool rank_worker(const Job &job, int rank) { return rank_upload(job, rank, false) && rank_compute(job, rank) && rank_download(job, rank, false); }
+
+// contexts / streams of the local ranks and the communicators of channels 0..S, created on first use
+int prepare(bcd_hip_multi *m, int S)
+{
+    for (int r = 0; r < m->n; ++r) {
+        if (m->local_rank >= 0 && r != m->local_rank) continue;
+        if (hipSetDevice(m->devices[r]) != hipSuccess) { fail(m, "hipSetDevice failed"); return BCD_HIP_EDEVICE; }
+        for (int c = 0; c <= S; ++c) {
+            if (m->ctx[r][c]) continue;
+            if (hipStreamCreateWithFlags(&m->stream[r][c], hipStreamNonBlocking) != hipSuccess ||
+                bcd_hip_ctx_create(&m->ctx[r][c], m->devices[r], m->stream[r][c]) != BCD_HIP_OK) { fail(m, "cannot create an engine context"); return BCD_HIP_EDEVICE; }
+            if (m->use_rccl && hipMalloc((void **)&m->d_red[r][c], 64) != hipSuccess) { fail(m, "hipMalloc failed"); return BCD_HIP_ENOMEM; }
+        }
+    }
+    if (m->use_rccl && m->n > 1)
+        for (int c = 0; c <= S; ++c) {
+            if (m->comm_ready[c]) continue;
+            ncclResult_t r;
+            if (m->local_rank >= 0) {
+                if ((size_t)c >= m->ids.size()) { fail(m, "not enough RCCL unique ids for this number of scales"); return BCD_HIP_EINVAL; }
+                r = ncclCommInitRank(&m->comm[c][m->local_rank], m->n, m->ids[c], m->local_rank); // collective: every process, same order
+            } else
+                r = ncclCommInitAll(m->comm[c], m->n, m->devices);
+            if (r != ncclSuccess) { fail(m, std::string("RCCL communicator creation failed: ") + ncclGetErrorString(r)); return BCD_HIP_EDEVICE; }
+            m->comm_ready[c] = true;
+        }
+    return BCD_HIP_OK;
+}
+
+int make_job(bcd_hip_multi *m, Job &job, int W, int H, int D, int nb_scales, const bcd_hip_params *prm)
+{
+    if (!prm) { fail(m, "null parameters"); return BCD_HIP_EINVAL; }
+    if (W <= 0 || H <= 0 || D <= 0 || nb_scales < 1 || nb_scales > MAX_S) { fail(m, "bad image size or number of scales"); return BCD_HIP_EINVAL; }
+    job.m = m; job.h_col = job.h_ns = job.h_hist = job.h_cov = nullptr; job.h_out = nullptr;
+    job.W = W; job.H = H; job.D = D; job.S = nb_scales; job.prm = *prm;
+    std::string err;
+    if (!job.geom.init(W, H, nb_scales, prm->search_radius, prm->patch_radius, m->n, err)) { fail(m, err); return BCD_HIP_EINVAL; }
+    if ((W >> (nb_scales - 1)) < 2 * prm->patch_radius + 1) { fail(m, "too many scales for this image size"); return BCD_HIP_EINVAL; }
+    return BCD_HIP_OK;
+}
+
+void reset_error(bcd_hip_multi *m)
+{
+    std::lock_guard<std::mutex> lk(m->err_mutex);
+    m->err.clear();
+    m->abort_flag.store(false);
 }
 
 } // namespace
@@ -435,7 +513,8 @@ void bcd_hip_multi_destroy(bcd_hip_multi *m)
     if (!m) return;
     for (int c = 0; c <= MAX_S; ++c)
         if (m->comm_ready[c])
-            for (int r = 0; r < m->n; ++r) (void)ncclCommDestroy(m->comm[c][r]);
+            for (int r = 0; r < m->n; ++r)
+                if (m->local_rank < 0 || r == m->local_rank) (void)ncclCommDestroy(m->comm[c][r]);
     for (int r = 0; r < m->n; ++r) {
         (void)hipSetDevice(m->devices[r]);
         for (int s = 0; s < MAX_S; ++s)
@@ -462,37 +541,15 @@ int bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const fl
                                int nb_scales, const bcd_hip_params *prm, float *h_out)
 {
     if (!m) return BCD_HIP_EINVAL;
-    {
-        std::lock_guard<std::mutex> lk(m->err_mutex);
-        m->err.clear();
-    }
-    m->abort_flag.store(false);
-    if (!h_colors || !h_ns || !h_hist || !h_cov || !h_out || !prm) { fail(m, "null pointer"); return BCD_HIP_EINVAL; }
-    if (W <= 0 || H <= 0 || D <= 0 || nb_scales < 1 || nb_scales > MAX_S) { fail(m, "bad image size or number of scales"); return BCD_HIP_EINVAL; }
+    reset_error(m);
+    if (m->local_rank >= 0) { fail(m, "this handle drives one rank of several processes: use the bcd_hip_multi_rank_* calls"); return BCD_HIP_EINVAL; }
+    if (!h_colors || !h_ns || !h_hist || !h_cov || !h_out) { fail(m, "null pointer"); return BCD_HIP_EINVAL; }
     Job job;
-    job.m = m; job.h_col = h_colors; job.h_ns = h_ns; job.h_hist = h_hist; job.h_cov = h_cov; job.h_out = h_out;
-    job.W = W; job.H = H; job.D = D; job.S = nb_scales; job.prm = *prm;
-    std::string err;
-    if (!job.geom.init(W, H, nb_scales, prm->search_radius, prm->patch_radius, m->n, err)) { fail(m, err); return BCD_HIP_EINVAL; }
-    if ((W >> (nb_scales - 1)) < 2 * prm->patch_radius + 1) { fail(m, "too many scales for this image size"); return BCD_HIP_EINVAL; }
-    // ---- lazily: contexts / streams per rank and channel, communicators per channel
-    const int S = nb_scales;
-    for (int r = 0; r < m->n; ++r) {
-        if (hipSetDevice(m->devices[r]) != hipSuccess) { fail(m, "hipSetDevice failed"); return BCD_HIP_EDEVICE; }
-        for (int c = 0; c <= S; ++c) {
-            if (m->ctx[r][c]) continue;
-            if (hipStreamCreateWithFlags(&m->stream[r][c], hipStreamNonBlocking) != hipSuccess ||
-                bcd_hip_ctx_create(&m->ctx[r][c], m->devices[r], m->stream[r][c]) != BCD_HIP_OK) { fail(m, "cannot create an engine context"); return BCD_HIP_EDEVICE; }
-            if (m->use_rccl && hipMalloc((void **)&m->d_red[r][c], 64) != hipSuccess) { fail(m, "hipMalloc failed"); return BCD_HIP_ENOMEM; }
-        }
-    }
-    if (m->use_rccl)
-        for (int c = 0; c <= S; ++c) {
-            if (m->comm_ready[c]) continue;
-            const ncclResult_t r = ncclCommInitAll(m->comm[c], m->n, m->devices);
-            if (r != ncclSuccess) { fail(m, std::string("ncclCommInitAll failed: ") + ncclGetErrorString(r)); return BCD_HIP_EDEVICE; }
-            m->comm_ready[c] = true;
-        }
+    int rc = make_job(m, job, W, H, D, nb_scales, prm);
+    if (rc != BCD_HIP_OK) return rc;
+    job.h_col = h_colors; job.h_ns = h_ns; job.h_hist = h_hist; job.h_cov = h_cov; job.h_out = h_out;
+    rc = prepare(m, nb_scales);
+    if (rc != BCD_HIP_OK) return rc;
     std::vector<std::thread> th;
     std::vector<char> ok(m->n, 1);
     for (int r = 1; r < m->n; ++r) th.emplace_back([&, r]() { ok[r] = rank_worker(job, r) ? 1 : 0; });
@@ -502,6 +559,94 @@ int bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const fl
         if (!ok[r]) { fail(m, "a rank failed"); return BCD_HIP_EDEVICE; }
     m->stats.frames += 1;
     return BCD_HIP_OK;
+}
+
+// ---- one process per GPU -------------------------------------------------------------------------------------------------------
+int bcd_hip_multi_unique_id(char *out128)
+{
+    if (!out128) return BCD_HIP_EINVAL;
+    static_assert(sizeof(ncclUniqueId) == BCD_HIP_MULTI_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return BCD_HIP_EDEVICE;
+    memcpy(out128, &id, sizeof(id));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_multi_create_rank(bcd_hip_multi **out, int rank, int n_ranks, int device, const char *ids, int n_ids)
+{
+    if (!out || rank < 0 || n_ranks < 1 || rank >= n_ranks || n_ranks > MAX_RANKS || (n_ranks > 1 && (!ids || n_ids < 2))) return BCD_HIP_EINVAL;
+    std::vector<int> devices(n_ranks, device);
+    int rc = bcd_hip_multi_create(out, devices.data(), n_ranks);
+    if (rc != BCD_HIP_OK) return rc;
+    bcd_hip_multi *m = *out;
+    m->local_rank = rank;
+    m->use_rccl = true; // ranks of other processes are only reachable through RCCL
+    m->stats.transport = 1;
+    for (int i = 0; i < n_ids && n_ranks > 1; ++i) {
+        ncclUniqueId id;
+        memcpy(&id, ids + (size_t)i * sizeof(id), sizeof(id));
+        m->ids.push_back(id);
+    }
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_multi_rank_configure(bcd_hip_multi *m, int W, int H, int D, int nb_scales, const bcd_hip_params *prm, int *first_input_line,
+                                 int *nb_input_lines, int *first_owned_line, int *nb_owned_lines)
+{
+    if (!m) return BCD_HIP_EINVAL;
+    reset_error(m);
+    if (m->local_rank < 0) { fail(m, "not a one-rank handle"); return BCD_HIP_EINVAL; }
+    Job job;
+    int rc = make_job(m, job, W, H, D, nb_scales, prm);
+    if (rc != BCD_HIP_OK) return rc;
+    rc = prepare(m, nb_scales);
+    if (rc != BCD_HIP_OK) return rc;
+    m->frame.W = W; m->frame.H = H; m->frame.D = D; m->frame.S = nb_scales; m->frame.prm = *prm; m->frame.set = true;
+    ScaleBand bands[MAX_S];
+    job.geom.bands(m->local_rank, bands);
+    if (first_input_line) *first_input_line = bands[0].loc0;
+    if (nb_input_lines) *nb_input_lines = bands[0].loc1 - bands[0].loc0;
+    if (first_owned_line) *first_owned_line = bands[0].own0;
+    if (nb_owned_lines) *nb_owned_lines = bands[0].own1 - bands[0].own0;
+    return BCD_HIP_OK;
+}
+
+static int rank_job(bcd_hip_multi *m, Job &job)
+{
+    if (!m) return BCD_HIP_EINVAL;
+    reset_error(m);
+    if (m->local_rank < 0 || !m->frame.set) { fail(m, "bcd_hip_multi_rank_configure has not been called"); return BCD_HIP_EINVAL; }
+    return make_job(m, job, m->frame.W, m->frame.H, m->frame.D, m->frame.S, &m->frame.prm);
+}
+
+int bcd_hip_multi_rank_upload(bcd_hip_multi *m, const float *h_colors, const float *h_ns, const float *h_hist, const float *h_cov)
+{
+    Job job;
+    int rc = rank_job(m, job);
+    if (rc != BCD_HIP_OK) return rc;
+    if (!h_colors || !h_ns || !h_hist || !h_cov) { fail(m, "null pointer"); return BCD_HIP_EINVAL; }
+    job.h_col = h_colors; job.h_ns = h_ns; job.h_hist = h_hist; job.h_cov = h_cov;
+    return rank_upload(job, m->local_rank, true) ? BCD_HIP_OK : BCD_HIP_EDEVICE;
+}
+
+int bcd_hip_multi_rank_step(bcd_hip_multi *m)
+{
+    Job job;
+    int rc = rank_job(m, job);
+    if (rc != BCD_HIP_OK) return rc;
+    if (!rank_compute(job, m->local_rank)) return BCD_HIP_EDEVICE;
+    m->stats.frames += 1;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_multi_rank_download(bcd_hip_multi *m, float *h_out_owned)
+{
+    Job job;
+    int rc = rank_job(m, job);
+    if (rc != BCD_HIP_OK) return rc;
+    if (!h_out_owned) { fail(m, "null pointer"); return BCD_HIP_EINVAL; }
+    job.h_out = h_out_owned;
+    return rank_download(job, m->local_rank, true) ? BCD_HIP_OK : BCD_HIP_EDEVICE;
 }
 
 } // extern "C"

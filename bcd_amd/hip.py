@@ -42,6 +42,8 @@ SYMBOLS = [
     "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_set_progress_callback",
     "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_denoise_host",
+    "bcd_hip_multi_unique_id", "bcd_hip_multi_create_rank", "bcd_hip_multi_rank_configure", "bcd_hip_multi_rank_upload", "bcd_hip_multi_rank_step",
+    "bcd_hip_multi_rank_download",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
@@ -380,6 +382,65 @@ class MultiDenoiser:
         s = MultiStats()
         lib().bcd_hip_multi_get_stats(self.h, C.byref(s))
         return s
+
+
+MULTI_ID_BYTES = 128
+
+
+def multi_unique_ids(n):
+    """n RCCL unique ids (bytes), to be created by rank 0 and handed to every process (bcd_hip_multi_create_rank)"""
+    out = b""
+    for _ in range(n):
+        buf = C.create_string_buffer(MULTI_ID_BYTES)
+        rc = lib().bcd_hip_multi_unique_id(buf)
+        if rc != 0:
+            raise BcdHipError("bcd_hip_multi_unique_id rc=%d" % rc)
+        out += buf.raw
+    return out
+
+
+class RankDenoiser:
+    """one rank of the row-band partition in a one-process-per-GPU job (bcd_hip_multi_rank_*): the band's inputs and result stay in HBM"""
+
+    def __init__(self, rank, world, device, ids):
+        h = _VP()
+        lib().bcd_hip_multi_last_error.restype = C.c_char_p
+        lib().bcd_hip_multi_last_error.argtypes = [_VP]
+        lib().bcd_hip_multi_destroy.argtypes = [_VP]
+        lib().bcd_hip_multi_destroy.restype = None
+        rc = lib().bcd_hip_multi_create_rank(C.byref(h), rank, world, device, ids, len(ids) // MULTI_ID_BYTES if ids else 0)
+        if rc != 0:
+            raise BcdHipError("bcd_hip_multi_create_rank failed: rc=%d" % rc)
+        self.h, self.rank, self.world = h, rank, world
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise BcdHipError("rc=%d: %s" % (rc, lib().bcd_hip_multi_last_error(self.h).decode()))
+
+    def configure(self, W, H, D, nscales, prm):
+        """-> (first input line, input lines, first owned line, owned lines) of this rank's band"""
+        v = [C.c_int(0) for _ in range(4)]
+        self._chk(lib().bcd_hip_multi_rank_configure(self.h, W, H, D, nscales, C.byref(prm), *[C.byref(x) for x in v]))
+        self.W, self.owned = W, (v[2].value, v[3].value)
+        return tuple(x.value for x in v)
+
+    def upload(self, col, ns, hist, cov):
+        f = lambda a: a.ctypes.data_as(_F)
+        self._chk(lib().bcd_hip_multi_rank_upload(self.h, f(col), f(ns), f(hist), f(cov)))
+
+    def step(self):
+        self._chk(lib().bcd_hip_multi_rank_step(self.h))
+
+    def download(self):
+        import numpy as np
+        out = np.empty((self.owned[1], self.W, 3), np.float32)
+        self._chk(lib().bcd_hip_multi_rank_download(self.h, out.ctypes.data_as(_F)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().bcd_hip_multi_destroy(self.h)
+            self.h = None
 
 
 def visit_order(W, H, w, random_order, seed):

@@ -140,6 +140,19 @@ const char *bcd_hip_multi_last_error(const bcd_hip_multi *m);
 int  bcd_hip_multi_get_stats(const bcd_hip_multi *m, bcd_hip_multi_stats *out);
 int  bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const float *h_nsamples, const float *h_histograms,
                                 const float *h_covariances, int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out);
+/* The same partition with ONE PROCESS PER GPU (torchrun / MPI style; what bench.py --gpus N uses): every process creates the handle
+ * of its own rank from unique ids all processes share (rank 0 calls bcd_hip_multi_unique_id once per channel -- nb_scales + 1 of
+ * them -- and distributes the bytes by whatever means the launcher offers), configures the frame, uploads the lines
+ * [first_input_line, +nb_input_lines) of the four inputs once, and calls bcd_hip_multi_rank_step per frame: inputs and result of
+ * the band stay in HBM.  bcd_hip_multi_rank_download copies the owned lines [first_owned_line, +nb_owned_lines) of the result. */
+#define BCD_HIP_MULTI_ID_BYTES 128
+int  bcd_hip_multi_unique_id(char *out /* BCD_HIP_MULTI_ID_BYTES */);
+int  bcd_hip_multi_create_rank(bcd_hip_multi **m, int rank, int n_ranks, int device, const char *ids, int n_ids);
+int  bcd_hip_multi_rank_configure(bcd_hip_multi *m, int W, int H, int D, int nb_scales, const bcd_hip_params *prm, int *first_input_line,
+                                  int *nb_input_lines, int *first_owned_line, int *nb_owned_lines);
+int  bcd_hip_multi_rank_upload(bcd_hip_multi *m, const float *h_colors, const float *h_nsamples, const float *h_histograms, const float *h_covariances);
+int  bcd_hip_multi_rank_step(bcd_hip_multi *m);
+int  bcd_hip_multi_rank_download(bcd_hip_multi *m, float *h_out_owned);
 
 /* ---- whole path, host buffers (what bcd::Denoiser / bcd_cli call): H2D + denoise + D2H -------- */
 int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_nsamples,

@@ -833,3 +833,29 @@ def test_bcd_cli_devices_list(hipctx, tmp_path):
     assert np.max(np.abs(outs[0] - outs[1])) <= 2e-3 * np.max(outs[0])   # both files are half precision
     r = subprocess.run([exe, "-i", stem + ".exr", "-o", str(tmp_path / "x.exr"), "--devices", "3-1"], capture_output=True, text=True)
     assert r.returncode == 1 and "--devices" in r.stdout
+
+
+@pytest.mark.gpu
+def test_one_process_per_gpu_rank_api_with_one_rank(hipctx):
+    """bcd_hip_multi_rank_* (what bench.py --gpus N drives, one process per GPU): with a single rank the band is the frame; the
+    resident-input / step / download cycle must give the single-GPU result, twice"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    W, H, S = 128, 96, 3
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 21, 0.12, 0.005)
+    prm = bh.default_params(m=1.0, random_order=1, seed=9)
+    want = hipctx.denoise_host(col, ns, hist, cov, S, prm)
+    rd = bh.RankDenoiser(0, 1, 0, None)
+    try:
+        l0, nl, o0, no = rd.configure(W, H, 60, S, prm)
+        assert (l0, nl, o0, no) == (0, H, 0, H)
+        rd.upload(col, ns, hist, cov)
+        rd.step()
+        a = rd.download()
+        rd.step()
+        b_ = rd.download()
+    finally:
+        rd.close()
+    assert rel_linf(a, want) < 1e-5 and rel_linf(b_, want) < 1e-5
+    ids = bh.multi_unique_ids(2)
+    assert len(ids) == 2 * bh.MULTI_ID_BYTES and ids[:128] != ids[128:]
