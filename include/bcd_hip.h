@@ -140,7 +140,7 @@ const char *bcd_hip_multi_last_error(const bcd_hip_multi *m);
 int  bcd_hip_multi_get_stats(const bcd_hip_multi *m, bcd_hip_multi_stats *out);
 int  bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const float *h_nsamples, const float *h_histograms,
                                 const float *h_covariances, int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out);
-/* The same partition with ONE PROCESS PER GPU (torchrun / MPI style; what bench.py --gpus N uses): every process creates the handle
+/* The same partition with ONE PROCESS PER GPU (MPI-style launchers; what bench.py --gpus N uses): every process creates the handle
  * of its own rank from unique ids all processes share (rank 0 calls bcd_hip_multi_unique_id once per channel -- nb_scales + 1 of
  * them -- and distributes the bytes by whatever means the launcher offers), configures the frame, uploads the lines
  * [first_input_line, +nb_input_lines) of the four inputs once, and calls bcd_hip_multi_rank_step per frame: inputs and result of
