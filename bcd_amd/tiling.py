@@ -215,7 +215,8 @@ def band_program_exact(eng, geom, rank, col, ns, hist, cov, prm, seed0):
         state = eng.active_init(nsim, w, r0, r1, prm.marked_skip_probability, seed, row_offset)
         if prm.marked_skip_probability > 0:
             first = prm.marked_skip_probability >= 1.0
-            for _ in range(4 * (sb.W + sb.H) + 64):
+            before = None
+            while True:   # every batch decides at least the earliest undecided pixel of the frame: ends after finitely many batches
                 got_up, got_down = yield ("st%d" % s, [state[r0:r0 + b].contiguous()] if up else None, [state[r1 - b:r1].contiguous()] if down else None)
                 if up:
                     state[r0 - b:r0] = got_up[0]
@@ -226,8 +227,9 @@ def band_program_exact(eng, geom, rank, col, ns, hist, cov, prm, seed0):
                 total = yield ("sum", left)
                 if total == 0:
                     break
-            else:
-                raise RuntimeError("marking fixed point did not converge")
+                if before is not None and total > before:
+                    raise RuntimeError("marking fixed point made no progress")
+                before = total
         state[:r0] = 0                                              # halo lines are processed by their owner
         state[r1:] = 0
         accs.append(eng.bayes(c_, v_, n_, h_, mask, nsim, state, prm))

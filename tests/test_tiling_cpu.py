@@ -161,3 +161,66 @@ def test_two_processes_gloo_exact_marking():
     got = np.concatenate([res[r] for r in range(world)], 0)
     want = ol.denoise_mono(*_inputs(W, H), ol.params(b=Prm.search_radius, m=1.0), order=_visit_order_global(W, H, 1, 1, 5))
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-6
+
+
+@pytest.mark.parametrize("m,random_order", [(0.0, 0), (1.0, 1)])
+def test_three_scales_b6_bands_match_full_frame(m, random_order):
+    """BASELINE configs[3]'s geometry (3 scales, b = 6: bands aligned to 4 lines, 7 halo lines per scale) at a reduced size, two
+    virtual ranks, oracle engine: -m 0 and the exact -m 1 program against the full frame in the same visiting order"""
+    W, H, S, world = 40, 64, 3, 2
+    arrs = _inputs(W, H, spp=8)
+    prm = Prm()
+    prm.search_radius = 6
+    prm.marked_skip_probability = m
+    prm.use_random_pixel_order = random_order
+    g = BandGeometry(W, H, S, prm.search_radius, 1, world)
+    outs = run_virtual(OracleEngine(None), g, [_slice(arrs, g, r) for r in range(world)], prm, 5, exact_marking=m > 0)
+    got = np.concatenate([o.numpy() for o in outs], 0)
+    orders, w_, h_ = None, W, H
+    if m > 0:
+        orders = []
+        for s in range(S):
+            orders.append(_visit_order_global(w_, h_, 1, random_order, 5 + s))
+            w_, h_ = w_ // 2, h_ // 2
+    want = ol.denoise_multiscale(*arrs, S, ol.params(b=6, m=m, threads=1), orders=orders)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-6
+
+
+def _gloo_worker_b6(rank, world, port, W, H, S, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    arrs = _inputs(W, H, spp=8)
+    prm = Prm()
+    prm.search_radius = 6
+    prm.marked_skip_probability = 1.0
+    prm.use_random_pixel_order = 1
+    g = BandGeometry(W, H, S, prm.search_radius, 1, world)
+    out = run_distributed(OracleEngine(None), g, rank, dist, _slice(arrs, g, rank), prm, 5, exact_marking=True)
+    q.put((rank, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_gloo_three_scales_b6_exact_marking():
+    """the same over two real processes (gloo): isend / irecv of |S|, states, accumulator and output lines + the all-reduce"""
+    import torch.multiprocessing as mp
+    W, H, S, world = 40, 64, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker_b6, args=(r, world, port, W, H, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got = np.concatenate([res[r] for r in range(world)], 0)
+    orders, w_, h_ = [], W, H
+    for s in range(S):
+        orders.append(_visit_order_global(w_, h_, 1, 1, 5 + s))
+        w_, h_ = w_ // 2, h_ // 2
+    want = ol.denoise_multiscale(*_inputs(W, H, spp=8), S, ol.params(b=6, m=1.0), orders=orders)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-6
