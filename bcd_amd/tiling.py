@@ -227,7 +227,7 @@ def band_program_exact(eng, geom, rank, col, ns, hist, cov, prm, seed0):
                 total = yield ("sum", left)
                 if total == 0:
                     break
-                if before is not None and total > before:
+                if before is not None and total >= before:
                     raise RuntimeError("marking fixed point made no progress")
                 before = total
         state[:r0] = 0                                              # halo lines are processed by their owner
