@@ -79,6 +79,7 @@ struct Work {
     int border_capacity = 0;       // entries of `border` offered to the last fast similarity pass (0: the exact kernels ran)
     int rounds_hint = 0;           // marking launches the last problem needed
     bool dep_ready = false;        // dependency lists of the current marking problem are in `dep` (reset by active_init)
+    const void *dep_mask = nullptr, *dep_state = nullptr; // ... extracted for these buffers (another problem on the same context rebuilds them)
     int32_t *h_counters = nullptr; // pinned
     bool initialised = false;      // set once every stream / event / pinned buffer below exists
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; // pair-distance kernel timing
@@ -307,11 +308,14 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
         const int iters = 8; // in-tile iterations per launch
         int i = 0;
         batch = random_order ? 3 : ROUND_BATCH;
+        if (wk.dep_ready && (wk.dep_mask != (const void *)d_mask || wk.dep_state != (const void *)d_state)) wk.dep_ready = false;
         if (!wk.dep_ready) {
             RCCHK(ensure(ctx, wk.dep, (size_t)W * H * words * sizeof(uint32_t)));
             HIPCHK(ctx, bcd_launch_mark_deps(d_mask, d_nsim, d_state, (uint32_t *)wk.dep.p, W, H, b, K + 1, random_order, seed,
                                              row_begin, row_end, row_offset, d_cnt + i++, wk.stream));
             wk.dep_ready = true;
+            wk.dep_mask = d_mask;
+            wk.dep_state = d_state;
             // first batch: what the previous marking problem of this workspace needed, plus one (frames of a sequence and
             // the bands of a frame behave alike), so that the usual case costs a single host round trip
             if (random_order) batch = std::min(ROUND_BATCH, std::max(5, wk.rounds_hint + 1));
@@ -937,7 +941,8 @@ int bcd_hip_active_step(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t 
     if (!ctx || !d_mask || !d_count || !d_state || !undecided) return bad(ctx, "bad argument");
     DEVICE_GUARD(ctx);
     int u = 0;
-    ctx->main.dep_ready = false; // stateless entry point: the dependency lists are rebuilt from (mask, count, state) on every call
+    // the dependency lists extracted by the first step after bcd_hip_active_init stay valid for the following steps of the same
+    // marking problem on the same buffers (masks and counts do not change; a pixel that is still undecided keeps its list)
     RCCHK(active_step(ctx, ctx->main, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, random_order, seed, row_offset, first_pass != 0,
                       d_state, &u, nullptr));
     *undecided = u;

@@ -190,8 +190,8 @@ int bcd_hip_active_set(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *
                        uint8_t *d_state, int32_t *rounds);
 /* the two halves of bcd_hip_active_set, for the multi-GPU band path: between two steps neighbouring bands exchange the states
  * of their boundary lines.  Only lines [main_row_begin, main_row_end) are initialised / decided; row_offset = line of the full
- * frame under local line 0 (keys and hashes are functions of the global pixel index).  bcd_hip_active_step is stateless: it
- * rebuilds the dependency lists from (mask, count, state) on every call; first_pass is a hint ("everything still undecided")
+ * frame under local line 0 (keys and hashes are functions of the global pixel index).  bcd_hip_active_step keeps the dependency
+ * lists it extracts on the first call after bcd_hip_active_init (same masks and counts until the next init); first_pass is a hint ("everything still undecided")
  * that implementations may ignore. */
 int bcd_hip_active_init(bcd_hip_ctx *ctx, const int32_t *d_count, int W, int H, int patch_radius, int main_row_begin, int main_row_end,
                         float skip_probability, uint32_t seed, int row_offset, uint8_t *d_state);
