@@ -1,11 +1,14 @@
 // ImageIO.h -- EXR <-> DeepImage, API of the reference's include/bcd/io/ImageIO.h:22-38.
 // OpenEXR is not available on the target boxes, so the codec underneath is this build's own minimal scanline
 // reader/writer (bcd_amd/host/ImageIO.cpp): single-part scanline files, channels HALF / FLOAT / UINT without
-// subsampling, compression NONE / RLE / ZIPS / ZIP.  (PIZ / PXR24 / B44 / DWA, tiled, deep and multi-part files are
-// reported as unsupported.)  File conventions of the reference (src/io/exr/io_exr.cpp):
+// subsampling, compression NONE / RLE / ZIPS / ZIP / PIZ on reading (ZIP on writing).  (PXR24 / B44 / DWA, tiled, deep and multi-part
+// files are reported as unsupported.)  File conventions of the reference (src/io/exr/io_exr.cpp):
 //   colours     : channels R, G, B (read as float whatever their storage type); written as HALF A,B,G,R with A = 1
 //   histograms  : FLOAT channels Bin_0000 ... Bin_{D}, the LAST one being the number of samples (src/core/Utils.cpp:21-45)
 //   covariances : FLOAT channels Bin_0000 ... Bin_0005 = xx, yy, zz, yz, xz, xy
+// The declarations below keep the names and member layout of the reference's include/bcd/io/ImageIO.h (BCD -- Bayesian Collaborative Denoising for
+// Monte-Carlo Rendering, M. Boughida and T. Boubekeur, Computer Graphics Forum (Proc. EGSR 2017) 36(4); BSD-style licence, see the
+// reference's LICENSE.txt) so that callers written against it compile unchanged; the implementation behind them is this build's own.
 #ifndef IMAGE_IO_H
 #define IMAGE_IO_H
 

@@ -6,6 +6,9 @@
 //   performSpikeRemovalPrefiltering, spikeRemovalThresholdStDevFactor
 //   nbOfScales, histoDistanceThreshold, useCuda, nbOfCores, patchRadius, searchWindowRadius, randomPixelOrder,
 //   markedPixelsSkippingProbability, minEigenValue
+// The declarations below keep the names and member layout of the reference's include/bcd/io/ParametersIO.h (BCD -- Bayesian Collaborative Denoising for
+// Monte-Carlo Rendering, M. Boughida and T. Boubekeur, Computer Graphics Forum (Proc. EGSR 2017) 36(4); BSD-style licence, see the
+// reference's LICENSE.txt) so that callers written against it compile unchanged; the implementation behind them is this build's own.
 #ifndef PARAMETERS_IO_H
 #define PARAMETERS_IO_H
 

@@ -5,11 +5,16 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_$C -o t -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $R/gpurun_out/pmc_$C.log 2>&1
+  rm -rf $R/gpurun_out/pmc_$C
+  rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_$C -o t -- python $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 "$@" > $R/gpurun_out/pmc_$C.log 2>&1
 done
-python - $R <<'PY'
+python - $R "$@" <<'PY'
 import sqlite3, sys, json, glob, os
 R = sys.argv[1]
+W, H = 1920, 1080
+for i, a in enumerate(sys.argv):
+    if a == "--width": W = int(sys.argv[i + 1])
+    if a == "--height": H = int(sys.argv[i + 1])
 res = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     db = sqlite3.connect(glob.glob(os.path.join(R, "gpurun_out", "pmc_" + C, "*.db"))[0])
@@ -26,9 +31,11 @@ fetch_kb = res["FETCH_SIZE"]["sum_kb"] / res["FETCH_SIZE"]["dispatches"]
 write_kb = res["WRITE_SIZE"]["sum_kb"] / res["WRITE_SIZE"]["dispatches"]
 # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
 # (16 B/lane) coalesced streaming read -> doubled.  WRITE_SIZE is uncalibrated, reported as is.
-out = {"1280x720_s3": {"kernel": "k_pairdist<60>", "fetch_size_kb_per_launch_raw": fetch_kb, "write_size_kb_per_launch_raw": write_kb,
+path = os.path.join(R, "gpurun_out", "pmc_traffic.json")
+out = json.load(open(path)) if os.path.exists(path) else {}
+out["%dx%d_s3" % (W, H)] = {"kernel": "k_pairdist_rw<60>", "fetch_size_kb_per_launch_raw": fetch_kb, "write_size_kb_per_launch_raw": write_kb,
                        "hbm_bytes_per_launch_avg": int((2 * fetch_kb + write_kb) * 1024),
-                       "note": "avg over the 3 scale launches of a 3-scale 720p step; read side = 2 x FETCH_SIZE (gfx950 correction), write side WRITE_SIZE as reported"}}
-json.dump(out, open(os.path.join(R, "gpurun_out", "pmc_traffic.json"), "w"), indent=1)
+                       "note": "avg over the 3 scale launches of a 3-scale step; read side = 2 x FETCH_SIZE (gfx950 correction), write side WRITE_SIZE as reported"}
+json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out))
 PY
