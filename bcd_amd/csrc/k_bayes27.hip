@@ -620,8 +620,9 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
-    // PHASE 1 has no use for V: three matrix buffers (15 wavefronts per CU instead of 12)
-    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = PHASE == 1 ? V : V + MSZ; // A, V contiguous: reused as the aggregation window
+    // PHASE 1 needs two matrix buffers only (C, and the member chunk / Jacobi-layout matrix): 20 wavefronts per CU instead of 12,
+    // which is what its member gathers want (58 % of its wave cycles wait for memory)
+    float *Cm = lds, *A = PHASE == 1 ? Cm : Cm + MSZ, *V = A + MSZ, *Bm = PHASE == 1 ? Cm + MSZ : V + MSZ; // A, V contiguous: reused as the aggregation window
     float *chunk = Bm;                         // member-staging chunk: Bm is free while the clouds are streamed (mean/covariance, output)
     float *cs = Bm + MSZ;                      // 2 x 28 floats (scratch of the spectral inverse), read as float4: offsets are multiples of 16 bytes
     float *noise = cs + 2 * KP;
@@ -672,14 +673,13 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: a chain of fma in member order, i.e. the reference's sequential sum with the
     // product fused; A and B operands are the same centred value, so the result is bitwise symmetric).
     // Operand layout: lane l holds element i = l & 31 of member 2s + (l >> 5); rows/columns 27..31 are zero.
-    covariance27(A, Cm, chunk, mean, colors, mem, p, g.b, n, W, lane);
+    covariance27(A, Cm, chunk, mean, colors, mem, p, g.b, n, W, lane); // (A is Cm here)
+    for (int e = lane; e < MSZ / 4; e += 64) reinterpret_cast<float4 *>(recC)[e] = reinterpret_cast<const float4 *>(Cm)[e];
+    __syncthreads();
     // ---- Step 1 (:421-436), first half: the matrix whose negative eigenvalues are clamped, C - N
-    add_noise27(A, noise, lane, -1.f);
-    to_jacobi_layout(Bm, A, lane);
-    for (int e = lane; e < MSZ / 4; e += 64) {
-        reinterpret_cast<float4 *>(recA)[e] = reinterpret_cast<const float4 *>(Bm)[e];
-        reinterpret_cast<float4 *>(recC)[e] = reinterpret_cast<const float4 *>(Cm)[e];
-    }
+    add_noise27(Cm, noise, lane, -1.f);
+    to_jacobi_layout(Bm, Cm, lane);
+    for (int e = lane; e < MSZ / 4; e += 64) reinterpret_cast<float4 *>(recA)[e] = reinterpret_cast<const float4 *>(Bm)[e];
     if (lane < P * 6) recX[lane] = noise[lane];
     if (lane < K) recX[P * 6 + lane] = mean[lane];
     __syncthreads(); // the next item reuses the LDS
@@ -774,8 +774,8 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     rec.C = rec.V + (size_t)nb_items * MSZ;
     rec.aux = rec.C + (size_t)nb_items * MSZ;
     rec.eig = rec.aux + (size_t)nb_items * AUX27;
-    const size_t lds2 = bcd_bayes27_lds_bytes(b), lds1 = lds2 - MSZ * sizeof(float);
-    const int per_cu1 = (int)std::min<size_t>(16, (size_t)160 * 1024 / lds1), per_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / lds2);
+    const size_t lds2 = bcd_bayes27_lds_bytes(b), lds1 = lds2 - 2 * MSZ * sizeof(float);
+    const int per_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / lds1), per_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / lds2);
     hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
                        d_work, g, min_eig, rec, sum, cnt);
     hipLaunchKernelGGL(k_jacobi27_batch, dim3(std::min((nb_items + 1) / 2, num_cus * 12)), dim3(64), 0, st, rec.A, nb_items, d_work + 1, rec.eig, rec.V);
