@@ -277,6 +277,7 @@ __device__ void add_noise27(float *M, const float *noise, int lane, float sign)
 // lane r owns row r; at step k the pivot row is broadcast with v_readlane (k is a compile-time constant), so the 27
 // steps need no LDS traffic and no barrier.  Returns false (wave-uniform) if a pivot is not positive or the bound
 // ||M^-1||_F * min_eig <= 1 fails (then lambda_min >= min_eig is not proven); M is then unspecified.
+
 __device__ inline float bcast_lane(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
 __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
@@ -293,14 +294,17 @@ __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
         ok = ok && (d > 0.f);
         const float inv_d = 1.f / d;
         const bool pivot_row = (lane == k);
-        const float f = m[k] * inv_d; // a_rk / d
+        // row r != k: a_rc - (a_rk / d) a_kc;  pivot row: a_kc / d  -- one multiply + fma for every lane (h selects the old value).
+        // (Sending the pivot row through LDS instead of 27 v_readlane per step was measured: twice as slow, the step then waits
+        // for an LDS round trip.)
+        const float f = pivot_row ? -inv_d : m[k] * inv_d, h = pivot_row ? 0.f : 1.f;
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             if (c == k) continue;
             const float pkc = bcast_lane(m[c], k); // a_kc (old)
-            m[c] = pivot_row ? pkc * inv_d : fmaf(-f, pkc, m[c]);
+            m[c] = fmaf(-f, pkc, h * m[c]);
         }
-        m[k] = pivot_row ? -inv_d : f;
+        m[k] = f; // -1 / d on the pivot row, a_rk / d elsewhere
     }
     float fro = 0.f;
 #pragma unroll
