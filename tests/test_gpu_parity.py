@@ -859,3 +859,29 @@ def test_one_process_per_gpu_rank_api_with_one_rank(hipctx):
     assert rel_linf(a, want) < 1e-5 and rel_linf(b_, want) < 1e-5
     ids = bh.multi_unique_ids(2)
     assert len(ids) == 2 * bh.MULTI_ID_BYTES and ids[:128] != ids[128:]
+
+
+@pytest.mark.gpu
+def test_bcd_cli_baseline_config0_plumbing(hipctx, tmp_path):
+    """BASELINE configs[0] as far as this build goes: `bcd_cli -s 1 -b 6 -w 1 --use-cuda 0 --ncores 1 -r 0` on a 128 x 96 scene (the
+    reference bundles none: data/inputs holds a .gitignore only).  There is no CPU path -- the flag is answered with a note and the
+    HIP device runs -- but the RESULT is the CPU path's: the oracle's single-thread scanline run on the same (half-precision) colours"""
+    import subprocess
+    import bcd_amd.core as core
+    W, H = 128, 96
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 21, 0.12, 0.0)
+    stem = str(tmp_path / "scene")
+    core.write_exr(stem + ".exr", col, False)
+    core.write_exr(stem + "_hist.exr", core.merge_hist_ns(hist, ns), True)
+    core.write_exr(stem + "_cov.exr", cov, True)
+    exe = _os.path.join(_os.path.dirname(core.LIB_PATH), "bcd_cli")
+    out_path = str(tmp_path / "out.exr")
+    r = subprocess.run([exe, "-i", stem + ".exr", "-h", stem + "_hist.exr", "-c", stem + "_cov.exr", "-o", out_path, "-s", "1", "-b", "6", "-w", "1",
+                        "-r", "0", "-p", "0", "-m", "1", "--ncores", "1", "--use-cuda", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "does not have" in r.stdout                                   # the CPU request is declined loudly, not silently
+    got = core.read_exr(out_path, False)
+    col_h = core.read_exr(stem + ".exr", False)                           # colours as the CLI saw them (half on disk)
+    want = ol.denoise_mono(col_h, ns, hist, cov, ol.params(b=6, m=1.0, threads=1))   # 1 thread, -r 0: plain scanline order
+    want = np.where(np.isfinite(want) & (want >= 0), want, 0.0).astype(np.float32)
+    assert np.max(np.abs(got - want.astype(np.float16).astype(np.float32))) <= 2e-3 * np.max(want)
