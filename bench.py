@@ -134,43 +134,60 @@ def main():
 
         def step():
             ctx.denoise(*d_in, S, prm, out)
-    elif args.python_bands:
-        from bcd_amd.tiling import BandDenoiser
-        band = BandDenoiser(ctx, dist, rank, world, W, H, 60, S, prm, exact_marking=not args.band_marking)
-        g0, g1 = band.input_lines()
-        col, ns, hist, cov = core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes, g0, g1 - g0)
-        band.upload(col, ns, hist, cov)
-        step = band.step
-        parallelism = "rowband%d-%s-torchdist" % (world, "bandmark" if args.band_marking else "exactmark")
     else:
-        # native driver, one process per GPU: RCCL unique ids from rank 0, one communicator per scale + one for the merges
-        ids = [bh.multi_unique_ids(S + 1) if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(ids, src=0)
-        rd = bh.RankDenoiser(rank, world, local_rank, ids[0])
+        def python_bands(exact):
+            """the same decomposition over torch.distributed (bcd_amd/tiling.py)"""
+            from bcd_amd.tiling import BandDenoiser
+            band = BandDenoiser(ctx, dist, rank, world, W, H, 60, S, prm, exact_marking=exact)
+            g0, g1 = band.input_lines()
+            band.upload(*core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes, g0, g1 - g0))
+            return band.step, "rowband%d-%s-torchdist" % (world, "exactmark" if exact else "bandmark")
 
-        def load(w_, h_):
-            l0, nl, _, _ = rd.configure(w_, h_, 60, S, prm)
-            rd.upload(*core.synthetic_scene(w_, h_, args.spp, 1234, args.sigma, args.spikes, l0, nl))
-        # ---- the band path must reproduce the single-GPU frame: checked at a reduced size, outside the timed region
-        cw, ch = [int(v) for v in args.check_size.split("x")]
-        load(cw, ch)
-        rd.step()
-        parts = [None] * world
-        if world > 1:
-            dist.all_gather_object(parts, rd.download())
+        def native_bands():
+            """native driver, one process per GPU: RCCL unique ids from rank 0, one communicator per scale + one for the merges"""
+            ids = [bh.multi_unique_ids(S + 1) if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            rd = bh.RankDenoiser(rank, world, local_rank, ids[0])
+
+            def load(w_, h_):
+                l0, nl, _, _ = rd.configure(w_, h_, 60, S, prm)
+                rd.upload(*core.synthetic_scene(w_, h_, args.spp, 1234, args.sigma, args.spikes, l0, nl))
+            # ---- the band path must reproduce the single-GPU frame: checked at a reduced size, outside the timed region
+            cw, ch = [int(v) for v in args.check_size.split("x")]
+            load(cw, ch)
+            rd.step()
+            parts = [None] * world
+            if world > 1:
+                dist.all_gather_object(parts, rd.download())
+            else:
+                parts = [rd.download()]
+            check = None
+            if rank == 0:
+                frame = core.synthetic_scene(cw, ch, args.spp, 1234, args.sigma, args.spikes)
+                want = ctx.denoise(*[torch.from_numpy(a).cuda() for a in frame], S, prm).cpu().numpy()
+                got = np.concatenate(parts, 0)
+                err = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+                assert got.shape == want.shape and err < 1e-5, "band path differs from the single-GPU frame: %g" % err
+                check = {"size": "%dx%d" % (cw, ch), "rel_linf_vs_single_gpu": err}
+            load(W, H)
+            return rd.step, "rowband%d-exactmark-native" % world, check
+
+        band_check, native_error = None, None
+        if args.python_bands:
+            step, parallelism = python_bands(not args.band_marking)
         else:
-            parts = [rd.download()]
-        if rank == 0:
-            frame = core.synthetic_scene(cw, ch, args.spp, 1234, args.sigma, args.spikes)
-            want = ctx.denoise(*[torch.from_numpy(a).cuda() for a in frame], S, prm).cpu().numpy()
-            got = np.concatenate(parts, 0)
-            err = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
-            assert got.shape == want.shape and err < 1e-5, "band path differs from the single-GPU frame: %g" % err
-            band_check = {"size": "%dx%d" % (cw, ch), "rel_linf_vs_single_gpu": err}
-        load(W, H)
-        step = rd.step
-        parallelism = "rowband%d-exactmark-native" % world
+            try:
+                step, parallelism, band_check = native_bands()
+            except Exception as e:   # reported in the JSON line, never silent; every rank must take the same decision
+                native_error = "%s: %s" % (type(e).__name__, e)
+            failed = torch.tensor([1 if native_error else 0], device="cuda")
+            if world > 1:
+                dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+            if int(failed.item()):
+                native_error = native_error or "the native driver failed on another rank"
+                step, parallelism = python_bands(True)
+                parallelism += " (native driver unavailable: %s)" % native_error
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -272,7 +289,7 @@ def main():
             res["roofline"].update({"achieved": None, "frac": None, "launches": None, "avg_launch_ms": None,
                                     "note": "kernel timing is reported by the single-GPU run (N = 1); the band drivers keep their engine contexts inside"})
             res["roofline"].pop("whole_process", None)
-            if not args.python_bands:
+            if band_check is not None:
                 res["band_check"] = band_check
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
