@@ -511,7 +511,7 @@ def _inputs_bins(W, H, spp, nbins, sigma=0.2, seed=5):
     return mean, ns, hist, cov
 
 
-@pytest.mark.parametrize("nbins", [10, 8, 4, 40])
+@pytest.mark.parametrize("nbins", [10, 8, 4, 40, 12])
 def test_other_histogram_depths(hipctx, nbins):
     """D = 3 x bins other than 60: templated kernels for D in {12, 24, 36, 120}, the generic pair-distance kernel otherwise"""
     import bcd_amd.hip as bh
