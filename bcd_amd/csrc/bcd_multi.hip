@@ -13,9 +13,18 @@
 //   * two lines of every unmerged output and one line of every merged output travel for the merges at the band edges.
 // The result is the single-GPU frame to fp32 round-off for every -m / -r setting.
 //
-// Transport: RCCL point-to-point (ncclSend / ncclRecv grouped per neighbour exchange, one communicator per scale so that the
-// scales' exchanges do not order each other; xGMI links between neighbouring devices) when the ranks sit on distinct devices;
-// ranks that share a device (virtual split, tests on a one-GPU box) exchange through device-to-device copies and host barriers.
+// Transport: RCCL point-to-point (ncclSend / ncclRecv grouped per neighbour exchange, one communicator and stream per scale;
+// xGMI links between neighbouring devices) when the ranks sit on distinct devices; ranks that share a device (virtual split,
+// tests on a one-GPU box) exchange through device-to-device copies and host barriers.
+//
+// Issue order of the RCCL operations (CommGate): a communication kernel spins on the device until its peers' kernel of the same
+// operation runs, and HIP multiplexes the streams of a process onto a few hardware queues, so two ranks that enqueue the
+// operations of two communicators in opposite orders can block each other for good (each queue's head waits for a kernel stuck
+// behind the other queue's head).  The scales run on concurrent host threads, so their relative order is a matter of timing;
+// the gate makes it a rule instead: within a rank, scale s enqueues its first exchange only after every coarser scale has
+// enqueued its last one, and the merges' exchanges come after all of them.  Every rank then enqueues the same global sequence,
+// and operation k only ever waits for operations < k and for compute kernels.  The coarse scales finish early (a quarter of
+// the pixels each), so the finest scale reaches the gate about when they are done.
 #include "../../include/bcd_hip.h"
 #include "bcd_common.h"
 
@@ -24,6 +33,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -107,6 +117,27 @@ struct HostBarrier {
     }
 };
 
+// ---- CommGate: scale s of a rank may start communicating once the scales s + 1 .. S - 1 of that rank are through -------------
+struct CommGate {
+    std::mutex m;
+    std::condition_variable cv;
+    unsigned done = 0; // bit s: scale s has enqueued its last exchange of this frame
+    std::atomic<bool> *abort_flag = nullptr;
+    void reset() { std::lock_guard<std::mutex> lk(m); done = 0; }
+    void finish(int s)
+    {
+        { std::lock_guard<std::mutex> lk(m); done |= 1u << s; }
+        cv.notify_all();
+    }
+    bool wait_coarser(int s, int S)
+    {
+        const unsigned need = ((1u << S) - 1u) & ~((2u << s) - 1u);
+        std::unique_lock<std::mutex> lk(m);
+        while ((done & need) != need && !abort_flag->load()) cv.wait_for(lk, std::chrono::milliseconds(50));
+        return !abort_flag->load();
+    }
+};
+
 struct DBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -138,6 +169,8 @@ struct bcd_hip_multi {
     ncclComm_t comm[MAX_S + 1][MAX_RANKS];
     bool comm_ready[MAX_S + 1];
     HostBarrier barrier[MAX_S + 1];
+    CommGate gate[MAX_RANKS];
+    bool ordered = false; // CommGate in force: always with RCCL; BCD_HIP_MULTI_ORDERED=1 turns it on for the in-process transport (tests)
     // in-process transport: what every rank offers its neighbours in the current exchange, per channel
     struct Offer { const void *up = nullptr, *down = nullptr; long long value = 0; };
     Offer offer[MAX_S + 1][MAX_RANKS];
@@ -276,8 +309,11 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
     float *sum = (float *)B(bcd_hip_multi::SUM).p;
     int32_t *cnt = (int32_t *)B(bcd_hip_multi::CNT).p;
 
+    // whatever way this scale ends, the finer scales must not wait for it any longer
+    struct GateRelease { CommGate &gate; int s; ~GateRelease() { gate.finish(s); } } release{ m->gate[rank], s };
     ECHK(m, rank, c, bcd_hip_pixel_cov(c, cov, ns, W, rows, pixcov));
     ECHK(m, rank, c, bcd_hip_similarity_masks(c, hist, ns, W, rows, D, w, b, job.prm.hist_dist_threshold, mask, nsim));
+    if (m->ordered && g.world > 1 && !m->gate[rank].wait_coarser(s, g.S)) return false;
     if (job.prm.marked_skip_probability > 0.f && g.world > 1) {
         // |S| of the b boundary lines comes from their owner (locally their windows are cut by the band edge)
         if (!exchange(m, rank, s, nsim + (size_t)r0 * W, up ? nsim + (size_t)(r0 - b) * W : nullptr, (size_t)b * W * 4,
@@ -379,6 +415,7 @@ bool rank_compute(const Job &job, int rank)
     {
         std::vector<std::thread> th;
         std::vector<char> ok(S, 1);
+        m->gate[rank].reset();
         for (int s = 1; s < S; ++s) th.emplace_back([&, s]() { ok[s] = scale_worker(job, rank, s, bands) ? 1 : 0; });
         ok[0] = scale_worker(job, rank, 0, bands) ? 1 : 0;
         for (auto &t : th) t.join();
@@ -502,6 +539,9 @@ int bcd_hip_multi_create(bcd_hip_multi **out, const int *devices, int n_ranks)
     memset(m->comm_ready, 0, sizeof(m->comm_ready));
     memset(&m->stats, 0, sizeof(m->stats));
     for (int c = 0; c <= MAX_S; ++c) { m->barrier[c].parties = n_ranks; m->barrier[c].abort_flag = &m->abort_flag; }
+    for (int r = 0; r < n_ranks; ++r) m->gate[r].abort_flag = &m->abort_flag;
+    const char *ordered = getenv("BCD_HIP_MULTI_ORDERED");
+    m->ordered = m->use_rccl || (ordered && atoi(ordered) != 0);
     m->stats.n_ranks = n_ranks;
     m->stats.transport = m->use_rccl ? 1 : 0;
     *out = m;
@@ -581,6 +621,7 @@ int bcd_hip_multi_create_rank(bcd_hip_multi **out, int rank, int n_ranks, int de
     bcd_hip_multi *m = *out;
     m->local_rank = rank;
     m->use_rccl = true; // ranks of other processes are only reachable through RCCL
+    m->ordered = true;
     m->stats.transport = 1;
     for (int i = 0; i < n_ids && n_ranks > 1; ++i) {
         ncclUniqueId id;

@@ -743,6 +743,28 @@ def test_native_multi_rank_driver_equals_single_gpu(hipctx, W, H, S, ranks, m, r
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks,m", [(2, 1.0), (4, 1.0), (3, 0.0)])
+def test_native_multi_rank_driver_ordered_communication(hipctx, monkeypatch, ranks, m):
+    """the issue-order rule of the RCCL transport (CommGate in bcd_multi.hip: a scale starts communicating when the coarser
+    scales of its rank are through) exercised on the in-process transport: same frame, no deadlock"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    monkeypatch.setenv("BCD_HIP_MULTI_ORDERED", "1")
+    W, H, S = 256, 288, 3
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 21, 0.12, 0.005)
+    prm = bh.default_params(m=m, random_order=1, seed=9, b=6)
+    want = hipctx.denoise_host(col, ns, hist, cov, S, prm)
+    md = bh.MultiDenoiser([0] * ranks)
+    try:
+        got = md.denoise_host(col, ns, hist, cov, S, prm)
+        again = md.denoise_host(col, ns, hist, cov, S, prm)
+    finally:
+        md.close()
+    assert rel_linf(got, want) < 1e-5
+    assert rel_linf(again, want) < 1e-5
+
+
+@pytest.mark.gpu
 def test_native_multi_rank_driver_large_window_prefilter_random_order(hipctx):
     """BASELINE configs[4] through the band path at a reduced size: b = 12, spike prefilter (-p 1) and random order (-r 1), 3 scales"""
     import bcd_amd.hip as bh
