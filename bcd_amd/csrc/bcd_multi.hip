@@ -311,6 +311,8 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
 
     // whatever way this scale ends, the finer scales must not wait for it any longer
     struct GateRelease { CommGate &gate; int s; ~GateRelease() { gate.finish(s); } } release{ m->gate[rank], s };
+    // the finest scale is the critical path of the band: the coarse scales' persistent estimate kernels keep to a quarter of the CU slots
+    ECHK(m, rank, c, bcd_hip_set_cu_share(c, s == 0 || g.S == 1 ? 100 : 25));
     ECHK(m, rank, c, bcd_hip_pixel_cov(c, cov, ns, W, rows, pixcov));
     ECHK(m, rank, c, bcd_hip_similarity_masks(c, hist, ns, W, rows, D, w, b, job.prm.hist_dist_threshold, mask, nsim));
     if (m->ordered && g.world > 1 && !m->gate[rank].wait_coarser(s, g.S)) return false;

@@ -39,7 +39,7 @@ class ScaleStats(C.Structure):
 # every symbol include/bcd_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
-    "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
+    "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_set_cu_share", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_set_progress_callback",
     "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_denoise_host",
     "bcd_hip_multi_unique_id", "bcd_hip_multi_create_rank", "bcd_hip_multi_rank_configure", "bcd_hip_multi_rank_upload", "bcd_hip_multi_rank_step",
@@ -310,6 +310,9 @@ class Context:
 
     def set_fast_similarity(self, on):
         self._chk(lib().bcd_hip_set_fast_similarity(self.h, 1 if on else 0))
+
+    def set_cu_share(self, percent):
+        self._chk(lib().bcd_hip_set_cu_share(self.h, int(percent)))
 
     def selftest_approx_distance(self, hist, ns, b):
         """(max relative deviation of a patch distance, pairs with different bin counts, flags) of the approximate distance planes

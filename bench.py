@@ -17,6 +17,7 @@ One JSON line on rank 0 (contract in the task statement), with the extra objects
 kernel, HIP-event timed inside this process) and `cpu_baseline` (oracle on host cores, bounded sample).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -51,6 +52,7 @@ def parse():
     ap.add_argument("--band-marking", action="store_true", help="with --python-bands: every band marks on its own (a valid order, NOT the single-GPU frame)")
     ap.add_argument("--band-path", action="store_true", help="use the multi-GPU row-band code path even with one rank (debug)")
     ap.add_argument("--check-size", default="640x576", help="N > 1: frame size of the equality check against a single-GPU run on rank 0")
+    ap.add_argument("--watchdog", type=int, default=900, help="N > 1: seconds after which a run that has not reached its JSON line dumps every thread's stack and exits (a blocked collective would otherwise hang the launcher)")
     ap.add_argument("--cpu-sample", default="960x540", help="frame size of the bounded CPU-baseline sample (all host cores)")
     ap.add_argument("--cpu-sample-1core", default="160x90", help="frame size of the one-core CPU-baseline sample")
     return ap.parse_args()
@@ -114,6 +116,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.band_path:
+        import faulthandler
+        if args.watchdog > 0:
+            faulthandler.dump_traceback_later(args.watchdog, exit=True)
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
@@ -293,8 +298,13 @@ def main():
                 res["band_check"] = band_check
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
+        # native libraries (RCCL's version banner) write to the C stdio buffer: flush it first so that the JSON line is the last line
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(res), flush=True)
     if dist is not None:
+        if args.watchdog > 0:
+            faulthandler.cancel_dump_traceback_later()
         dist.destroy_process_group()
 
 

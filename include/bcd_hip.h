@@ -86,6 +86,11 @@ int  bcd_hip_set_concurrent_scales(bcd_hip_ctx *ctx, int enabled);
  * tau (1 +- 2^-14) (default on for w = 1 and D in {24, 36, 60}; also disabled by BCD_HIP_EXACT_SIMILARITY=1).  The masks are
  * bit-identical either way; 0 forces the exact kernels. */
 int  bcd_hip_set_fast_similarity(bcd_hip_ctx *ctx, int enabled);
+/* share (1..100 %, default 100) of the device's CU slots the persistent estimate kernels of this context occupy.  A caller that
+ * runs several contexts on one device at once lowers it for the contexts that have slack, so that the short kernels of the one on
+ * the critical path find room beside them (bcd_hip_denoise does this itself for its coarse scales; the multi-GPU driver uses
+ * it for its per-scale contexts).  Results do not depend on it. */
+int  bcd_hip_set_cu_share(bcd_hip_ctx *ctx, int percent);
 int  bcd_hip_set_progress_callback(bcd_hip_ctx *ctx, bcd_hip_progress_fn fn, void *user);
 int  bcd_hip_get_stats(const bcd_hip_ctx *ctx, int scale, bcd_hip_scale_stats *out);
 /* duration (ms, HIP events on the context's stream) and launch count of the pair-distance kernel
