@@ -73,7 +73,7 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
     float *ring = reinterpret_cast<float *>(lds4);
     float *ring_n = ring + 4 * L::ROW;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (wave-uniform: loop control on the scalar unit)
     const int ty = wave & 3, hv = wave >> 2; // the two halves of a tile line land on the same SIMD
     int tile;
     {
@@ -186,11 +186,13 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                     auto den = [&](float s_) __attribute__((always_inline)) { return UNI ? s_ : n12 * s_; };
                     // a wave-uniform branch per group of 4 bins (most groups are empty for all 64 pixels of a line segment), then a
                     // divergent branch (execz) per bin: DenoisingUnit.cpp:379 decides exactly which bins count
+                    // (the group test is spelled as four lane masks OR-ed on the scalar unit: written as a per-lane `any`, the compiler
+                    // packs the four compare results into a bit field first -- 12 extra vector instructions per group)
                     float sg[4];
-                    bool any = false;
+                    uint64_t live = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { sg[e] = h1[4 * q + e] + b2[e]; any = any || sg[e] > 1.f; }
-                    if (__builtin_amdgcn_ballot_w64(any) != 0) {
+                    for (int e = 0; e < 4; ++e) { sg[e] = h1[4 * q + e] + b2[e]; live |= __builtin_amdgcn_ballot_w64(sg[e] > 1.f); }
+                    if (live != 0) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (sg[e] > 1.f) {
