@@ -502,10 +502,13 @@ __device__ inline void stage_store(float *chunk, const float (&pre)[STAGE_REGS],
 }
 
 // empirical covariance of the member patches on the matrix core (see the call site)
-__device__ __attribute__((noinline)) void covariance27(float *A, float *Cm, float *chunk, const float *mean, const float *__restrict__ colors,
-                                                       const uint16_t *mem, int p, int b, int n, int W, int lane)
+// (the matrix leaves the accumulator registers for the per-pixel records: C in the LD layout, and C - N -- the matrix whose
+// negative eigenvalues are clamped, Step 1 (:421-436) -- in the eigensolver's 28 x 28 layout, padding row / column zero)
+__device__ __attribute__((noinline)) void covariance27(float *__restrict__ recA, float *__restrict__ recC, float *chunk, const float *mean,
+                                                       const float *noise, const float *__restrict__ colors, const uint16_t *mem, int p, int b, int n,
+                                                       int W, int lane)
 {
-    LDS_POINTER(A); LDS_POINTER(Cm); LDS_POINTER(chunk); LDS_POINTER(mean); LDS_POINTER(mem);
+    LDS_POINTER(chunk); LDS_POINTER(mean); LDS_POINTER(noise); LDS_POINTER(mem);
     {
         const int mi = lane & 31, mk = lane >> 5;
         const float my_mean = mi < K ? mean[mi] : 0.f;
@@ -527,16 +530,19 @@ __device__ __attribute__((noinline)) void covariance27(float *A, float *Cm, floa
         }
         const float inv = 1.f / (float)(n - 1);
         // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        const int mo = mi / 3, mj = mi - 3 * mo;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = (e & 3) + 8 * (e >> 2) + 4 * mk;
-            if (r < K && mi < K) {
-                const float v = acc[e] * inv;
-                A[r * LD + mi] = v;
-                Cm[r * LD + mi] = v;
+            const float v = acc[e] * inv; // rows / columns 27..31 of the product are exactly zero (zero operands)
+            if (r < K && mi < LD) recC[r * LD + mi] = v;
+            if (r < KP && mi < KP) {
+                const int ro = r / 3, ri = r - 3 * ro;
+                // the block-diagonal noise covariance: 3 x 3 block of pixel ro (symmetric storage xx,yy,zz,yz,xz,xy)
+                const float nv = (ro == mo && r < K && mi < K) ? noise[ro * 6 + noise_idx(ri, mj)] : 0.f;
+                recA[r * JLD + mi] = v - nv;
             }
         }
-        __syncthreads();
     }
 
 }
@@ -624,9 +630,10 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
-    // PHASE 1 needs two matrix buffers only (C, and the member chunk / Jacobi-layout matrix): 20 wavefronts per CU instead of 12,
-    // which is what its member gathers want (58 % of its wave cycles wait for memory)
-    float *Cm = lds, *A = PHASE == 1 ? Cm : Cm + MSZ, *V = A + MSZ, *Bm = PHASE == 1 ? Cm + MSZ : V + MSZ; // A, V contiguous: reused as the aggregation window
+    // PHASE 1 needs one matrix buffer only (the member chunk; its matrices go from the accumulator registers to the records) and
+    // runs 20 wavefronts per CU instead of 12, which is what its member gathers want (half of its wave cycles wait for memory;
+    // 28 per CU were measured: no faster, and 4 KB instead of 7 KB per wavefront leave LDS to the kernels running beside it)
+    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = PHASE == 1 ? lds : V + MSZ; // A, V contiguous: reused as the aggregation window
     float *chunk = Bm;                         // member-staging chunk: Bm is free while the clouds are streamed (mean/covariance, output)
     float *cs = Bm + MSZ;                      // 2 x 28 floats (scratch of the spectral inverse), read as float4: offsets are multiples of 16 bytes
     float *noise = cs + 2 * KP;
@@ -677,13 +684,7 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: a chain of fma in member order, i.e. the reference's sequential sum with the
     // product fused; A and B operands are the same centred value, so the result is bitwise symmetric).
     // Operand layout: lane l holds element i = l & 31 of member 2s + (l >> 5); rows/columns 27..31 are zero.
-    covariance27(A, Cm, chunk, mean, colors, mem, p, g.b, n, W, lane); // (A is Cm here)
-    for (int e = lane; e < MSZ / 4; e += 64) reinterpret_cast<float4 *>(recC)[e] = reinterpret_cast<const float4 *>(Cm)[e];
-    __syncthreads();
-    // ---- Step 1 (:421-436), first half: the matrix whose negative eigenvalues are clamped, C - N
-    add_noise27(Cm, noise, lane, -1.f);
-    to_jacobi_layout(Bm, Cm, lane);
-    for (int e = lane; e < MSZ / 4; e += 64) reinterpret_cast<float4 *>(recA)[e] = reinterpret_cast<const float4 *>(Bm)[e];
+    covariance27(recA, recC, chunk, mean, noise, colors, mem, p, g.b, n, W, lane);
     if (lane < P * 6) recX[lane] = noise[lane];
     if (lane < K) recX[P * 6 + lane] = mean[lane];
     __syncthreads(); // the next item reuses the LDS
@@ -778,7 +779,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     rec.C = rec.V + (size_t)nb_items * MSZ;
     rec.aux = rec.C + (size_t)nb_items * MSZ;
     rec.eig = rec.aux + (size_t)nb_items * AUX27;
-    const size_t lds2 = bcd_bayes27_lds_bytes(b), lds1 = lds2 - 2 * MSZ * sizeof(float);
+    const size_t lds2 = bcd_bayes27_lds_bytes(b), lds1 = lds2 - 3 * MSZ * sizeof(float);
     const int per_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / lds1), per_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / lds2);
     hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
                        d_work, g, min_eig, rec, sum, cnt);

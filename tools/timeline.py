@@ -6,7 +6,7 @@ tabs = [r[0] for r in db.execute("select name from sqlite_master where type='tab
 kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]; ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 cols = [r[1] for r in db.execute("pragma table_info(%s)" % kd)]
 st, en = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
-qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)  # HIP stream when recorded, else the hardware queue
 sel = "s.kernel_name, d.%s, d.%s, %s" % (st, en, ("d." + qcol) if qcol else "0")
 rows = list(db.execute("select %s from %s d join %s s on d.kernel_id = s.id order by d.%s" % (sel, kd, ks, st)))
 t_end = max(r[2] for r in rows); t0 = t_end - span_ms * 1e6
