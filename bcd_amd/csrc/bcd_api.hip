@@ -254,8 +254,9 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         int e = 0;
         if (wk.h_counters[41] == 0 && n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
     }
-    // the approximate path needs tau (1 +- delta) to be ordinary numbers well above the underflow threshold of a term
-    const bool fast = exact_mode != 1 && ctx->fast_similarity && w == 1 && bcd_pairdist_cs_supported(D) && tau >= 1e-18f && tau <= 1e18f;
+    // the approximate path keeps its T plane in binary16: thresholds it cannot decide safely take the exact kernels (bcd_common.h)
+    const bool fast = exact_mode != 1 && ctx->fast_similarity && w == 1 && bcd_pairdist_cs_supported(D) && tau >= BCD_APPROX_TAU_MIN &&
+                      tau <= BCD_APPROX_TAU_MAX;
     if (fast) {
         const int capacity = (int)std::min<size_t>(std::max<size_t>(npix, 1u << 16), 1u << 28);
         RCCHK(ensure(ctx, wk.border, (size_t)capacity * sizeof(uint2)));

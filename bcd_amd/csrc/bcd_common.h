@@ -37,9 +37,15 @@ __host__ __device__ inline int bcd_delta_index(int dl, int dc, int b)
 __host__ __device__ inline int bcd_delta_count(int b) { return (b + 1) + b * (2 * b + 1); }
 
 // ---- fast similarity path (k_similarity_fast.hip): approximate distance planes, exact decision at the threshold ----
-// relative half-width of the band around tau inside which a pair is re-evaluated exactly; the worst-case deviation of the
-// approximate patch distance from the reference's fp32 value is ~1e-5 (derivation in k_similarity_fast.hip)
-#define BCD_APPROX_DELTA 6.103515625e-05f /* 2^-14 */
+// The approximate T plane is stored in binary16 (3 instead of 5 bytes per plane entry with the count byte): every entry then carries a
+// relative error <= 2^-11 on top of the ~1e-5 of the approximate arithmetic (derivation in k_similarity_fast.hip), all entries are
+// >= 0, so the patch distance is within 5.0e-4 of the reference's; pairs inside tau (1 +- 2^-10) are re-evaluated exactly.
+// Thresholds outside [BCD_APPROX_TAU_MIN, BCD_APPROX_TAU_MAX] take the exact kernels: below, binary16 subnormals (absolute error
+// 2^-25 per entry) would matter; above, an entry that overflowed to +inf could belong to a similar pair.
+#define BCD_APPROX_DELTA 9.765625e-04f /* 2^-10 */
+#define BCD_APPROX_TAU_MIN 0.015625f
+#define BCD_APPROX_TAU_MAX 64.f
+typedef unsigned short bcd_half_bits; // storage type of the approximate T plane (binary16)
 struct BcdBorderline {
     float tau_hi;      // tau (1 + delta); the kernels get tau (1 - delta) as their threshold
     uint2 *list;       // (pixel index, displacement index) of the pairs with tau_lo < d' <= tau_hi

@@ -12,6 +12,7 @@
 // This file is compiled with -ffp-contract=off: the reference is built without FMA contraction and the
 // membership test d <= tau is discrete.
 #include "bcd_common.h"
+#include <hip/hip_fp16.h>
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -320,8 +321,14 @@ __device__ inline void borderline_append(const BcdBorderline &bl, uint32_t pix, 
     if (slot < bl.capacity) bl.list[slot] = make_uint2(pix, didx);
 }
 
+// plane element type: the approximate planes hold T in binary16 (bcd_common.h), the exact ones in fp32
+template <bool APPROX> struct PlaneT { typedef float type; };
+template <> struct PlaneT<true> { typedef __half type; };
+__device__ inline float plane_value(float v) { return v; }
+__device__ inline float plane_value(__half v) { return __half2float(v); }
+
 template <bool APPROX>
-__global__ __launch_bounds__(64) void k_fwd_masks_w1(const float *__restrict__ T, const uint8_t *__restrict__ Cn,
+__global__ __launch_bounds__(64) void k_fwd_masks_w1(const typename PlaneT<APPROX>::type *__restrict__ T, const uint8_t *__restrict__ Cn,
                                                      int W, int H, int b, float tau, int fwords, int nd,
                                                      uint32_t *__restrict__ fwd, BcdBorderline bl)
 {
@@ -344,12 +351,12 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const float *__restrict__ T
     for (int didx = 32 * wi; didx < d_end; ++didx) {
         int dl = 0, dc = didx;
         if (didx > b) { int e = didx - (b + 1); dl = 1 + e / side; dc = e - (dl - 1) * side - b; }
-        const float *Tp = T + (size_t)didx * plane;
+        const typename PlaneT<APPROX>::type *Tp = T + (size_t)didx * plane;
         const uint8_t *Cp = Cn + (size_t)didx * plane;
         float tc[FWD_RB + 2], tl[FWD_RB + 2], tr[FWD_RB + 2];
         int nh[FWD_RB + 2];
 #pragma unroll
-        for (int i = 0; i < FWD_RB + 2; ++i) { tc[i] = Tp[off[i]]; nh[i] = Cp[off[i]]; }
+        for (int i = 0; i < FWD_RB + 2; ++i) { tc[i] = plane_value(Tp[off[i]]); nh[i] = Cp[off[i]]; }
 #pragma unroll
         for (int i = 0; i < FWD_RB + 2; ++i) {
             tl[i] = lane_up(tc[i]); tr[i] = lane_down(tc[i]);
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const float *__restrict__ T
 // kernel streams 391 MB of planes at 720p and the narrow version reached half of what a plain streaming kernel does.  A
 // wavefront covers 256 columns, of which the 248 of lanes 1..62 are produced (the outer lanes only supply the halo).
 template <bool APPROX>
-__global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const float *__restrict__ T, const uint8_t *__restrict__ Cn,
+__global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APPROX>::type *__restrict__ T, const uint8_t *__restrict__ Cn,
                                                        int W, int H, int b, float tau, int fwords, int nd,
                                                        uint32_t *__restrict__ fwd, BcdBorderline bl)
 {
@@ -404,13 +411,20 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const float *__restrict__
     for (int didx = 32 * wi; didx < d_end; ++didx) {
         int dl = 0, dc = didx;
         if (didx > b) { int e = didx - (b + 1); dl = 1 + e / side; dc = e - (dl - 1) * side - b; }
-        const float *Tp = T + (size_t)didx * plane;
+        const typename PlaneT<APPROX>::type *Tp = T + (size_t)didx * plane;
         const uint8_t *Cp = Cn + (size_t)didx * plane;
         float t[FWD_RB + 2][6]; // left neighbour, the lane's four columns, right neighbour
         int nh[FWD_RB + 2][4];  // horizontal 3-sums of the counts
 #pragma unroll
         for (int i = 0; i < FWD_RB + 2; ++i) {
-            const float4 v = *reinterpret_cast<const float4 *>(Tp + off[i]);
+            float4 v;
+            if (APPROX) { // four binary16 values: one 8-byte load
+                const uint2 hv = *reinterpret_cast<const uint2 *>(Tp + off[i]);
+                const __half2 h01 = *reinterpret_cast<const __half2 *>(&hv.x), h23 = *reinterpret_cast<const __half2 *>(&hv.y);
+                const float2 f01 = __half22float2(h01), f23 = __half22float2(h23);
+                v = make_float4(f01.x, f01.y, f23.x, f23.y);
+            } else
+                v = *reinterpret_cast<const float4 *>(Tp + off[i]);
             const uint32_t cw = *reinterpret_cast<const uint32_t *>(Cp + off[i]);
             t[i][1] = v.x; t[i][2] = v.y; t[i][3] = v.z; t[i][4] = v.w;
             const int n0 = cw & 255, n1 = (cw >> 8) & 255, n2 = (cw >> 16) & 255, n3 = cw >> 24;
@@ -674,7 +688,7 @@ hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H,
 
 hipError_t bcd_launch_verify_pairs(const float *, const float *, int, int, int, int, float, const void *, const int *, int, uint32_t *, hipStream_t);
 
-// ap != nullptr: T / Cn are the approximate planes of k_pairdist_cs; pairs within tau (1 +- BCD_APPROX_DELTA) are listed and
+// ap != nullptr: T / Cn are the approximate planes of k_pairdist_rw (T in binary16, passed as an untyped buffer); pairs within tau (1 +- BCD_APPROX_DELTA) are listed and
 // re-evaluated exactly from (hist, ns) before the symmetric masks are completed (w = 1 only)
 hipError_t bcd_launch_masks(const float *T, const uint8_t *Cn, int W, int H, int w, int b, float tau,
                             uint32_t *mask, int32_t *count, uint32_t *fwd_scratch, hipStream_t st,
@@ -691,11 +705,11 @@ hipError_t bcd_launch_masks(const float *T, const uint8_t *Cn, int W, int H, int
         const bool wide = W % 4 == 0 && (int64_t)W * H >= 400000;
         const dim3 gw((W + 247) / 248, (H + FWD_RB - 1) / FWD_RB, fwords), gn((W + 61) / 62, (H + FWD_RB - 1) / FWD_RB, fwords);
         if (wide && ap)
-            hipLaunchKernelGGL(k_fwd_masks_w1v4<true>, gw, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
+            hipLaunchKernelGGL(k_fwd_masks_w1v4<true>, gw, dim3(64), 0, st, reinterpret_cast<const __half *>(T), Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
         else if (wide)
             hipLaunchKernelGGL(k_fwd_masks_w1v4<false>, gw, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
         else if (ap)
-            hipLaunchKernelGGL(k_fwd_masks_w1<true>, gn, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
+            hipLaunchKernelGGL(k_fwd_masks_w1<true>, gn, dim3(64), 0, st, reinterpret_cast<const __half *>(T), Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
         else
             hipLaunchKernelGGL(k_fwd_masks_w1<false>, gn, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
         if (ap) {

@@ -3,7 +3,7 @@
 //
 // The planes T_delta(x), C_delta(x) of k_similarity.hip are consumed by exactly one test, d(p, p+delta) <= tau
 // (src/core/DenoisingUnit.cpp:209).  Here T is evaluated with one v_rcp_f32 + fma per bin (error bound below) and in any
-// summation order; C (integer bin counts, the `b1 + b2 <= 1` skip test of DenoisingUnit.cpp:379) stays exact.  The mask
+// summation order, and stored in binary16; C (integer bin counts, the `b1 + b2 <= 1` skip test of DenoisingUnit.cpp:379) stays exact.  The mask
 // kernel then decides every pair whose approximate distance lies outside tau (1 +- BCD_APPROX_DELTA) and appends the few
 // borderline pairs to a list; k_verify_pairs re-evaluates those with the reference's exact operation sequence
 // (sequential bins, IEEE division) and sets their bits.  The masks are therefore bit-identical to the exact path.
@@ -17,8 +17,12 @@
 // reference's patch distance goes through <= (D - 1) + 8 additions and one division: d_ref = d* (1 + a), |a| <= (D + 9) u;
 // here through <= D + 8 fma / additions and one division: d' = d* (1 + a'), |a'| <= (D + 11) u.  Hence
 //     |d' / d_ref - 1| <= (2 D + 20) u + O(u^2)  =  8.3e-6 for D = 60
-// in the worst case (every round-off pointing the same way); BCD_APPROX_DELTA = 2^-14 = 6.1e-5 is 7 times that.  Measured
-// maximum over whole frames: ~4.4e-7 (bcd_hip_selftest_approx_distance; the GPU tests assert < delta / 8).
+// in the worst case (every round-off pointing the same way).  The plane itself is then stored in binary16 (round to nearest: one
+// more factor 1 +- 2^-11 per entry, and entries are >= 0, so the same bound carries to their sums): together |d' / d_ref - 1| <
+// 5.0e-4, and BCD_APPROX_DELTA = 2^-10 = 9.8e-4 is twice that.  The plane costs 3 bytes per entry instead of 5 (count byte
+// included) and the mask kernel, which streams it, is memory bound.  Thresholds outside [2^-6, 64] go to the exact kernels
+// (binary16 subnormals below, overflow to +inf above: bcd_common.h).  Measured maximum over whole frames: 2.4e-4
+// (bcd_hip_selftest_approx_distance; the GPU tests assert < delta / 2), a few thousand re-evaluated pairs per 1080p scale.
 //
 // Cost model that shaped the kernel (measured on MI355X): a SIMD issues about one instruction of ANY kind per 2-3 cycles
 // -- VALU, scalar, branch and LDS instructions all compete for it -- so the aim is the smallest instruction count per
@@ -28,6 +32,7 @@
 //     ~7.5 instructions per bin on average (flat, select-based code: 9-10; the exact kernel: ~20);
 //   * 128 VGPRs -> 4 wavefronts per SIMD (the exact kernel: 2), neighbour histograms read two float4 ahead of their use.
 #include "bcd_common.h"
+#include <hip/hip_fp16.h>
 #include <atomic>
 #include <cstdlib>
 
@@ -64,7 +69,7 @@ template <int D> struct RwLayout {
 
 template <int D, bool UNI>
 __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H,
-                                                              int b, float *__restrict__ T, uint8_t *__restrict__ Cn, int *range_flag,
+                                                              int b, __half *__restrict__ T, uint8_t *__restrict__ Cn, int *range_flag,
                                                               float uni_n)
 {
     using L = RwLayout<D>;
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                 const int nc_ = c + dc;
                 if (inside && nc_ >= 0 && nc_ < W && nr < H) {
                     const size_t o = (size_t)bcd_delta_index(dl, dc, b) * plane + pix;
-                    T[o] = sum;
+                    T[o] = __float2half_rn(sum); // binary16 plane (a sum beyond 65504 becomes +inf: far above any admitted tau)
                     Cn[o] = (uint8_t)cnt;
                 }
             }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(64) void k_verify_pairs(const float *__restrict__ h
 
 // self-test: largest relative deviation between the patch distances from two sets of planes (approximate vs exact), over all
 // pairs of main pixels; bits of (max rel, as uint) via atomicMax -- valid because the values are non-negative floats
-__global__ __launch_bounds__(256) void k_max_rel_dev(const float *__restrict__ Ta, const float *__restrict__ Tb, const uint8_t *__restrict__ Ca,
+__global__ __launch_bounds__(256) void k_max_rel_dev(const __half *__restrict__ Ta, const float *__restrict__ Tb, const uint8_t *__restrict__ Ca,
                                                      const uint8_t *__restrict__ Cb, int W, int H, int b, unsigned int *__restrict__ out /* [0] max rel bits, [1] count mismatches */)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6), didx = blockIdx.z;
@@ -295,10 +300,11 @@ __global__ __launch_bounds__(256) void k_max_rel_dev(const float *__restrict__ T
     for (int ol = -1; ol <= 1; ++ol)
         for (int oc = -1; oc <= 1; ++oc) {
             const size_t i = base + (size_t)(r + ol) * W + (c + oc);
-            sa += Ta[i]; sb += Tb[i]; na += Ca[i]; nb += Cb[i];
+            sa += __half2float(Ta[i]); sb += Tb[i]; na += Ca[i]; nb += Cb[i];
         }
     if (na != nb) { atomicAdd(out + 1, 1u); return; }
     if (nb == 0) return;
+    if (isinf(sa) && sb > 65504.f) return; // a binary16 entry overflowed: such a pair is far above any admitted threshold
     const float rel = sb > 0.f ? fabsf(sa - sb) / sb : (sa == 0.f ? 0.f : 1.f);
     atomicMax(out, __float_as_uint(rel));
 }
@@ -324,7 +330,7 @@ hipError_t bcd_launch_pairdist_cs(const float *hist, const float *ns, int W, int
             if (e != hipSuccess) return e;                                                                           \
             if (dev >= 0 && dev < 64) granted[dev].store(1);                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, T, Cn, d_range_flag, uni_n); \
+        hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, reinterpret_cast<__half *>(T), Cn, d_range_flag, uni_n); \
         return hipGetLastError();                                                                                    \
     }
 #define BCD_RW_DEPTH(DD) case DD: if (uni_n > 0.f) BCD_RW_LAUNCH(DD, true) else BCD_RW_LAUNCH(DD, false)
@@ -350,6 +356,6 @@ hipError_t bcd_launch_verify_pairs(const float *hist, const float *ns, int W, in
 hipError_t bcd_launch_max_rel_dev(const float *Ta, const float *Tb, const uint8_t *Ca, const uint8_t *Cb, int W, int H, int b, unsigned int *out,
                                   hipStream_t st)
 {
-    hipLaunchKernelGGL(k_max_rel_dev, dim3((W + 63) / 64, (H + 3) / 4, bcd_delta_count(b)), dim3(256), 0, st, Ta, Tb, Ca, Cb, W, H, b, out);
+    hipLaunchKernelGGL(k_max_rel_dev, dim3((W + 63) / 64, (H + 3) / 4, bcd_delta_count(b)), dim3(256), 0, st, reinterpret_cast<const __half *>(Ta), Tb, Ca, Cb, W, H, b, out);
     return hipGetLastError();
 }

@@ -674,7 +674,29 @@ def test_fast_similarity_path_equals_exact_kernels(hipctx, kind):
     assert np.array_equal(c1.cpu().numpy(), c0.cpu().numpy())
     rel, count_mismatches, flags = hipctx.selftest_approx_distance(d_hist, d_ns, b)
     assert count_mismatches == 0 and (flags >> 4) == 0
-    assert rel < 2.0 ** -14 / 8, rel  # measured ~3e-7; the exactly re-evaluated band is +-6.1e-5
+    # the approximate T plane is stored in binary16: worst case 5.0e-4 (2^-11 per entry + the fp32 round-off), measured ~2.4e-4;
+    # the exactly re-evaluated band is +-2^-10
+    assert rel < 2.0 ** -10 / 1.9, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tau", [2.0 ** -6, 0.01, 64.0, 100.0])
+def test_similarity_thresholds_at_and_beyond_the_range_of_the_approximate_planes(hipctx, tau):
+    """the binary16 planes of the fast path serve thresholds in [2^-6, 64] only (subnormals below, +inf above); outside, the exact
+    kernels run -- either way the masks are the exact path's masks"""
+    import bcd_amd.core as core
+    col, ns, hist, cov = core.synthetic_scene(96, 48, 16, 3, 0.05 if tau < 0.1 else 0.6, 0.02)
+    d_hist, d_ns = dev(hist, ns)
+    try:
+        hipctx.set_fast_similarity(True)
+        m1, c1 = hipctx.similarity_masks(d_hist, d_ns, 1, 6, tau)
+        hipctx.set_fast_similarity(False)
+        m0, c0 = hipctx.similarity_masks(d_hist, d_ns, 1, 6, tau)
+    finally:
+        hipctx.set_fast_similarity(True)
+    assert np.array_equal(m1.cpu().numpy(), m0.cpu().numpy())
+    assert np.array_equal(c1.cpu().numpy(), c0.cpu().numpy())
+    assert 0 < int(c1.sum()) < c1.numel() * 169   # a threshold that actually separates pairs on this frame
 
 
 @pytest.mark.gpu
