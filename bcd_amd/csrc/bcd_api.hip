@@ -26,8 +26,8 @@ hipError_t bcd_launch_compare_planes(const float *, const uint8_t *, const float
 hipError_t bcd_launch_selftest_div(uint32_t, int, int, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t,
                             const BcdBorderline *, const float *, const float *, int);
-int bcd_pairdist_cs_supported(int D);
-hipError_t bcd_launch_pairdist_cs(const float *, const float *, int, int, int, int, float *, uint8_t *, int *, float, hipStream_t);
+int bcd_pairdist_rw_supported(int D);
+hipError_t bcd_launch_pairdist_rw(const float *, const float *, int, int, int, int, void * /* binary16 T planes */, uint8_t *, int *, float, hipStream_t);
 hipError_t bcd_launch_max_rel_dev(const float *, const float *, const uint8_t *, const uint8_t *, int, int, int, unsigned int *, hipStream_t);
 hipError_t bcd_launch_window_distances(const float *, const uint8_t *, int, int, int, int, int, int, float *, hipStream_t);
 hipError_t bcd_launch_pixel_cov(const float *, const float *, int64_t, float *, hipStream_t);
@@ -213,7 +213,7 @@ bool similarity_needs_redo(const Work &wk)
 // exact_mode: 0 = production kernels, flags checked here (one stream synchronisation); 1 = exact kernels with the compiler's division;
 // 2 = production kernels, flags copied to wk.h_counters[40] / [43] but NOT checked: the caller validates after its own
 // synchronisation with similarity_needs_redo().
-// Production kernels: w = 1 and a supported depth -> approximate planes (k_pairdist_cs) + exact verification of the borderline
+// Production kernels: w = 1 and a supported depth -> approximate planes (k_pairdist_rw) + exact verification of the borderline
 // pairs; otherwise the exact planes with the scale-free division (k_pairdist<FAST>).
 int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
                uint32_t *d_mask, int32_t *d_count, int exact_mode = 0)
@@ -255,14 +255,14 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         if (wk.h_counters[41] == 0 && n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
     }
     // the approximate path keeps its T plane in binary16: thresholds it cannot decide safely take the exact kernels (bcd_common.h)
-    const bool fast = exact_mode != 1 && ctx->fast_similarity && w == 1 && bcd_pairdist_cs_supported(D) && tau >= BCD_APPROX_TAU_MIN &&
+    const bool fast = exact_mode != 1 && ctx->fast_similarity && w == 1 && bcd_pairdist_rw_supported(D) && tau >= BCD_APPROX_TAU_MIN &&
                       tau <= BCD_APPROX_TAU_MAX;
     if (fast) {
         const int capacity = (int)std::min<size_t>(std::max<size_t>(npix, 1u << 16), 1u << 28);
         RCCHK(ensure(ctx, wk.border, (size_t)capacity * sizeof(uint2)));
         wk.border_capacity = capacity;
         if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
-        HIPCHK(ctx, bcd_launch_pairdist_cs(d_hist, d_ns, W, H, D, b, (float *)wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream));
+        HIPCHK(ctx, bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream));
         if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         BcdBorderline bl = { 0.f, (uint2 *)wk.border.p, d_flag + 3, capacity };
@@ -1119,7 +1119,7 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
 {
     if (!ctx || !d_hist || !d_ns || !max_rel_dev || !count_mismatches || W <= 0 || H <= 0 || search_radius < 1) return bad(ctx, "bad argument");
     DEVICE_GUARD(ctx);
-    if (!bcd_pairdist_cs_supported(D)) { set_err(ctx, "no approximate kernel for this histogram depth"); return BCD_HIP_EUNSUPPORTED; }
+    if (!bcd_pairdist_rw_supported(D)) { set_err(ctx, "no approximate kernel for this histogram depth"); return BCD_HIP_EUNSUPPORTED; }
     Work &wk = ctx->main;
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
@@ -1148,7 +1148,7 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
             rc = BCD_HIP_EDEVICE; break;
         }
         // approximate planes (production variant) against the exact planes (compiler's division, general formula)
-        if (bcd_launch_pairdist_cs(d_hist, d_ns, W, H, D, search_radius, (float *)wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream) != hipSuccess ||
+        if (bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream) != hipSuccess ||
             bcd_launch_pairdist(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, d_flag, 0.f, wk.stream) != hipSuccess ||
             bcd_launch_max_rel_dev((const float *)wk.T.p, T2, (const uint8_t *)wk.Cn.p, C2, W, H, search_radius, d_res, wk.stream) != hipSuccess) {
             rc = BCD_HIP_EDEVICE; break;

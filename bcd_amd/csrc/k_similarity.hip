@@ -313,7 +313,7 @@ __device__ inline int lane_down(int v)     { return __shfl_down(v, 1); }
 // planes are loaded once and shared by the lines of the strip (1.5 loads per output instead of 3); the nine T values are
 // summed in the reference's order (patch line by line, left to right), the counts are integers.
 constexpr int FWD_RB = 4;
-// APPROX: the planes come from k_pairdist_cs (k_similarity_fast.hip); tau is then tau (1 - delta), pairs up to bl.tau_hi are
+// APPROX: the planes come from k_pairdist_rw (k_similarity_fast.hip); tau is then tau (1 - delta), pairs up to bl.tau_hi are
 // appended to the borderline list (their bit is decided by k_verify_pairs)
 __device__ inline void borderline_append(const BcdBorderline &bl, uint32_t pix, uint32_t didx)
 {

@@ -39,14 +39,14 @@
 
 namespace {
 
-constexpr int CS_TW = 64, CS_TH = 4;   // tile
-constexpr int CS_CW = 12;              // widest span of column displacements served by one staged window
-constexpr int CS_NCOLS = CS_TW + CS_CW;
-constexpr int CS_ND = CS_CW + 1;       // displacements per window
+constexpr int RW_TW = 64, RW_TH = 4;   // tile
+constexpr int RW_CW = 12;              // widest span of column displacements served by one staged window
+constexpr int RW_NCOLS = RW_TW + RW_CW;
+constexpr int RW_ND = RW_CW + 1;       // displacements per window
 
-constexpr float CS_BIN_MAX = 1048576.f;   // the guarded range of k_similarity.hip (PD_BIN_MAX, PD_N_MIN, PD_N_MAX)
-constexpr float CS_N_MIN = 0.0009765625f;
-constexpr float CS_N_MAX = 65536.f;
+constexpr float RW_BIN_MAX = 1048576.f;   // the guarded range of k_similarity.hip (PD_BIN_MAX, PD_N_MIN, PD_N_MAX)
+constexpr float RW_N_MIN = 0.0009765625f;
+constexpr float RW_N_MAX = 65536.f;
 
 // ---------------------------------------------------------------------------------------------------
 // k_pairdist_rw: rolling window, displacements split between two wavefront sets.
@@ -62,9 +62,9 @@ constexpr int RW_THREADS = 512;
 
 template <int D> struct RwLayout {
     static_assert(D % 4 == 0, "whole float4 groups");
-    static constexpr int ROW = ((CS_NCOLS * D + 63) / 64) * 64; // ring line stride (dwords): a multiple of the 64 banks
-    static constexpr int LDS_DWORDS = 4 * ROW + 4 * CS_NCOLS;    // + sample counts
-    static constexpr int NPRE = (CS_NCOLS * (D / 4) + RW_THREADS - 1) / RW_THREADS; // float4 per thread of one prefetched line
+    static constexpr int ROW = ((RW_NCOLS * D + 63) / 64) * 64; // ring line stride (dwords): a multiple of the 64 banks
+    static constexpr int LDS_DWORDS = 4 * ROW + 4 * RW_NCOLS;    // + sample counts
+    static constexpr int NPRE = (RW_NCOLS * (D / 4) + RW_THREADS - 1) / RW_THREADS; // float4 per thread of one prefetched line
 };
 
 template <int D, bool UNI>
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
         const int xcd = id & 7, k = id >> 3, q = nt >> 3, rem = nt & 7;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
     }
-    const int col0 = (tile % gridDim.x) * CS_TW, row0 = (tile / gridDim.x) * CS_TH; // row0 % 4 == 0: line g of the image lives in slot g & 3
+    const int col0 = (tile % gridDim.x) * RW_TW, row0 = (tile / gridDim.x) * RW_TH; // row0 % 4 == 0: line g of the image lives in slot g & 3
     const int c = col0 + lane, r = row0 + ty;
     const bool inside = (c < W) && (r < H);
     const size_t plane = (size_t)W * H;
@@ -104,10 +104,10 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
         if (hv == 0) { // every pixel of the image is the own pixel of exactly one (line, half 0) wavefront: this covers the whole input
             bool bad = false;
 #pragma unroll
-            for (int k = 0; k < D; ++k) bad = bad || !(h1[k] >= 0.f && h1[k] <= CS_BIN_MAX);
+            for (int k = 0; k < D; ++k) bad = bad || !(h1[k] >= 0.f && h1[k] <= RW_BIN_MAX);
             if (inside) {
                 const float nv = ns[pix];
-                bad = bad || !(nv >= CS_N_MIN && nv <= CS_N_MAX);
+                bad = bad || !(nv >= RW_N_MIN && nv <= RW_N_MAX);
                 if (UNI && nv != uni_n) atomicOr(range_flag, 2);
             }
             if (bad) atomicOr(range_flag, 1);
@@ -136,11 +136,11 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
             const int i = threadIdx.x + u * RW_THREADS;
             if (i < wcols * Q) *reinterpret_cast<float4 *>(dst + 4 * i) = pre[u];
         }
-        if (!UNI && (int)threadIdx.x < wcols) ring_n[(g & 3) * CS_NCOLS + threadIdx.x] = pre_n;
+        if (!UNI && (int)threadIdx.x < wcols) ring_n[(g & 3) * RW_NCOLS + threadIdx.x] = pre_n;
     };
 
-    for (int cbeg = -b; cbeg <= b; cbeg += CS_ND) {
-        const int cend = min(b, cbeg + CS_CW), nc = cend - cbeg + 1, wcols = CS_TW + (cend - cbeg);
+    for (int cbeg = -b; cbeg <= b; cbeg += RW_ND) {
+        const int cend = min(b, cbeg + RW_CW), nc = cend - cbeg + 1, wcols = RW_TW + (cend - cbeg);
         const int dl0 = cend >= 0 ? 0 : 1; // displacement line 0 only holds dc >= 0
         float4 pre[NPRE];
         float pre_n = 1.f;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
             // the line that enters the ring for dl + 1 travels while dl is evaluated
             if (dl < b) fetch_line(pre, pre_n, row0 + dl + 4, cbeg, wcols);
             const float *nrow = ring + ((ty + dl) & 3) * L::ROW;
-            const float *nrow_n = ring_n + ((ty + dl) & 3) * CS_NCOLS;
+            const float *nrow_n = ring_n + ((ty + dl) & 3) * RW_NCOLS;
             const int nr = r + dl;
             // first displacement of this wavefront on this line (dl == 0 only holds dc >= 0)
             const int j0 = (dl == 0 && cbeg < 0) ? -cbeg : 0;
@@ -312,12 +312,12 @@ __global__ __launch_bounds__(256) void k_max_rel_dev(const __half *__restrict__ 
 } // namespace
 
 // 1 if the fast (approximate + verify) path has a kernel for this histogram depth
-int bcd_pairdist_cs_supported(int D) { return D == 60 || D == 36 || D == 24; }
+int bcd_pairdist_rw_supported(int D) { return D == 60 || D == 36 || D == 24; }
 
-hipError_t bcd_launch_pairdist_cs(const float *hist, const float *ns, int W, int H, int D, int b, float *T, uint8_t *Cn, int *d_range_flag,
+hipError_t bcd_launch_pairdist_rw(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,
                                   float uni_n, hipStream_t st)
 {
-    dim3 grid((W + CS_TW - 1) / CS_TW, (H + CS_TH - 1) / CS_TH), block(RW_THREADS);
+    dim3 grid((W + RW_TW - 1) / RW_TW, (H + RW_TH - 1) / RW_TH), block(RW_THREADS);
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
 #define BCD_RW_LAUNCH(DD, UU)                                                                                        \
@@ -330,7 +330,7 @@ hipError_t bcd_launch_pairdist_cs(const float *hist, const float *ns, int W, int
             if (e != hipSuccess) return e;                                                                           \
             if (dev >= 0 && dev < 64) granted[dev].store(1);                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, reinterpret_cast<__half *>(T), Cn, d_range_flag, uni_n); \
+        hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, static_cast<__half *>(T), Cn, d_range_flag, uni_n); \
         return hipGetLastError();                                                                                    \
     }
 #define BCD_RW_DEPTH(DD) case DD: if (uni_n > 0.f) BCD_RW_LAUNCH(DD, true) else BCD_RW_LAUNCH(DD, false)

@@ -244,7 +244,7 @@ int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, 
 int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius,
                                       int *variant, int64_t *mismatches);
 
-/* self-test of the approximate pair-distance kernel (k_pairdist_cs) on given inputs: *max_rel_dev = largest relative deviation of a
+/* self-test of the approximate pair-distance kernel (k_pairdist_rw) on given inputs: *max_rel_dev = largest relative deviation of a
  * patch distance d(p, p + delta) computed from the approximate planes from the one computed from the exact planes, over all pairs of
  * main pixels (must stay far below 2^-14, the half-width of the band that is re-evaluated exactly); *count_mismatches = pairs whose
  * integer bin counts differ (must be 0); *flags as *variant above */
