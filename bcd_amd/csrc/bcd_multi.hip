@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -466,7 +467,18 @@ bool rank_download(const Job &job, int rank, bool local_band)
     return true;
 }
 
-bool rank_worker(const Job &job, int rank) { return rank_upload(job, rank, false) && rank_compute(job, rank) && rank_download(job, rank, false); }
+bool rank_worker(const Job &job, int rank)
+{
+    bcd_hip_multi *m = job.m;
+    if (!rank_upload(job, rank, false)) return false;
+    // every rank has its inputs resident: what follows is what a resident-data caller would time (stats.compute_ms, rank 0's clock)
+    if (!m->barrier[job.S].wait()) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!rank_compute(job, rank)) return false;
+    if (!m->barrier[job.S].wait()) return false;
+    if (rank == 0) m->stats.compute_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rank_download(job, rank, false);
+}
 
 // contexts / streams of the local ranks and the communicators of channels 0..S, created on first use
 int prepare(bcd_hip_multi *m, int S)

@@ -342,7 +342,7 @@ class Context:
 
 
 class MultiStats(C.Structure):
-    _fields_ = [("n_ranks", C.c_int32), ("transport", C.c_int32), ("frames", C.c_int64), ("marking_rounds", C.c_int32 * 8)]
+    _fields_ = [("n_ranks", C.c_int32), ("transport", C.c_int32), ("frames", C.c_int64), ("marking_rounds", C.c_int32 * 8), ("compute_ms", C.c_float)]
 
 
 class MultiDenoiser:

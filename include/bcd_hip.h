@@ -138,6 +138,7 @@ typedef struct bcd_hip_multi_stats {
     int32_t transport;          /* 1 = RCCL, 0 = in-process copies (ranks share a device) */
     int64_t frames;
     int32_t marking_rounds[8];  /* exchange + marking batches per scale of the last frame */
+    float   compute_ms;         /* bcd_hip_multi_denoise_host: last frame between "every rank has its inputs" and "every rank has its band" */
 } bcd_hip_multi_stats;
 int  bcd_hip_multi_create(bcd_hip_multi **m, const int *devices, int n_ranks);
 void bcd_hip_multi_destroy(bcd_hip_multi *m);
