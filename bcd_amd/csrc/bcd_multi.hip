@@ -179,6 +179,7 @@ struct bcd_hip_multi {
     enum { IN_COL, IN_NS, IN_HIST, IN_COV, OUT, PIXCOV, MASK, NSIM, STATE, SUM, CNT, RX_UP_S, RX_UP_C, RX_DN_S, RX_DN_C, NBUF };
     DBuf buf[MAX_RANKS][MAX_S][NBUF];
     long long *d_red[MAX_RANKS][MAX_S + 1]; // all-reduce scratch (RCCL transport)
+    hipEvent_t ev_level[MAX_RANKS][MAX_S]; // pyramid level s of the rank is complete (recorded on the rank's tail stream)
     bcd_hip_multi_stats stats;
     // one-process-per-GPU use (bcd_hip_multi_create_rank): only `local_rank` lives in this process; its communicators are built
     // with ncclCommInitRank from the ids all processes share
@@ -312,6 +313,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
 
     // whatever way this scale ends, the finer scales must not wait for it any longer
     struct GateRelease { CommGate &gate; int s; ~GateRelease() { gate.finish(s); } } release{ m->gate[rank], s };
+    if (s > 0) MCHK(m, rank, hipStreamWaitEvent(st, m->ev_level[rank][s], 0));
     // the finest scale is the critical path of the band: the coarse scales' persistent estimate kernels keep to a quarter of the CU slots
     ECHK(m, rank, c, bcd_hip_set_cu_share(c, s == 0 || g.S == 1 ? 100 : 25));
     ECHK(m, rank, c, bcd_hip_pixel_cov(c, cov, ns, W, rows, pixcov));
@@ -412,8 +414,8 @@ bool rank_compute(const Job &job, int rank)
         ECHK(m, rank, cm, bcd_hip_downscale_sum(cm, pn, prev.W, rows, 1, (float *)B(s, bcd_hip_multi::IN_NS).p));
         ECHK(m, rank, cm, bcd_hip_downscale_sum(cm, ph, prev.W, rows, D, (float *)B(s, bcd_hip_multi::IN_HIST).p));
         ECHK(m, rank, cm, bcd_hip_downscale_cov(cm, pv, pn, prev.W, rows, (float *)B(s, bcd_hip_multi::IN_COV).p));
+        MCHK(m, rank, hipEventRecord(m->ev_level[rank][s], sm)); // scale s starts when its level is there; the finest scale at once
     }
-    MCHK(m, rank, hipStreamSynchronize(sm));
     // ---- the scales are independent until the merges: one thread, stream and context each
     {
         std::vector<std::thread> th;
@@ -487,6 +489,7 @@ int prepare(bcd_hip_multi *m, int S)
         if (m->local_rank >= 0 && r != m->local_rank) continue;
         if (hipSetDevice(m->devices[r]) != hipSuccess) { fail(m, "hipSetDevice failed"); return BCD_HIP_EDEVICE; }
         for (int c = 0; c <= S; ++c) {
+            if (c < S && !m->ev_level[r][c] && hipEventCreateWithFlags(&m->ev_level[r][c], hipEventDisableTiming) != hipSuccess) { fail(m, "hipEventCreate failed"); return BCD_HIP_EDEVICE; }
             if (m->ctx[r][c]) continue;
             if (hipStreamCreateWithFlags(&m->stream[r][c], hipStreamNonBlocking) != hipSuccess ||
                 bcd_hip_ctx_create(&m->ctx[r][c], m->devices[r], m->stream[r][c]) != BCD_HIP_OK) { fail(m, "cannot create an engine context"); return BCD_HIP_EDEVICE; }
@@ -550,6 +553,7 @@ int bcd_hip_multi_create(bcd_hip_multi **out, const int *devices, int n_ranks)
     memset(m->ctx, 0, sizeof(m->ctx));
     memset(m->stream, 0, sizeof(m->stream));
     memset(m->d_red, 0, sizeof(m->d_red));
+    memset(m->ev_level, 0, sizeof(m->ev_level));
     memset(m->comm_ready, 0, sizeof(m->comm_ready));
     memset(&m->stats, 0, sizeof(m->stats));
     for (int c = 0; c <= MAX_S; ++c) { m->barrier[c].parties = n_ranks; m->barrier[c].abort_flag = &m->abort_flag; }
@@ -577,6 +581,7 @@ void bcd_hip_multi_destroy(bcd_hip_multi *m)
             if (m->d_red[r][c]) (void)hipFree(m->d_red[r][c]);
             if (m->ctx[r][c]) bcd_hip_ctx_destroy(m->ctx[r][c]);
             if (m->stream[r][c]) (void)hipStreamDestroy(m->stream[r][c]);
+            if (c < MAX_S && m->ev_level[r][c]) (void)hipEventDestroy(m->ev_level[r][c]);
         }
     }
     delete m;
