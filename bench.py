@@ -5,8 +5,9 @@ A "step" is one full denoise of one synthetic 1920x1080 frame (BASELINE.json con
 seeded random order): the pyramid build, and per scale the pair-distance / mask kernels, the marking fixed point, the
 Bayesian patch kernel, finalisation and merge.  Inputs are resident in HBM before the timed region.
 After the timed region (N = 1, untimed, skipped by --no-extras): the pair-distance kernel with the scales serialised
-(`roofline.isolated_*`), the low-noise variant of the frame (`low_noise`), the same frame with -m 0 (`m0`), and the CPU
-oracle on all host cores and on one core (`cpu_baseline`).
+(`roofline.isolated_*`), the low-noise variant of the frame (`low_noise`), the same frame with -m 0 (`m0`), the 3840x2160
+frame of BASELINE.json configs[3] (`frame_4k`; at N > 1 the same frame over the same row bands, measured before the timed
+region: the per-N points of the 4K strong-scaling curve), and the CPU oracle on all host cores and on one core (`cpu_baseline`).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into horizontal bands of
 main pixels (strong scaling); every rank owns a band plus (b+w)*2^(S-1) halo lines of input, rebuilds the pyramid
 for its band, and exchanges marking states, accumulator and output halo lines with its two neighbours over RCCL
@@ -48,6 +49,7 @@ def parse():
     ap.add_argument("--random-order", type=int, default=1, help="-r of bcd_cli")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs after the timed region (isolated kernel timing, low-noise frame, -m 0)")
+    ap.add_argument("--no-4k", action="store_true", help="skip the untimed 3840x2160 leg (frame_4k in the JSON line)")
     ap.add_argument("--python-bands", action="store_true", help="N > 1: the torch.distributed orchestration of bcd_amd/tiling.py instead of the native driver (test harness)")
     ap.add_argument("--band-marking", action="store_true", help="with --python-bands: every band marks on its own (a valid order, NOT the single-GPU frame)")
     ap.add_argument("--band-path", action="store_true", help="use the multi-GPU row-band code path even with one rank (debug)")
@@ -131,6 +133,7 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = bh.Context(local_rank, stream)
 
+    extras = {}   # untimed legs reported next to the headline
     parallelism = "single"
     if world == 1 and not args.band_path:
         col, ns, hist, cov = core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes)
@@ -175,7 +178,31 @@ def main():
                 err = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
                 assert got.shape == want.shape and err < 1e-5, "band path differs from the single-GPU frame: %g" % err
                 check = {"size": "%dx%d" % (cw, ch), "rel_linf_vs_single_gpu": err}
+            # BASELINE configs[3]: the 4K frame row-banded over the same ranks (the strong-scaling target of north_star is quoted on it);
+            # same calls as the timed region below, before it
+            if not (args.no_extras or args.no_4k):
+                w4, h4 = 3840, 2160
+                load(w4, h4)
+                rd.step()   # two untimed steps: the first one at a new size grows the workspaces, the second one settles the
+                rd.step()   # size of the first marking batch
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    rd.step()
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t4 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+                if world > 1:
+                    dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+                ms4 = float(t4.item()) * 1e3 / 3
+                extras["frame_4k"] = {"value": round(w4 * h4 / 1e6 / (ms4 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms4, 4), "steps": 3,
+                                      "workload": "3840x2160 frame of the same generator and flags (BASELINE configs[3]) over the same %d row bands, inputs resident" % world}
             load(W, H)
+            rd.step()   # (workspaces and the size of the first marking batch settle in two steps at a new frame size; untimed,
+            rd.step()   # before the warm-up steps the caller asked for)
             return rd.step, "rowband%d-exactmark-native" % world, check
 
         band_check, native_error = None, None
@@ -224,7 +251,6 @@ def main():
     # the three scales run concurrently on separate streams, so a launch's event-to-event time includes the kernels it
     # overlaps with; the same kernel timed in isolation (scales one after the other, three extra untimed steps):
     iso_ms = None
-    extras = {}
     if single and not args.no_extras:
         ctx.set_concurrent_scales(False)
         step()
@@ -252,6 +278,21 @@ def main():
                                    workload="same frame generator with sigma 0.10, no spikes")
         extras["m0"] = dict(leg((col, ns, hist, cov), bh.default_params(b=b, w=w, m=0.0, random_order=args.random_order, seed=1234), 2),
                             workload="the default frame with -m 0 (no marking: every main pixel is processed)")
+        # BASELINE configs[3]'s frame on this one GPU: the N = 1 point of the 4K strong-scaling curve (north_star), untimed leg
+        if not args.no_4k:
+            w4, h4 = 3840, 2160
+            d4 = [torch.from_numpy(a).cuda() for a in core.synthetic_scene(w4, h4, args.spp, 1234, args.sigma, args.spikes)]
+            out4 = torch.empty((h4, w4, 3), dtype=torch.float32, device="cuda")
+            ctx.denoise(*d4, S, prm, out4)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                ctx.denoise(*d4, S, prm, out4)
+            torch.cuda.synchronize()
+            ms4 = (time.perf_counter() - t1) * 1e3 / 3
+            extras["frame_4k"] = {"value": round(w4 * h4 / 1e6 / (ms4 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms4, 4), "steps": 3,
+                                  "workload": "3840x2160 frame of the same generator and flags (BASELINE configs[3]), inputs resident"}
+            del d4, out4
     all_ms, all_launches = ctx.kernel_time()  # every launch of this process, warm-up and untimed legs included
     algo_bytes_per_step = ALGO_READ_BYTES_PER_PIXEL * sum(sc["w"] * sc["h"] for sc in scales)
     achieved = (algo_bytes_per_step * args.steps / (pd_ms * 1e-3)) / 1e9 if pd_ms > 0 else 0.0
