@@ -589,6 +589,25 @@ def test_720p_three_scale_frame_against_the_oracle(hipctx):
 
 
 @pytest.mark.gpu
+def test_quarter_hd_three_scale_marking_run_against_the_oracle(hipctx):
+    """the bench workload (noisy frame, 3 scales, b = 6, -m 1 -r 1) at 480 x 270 against the oracle visiting the pixels in the SAME
+    explicit order (one thread, ~15 s): marking decisions, fallback and full estimates, pyramid and merges in one comparison"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H = 480, 270
+    col, ns, hist, cov = core.synthetic_scene(W, H, 32, 1234, 0.35, 0.01)
+    prm = bh.default_params(m=1.0, random_order=1, seed=1234)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), 3, prm).cpu().numpy()
+    frac = [hipctx.stats(s).processed / max(1, hipctx.stats(s).main_pixels) for s in range(3)]
+    orders = _orders(W, H, 1, 1, 1234, 3)
+    want = ol.denoise_multiscale(col, ns, hist, cov, 3, ol.params(m=1.0), orders=orders)
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+    assert 0.05 < frac[0] < 0.8   # marking did skip pixels on the finest scale
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["uniform_pow2", "uniform_12", "mixed", "one_pixel_differs"])
 def test_sample_count_paths_of_the_distance_kernel_bitexact(hipctx, kind):
     """k_pairdist drops the sample-count products when every pixel has the same power-of-two count (exact identity); any other
