@@ -7,7 +7,7 @@ Bayesian patch kernel, finalisation and merge.  Inputs are resident in HBM befor
 After the timed region (N = 1, untimed, skipped by --no-extras): the pair-distance kernel with the scales serialised
 (`roofline.isolated_*`), the low-noise variant of the frame (`low_noise`), the same frame with -m 0 (`m0`), the 3840x2160
 frame of BASELINE.json configs[3] (`frame_4k`; at N > 1 the same frame over the same row bands, measured before the timed
-region: the per-N points of the 4K strong-scaling curve), and the CPU oracle on all host cores and on one core (`cpu_baseline`).
+region: the per-N points of the 4K strong-scaling curve) and of configs[4] (`frame_4k_b12_prefilter`, N = 1), and the CPU oracle on all host cores and on one core (`cpu_baseline`).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into horizontal bands of
 main pixels (strong scaling); every rank owns a band plus (b+w)*2^(S-1) halo lines of input, rebuilds the pyramid
 for its band, and exchanges marking states, accumulator and output halo lines with its two neighbours over RCCL
@@ -292,6 +292,18 @@ def main():
             ms4 = (time.perf_counter() - t1) * 1e3 / 3
             extras["frame_4k"] = {"value": round(w4 * h4 / 1e6 / (ms4 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms4, 4), "steps": 3,
                                   "workload": "3840x2160 frame of the same generator and flags (BASELINE configs[3]), inputs resident"}
+            # BASELINE configs[4] on this one GPU: large search window, spike prefilter (a step of its own, on the resident copies:
+            # src/cli/main.cpp:428-441), random order
+            prm12 = bh.default_params(b=12, w=w, m=args.skip_prob, random_order=1, seed=1234)
+            ctx.denoise(*ctx.spike_filter(*d4, 2.0), S, prm12, out4)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                ctx.denoise(*ctx.spike_filter(*d4, 2.0), S, prm12, out4)
+            torch.cuda.synchronize()
+            ms12 = (time.perf_counter() - t1) * 1e3 / 2
+            extras["frame_4k_b12_prefilter"] = {"value": round(w4 * h4 / 1e6 / (ms12 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms12, 4), "steps": 2,
+                                                "workload": "the 3840x2160 frame with -b 12 -p 1 --p-factor 2 -r 1 (BASELINE configs[4]); the prefilter kernel is inside the timed step"}
             del d4, out4
     all_ms, all_launches = ctx.kernel_time()  # every launch of this process, warm-up and untimed legs included
     algo_bytes_per_step = ALGO_READ_BYTES_PER_PIXEL * sum(sc["w"] * sc["h"] for sc in scales)
