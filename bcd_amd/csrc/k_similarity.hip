@@ -372,10 +372,17 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const typename PlaneT<APPRO
             s += tl[i + 2]; s += tc[i + 2]; s += tr[i + 2];
             const int n = nh[i] + nh[i + 1] + nh[i + 2];
             const int r = rb + i;
-            const float d = s / (float)n; // 0/0 = NaN -> not similar
             if (cols_ok && r >= 1 && r <= H - 2 && r + dl <= H - 2) {
-                if (d <= tau) word[i] |= 1u << (didx & 31);
-                else if (APPROX && writer && d <= bl.tau_hi) borderline_append(bl, (uint32_t)(r * W + c), (uint32_t)didx);
+                if (APPROX) {
+                    // no division on the approximate planes: s <= tau' n differs from s / n <= tau' by an ulp, which the band around tau
+                    // absorbs (its half-width is 2^-10, the planes' error 5e-4); n == 0 (0 / 0 in the reference) is never similar
+                    const float fn = (float)n;
+                    if (n > 0 && s <= tau * fn) word[i] |= 1u << (didx & 31);
+                    else if (n > 0 && writer && s <= bl.tau_hi * fn) borderline_append(bl, (uint32_t)(r * W + c), (uint32_t)didx);
+                } else {
+                    const float d = s / (float)n; // 0/0 = NaN -> not similar
+                    if (d <= tau) word[i] |= 1u << (didx & 31);
+                }
             }
         }
     }
@@ -444,10 +451,15 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APP
                 s += t[i + 2][j]; s += t[i + 2][j + 1]; s += t[i + 2][j + 2];
                 const int n = nh[i][j] + nh[i + 1][j] + nh[i + 2][j];
                 const int r = rb + i;
-                const float d = s / (float)n; // 0/0 = NaN -> not similar
                 if (cols_ok && r >= 1 && r <= H - 2 && r + dl <= H - 2) {
-                    if (d <= tau) word[i][j] |= 1u << (didx & 31);
-                    else if (APPROX && writer && d <= bl.tau_hi) borderline_append(bl, (uint32_t)(r * W + cj), (uint32_t)didx);
+                    if (APPROX) { // (no division: see k_fwd_masks_w1)
+                        const float fn = (float)n;
+                        if (n > 0 && s <= tau * fn) word[i][j] |= 1u << (didx & 31);
+                        else if (n > 0 && writer && s <= bl.tau_hi * fn) borderline_append(bl, (uint32_t)(r * W + cj), (uint32_t)didx);
+                    } else {
+                        const float d = s / (float)n; // 0/0 = NaN -> not similar
+                        if (d <= tau) word[i][j] |= 1u << (didx & 31);
+                    }
                 }
             }
         }
