@@ -181,6 +181,12 @@ struct bcd_hip_multi {
     long long *d_red[MAX_RANKS][MAX_S + 1]; // all-reduce scratch (RCCL transport)
     hipEvent_t ev_level[MAX_RANKS][MAX_S]; // pyramid level s of the rank is complete (recorded on the rank's tail stream)
     bcd_hip_multi_stats stats;
+    // communication trace of the last frame (bcd_hip_multi_set_comm_trace): per rank, in the order the rank ENQUEUED its operations,
+    // (channel, kind, bytes to / from the rank above, bytes to / from the rank below).  Lets a test check on one GPU what decides
+    // whether the RCCL transport can deadlock: that all ranks enqueue the same sequence and that neighbours agree on every size.
+    bool trace_on = false;
+    std::mutex trace_mutex[MAX_RANKS];
+    std::vector<int64_t> trace[MAX_RANKS];
     // one-process-per-GPU use (bcd_hip_multi_create_rank): only `local_rank` lives in this process; its communicators are built
     // with ncclCommInitRank from the ids all processes share
     int local_rank = -1;
@@ -212,11 +218,19 @@ void fail(bcd_hip_multi *m, const std::string &msg)
 
 // one neighbour exchange on channel `ch`: `bytes_*` to / from the rank above (up) and below (down); null pointers at the borders.
 // The data must have been produced on stream[rank][ch]; on return the received data is ordered before later work of that stream.
+void trace_op(bcd_hip_multi *m, int rank, int ch, int kind, size_t bytes_up, size_t bytes_down)
+{
+    if (!m->trace_on) return;
+    std::lock_guard<std::mutex> lk(m->trace_mutex[rank]);
+    for (int64_t v : { (int64_t)ch, (int64_t)kind, (int64_t)bytes_up, (int64_t)bytes_down }) m->trace[rank].push_back(v);
+}
+
 bool exchange(bcd_hip_multi *m, int rank, int ch, const void *send_up, void *recv_up, size_t bytes_up, const void *send_down, void *recv_down,
               size_t bytes_down)
 {
     hipStream_t st = m->stream[rank][ch];
     const bool up = rank > 0, down = rank < m->n - 1;
+    trace_op(m, rank, ch, 0, up ? bytes_up : 0, down ? bytes_down : 0);
     if (m->use_rccl) {
         ncclResult_t r = ncclGroupStart();
         if (r == ncclSuccess && up) { r = ncclSend(send_up, bytes_up, ncclChar, rank - 1, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(recv_up, bytes_up, ncclChar, rank - 1, m->comm[ch][rank], st); }
@@ -239,6 +253,7 @@ bool exchange(bcd_hip_multi *m, int rank, int ch, const void *send_up, void *rec
 // sum of one integer over all ranks (channel ch); every rank gets the total
 bool allreduce(bcd_hip_multi *m, int rank, int ch, long long *value)
 {
+    trace_op(m, rank, ch, 1, 0, 0);
     if (m->use_rccl) {
         hipStream_t st = m->stream[rank][ch];
         MCHK(m, rank, hipMemcpyAsync(m->d_red[rank][ch], value, sizeof(long long), hipMemcpyHostToDevice, st));
@@ -596,6 +611,22 @@ int bcd_hip_multi_get_stats(const bcd_hip_multi *m, bcd_hip_multi_stats *out)
     return BCD_HIP_OK;
 }
 
+int bcd_hip_multi_set_comm_trace(bcd_hip_multi *m, int enabled)
+{
+    if (!m) return BCD_HIP_EINVAL;
+    m->trace_on = enabled != 0;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_multi_get_comm_trace(bcd_hip_multi *m, int rank, int64_t *out, int capacity)
+{
+    if (!m || rank < 0 || rank >= m->n || capacity < 0 || (capacity > 0 && !out)) return -1;
+    std::lock_guard<std::mutex> lk(m->trace_mutex[rank]);
+    const int n = (int)m->trace[rank].size();
+    for (int i = 0; i < n && i < capacity; ++i) out[i] = m->trace[rank][i];
+    return n;
+}
+
 int bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const float *h_ns, const float *h_hist, const float *h_cov, int W, int H, int D,
                                int nb_scales, const bcd_hip_params *prm, float *h_out)
 {
@@ -609,6 +640,7 @@ int bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const fl
     job.h_col = h_colors; job.h_ns = h_ns; job.h_hist = h_hist; job.h_cov = h_cov; job.h_out = h_out;
     rc = prepare(m, nb_scales);
     if (rc != BCD_HIP_OK) return rc;
+    for (int r = 0; r < m->n; ++r) m->trace[r].clear();
     std::vector<std::thread> th;
     std::vector<char> ok(m->n, 1);
     for (int r = 1; r < m->n; ++r) th.emplace_back([&, r]() { ok[r] = rank_worker(job, r) ? 1 : 0; });

@@ -144,6 +144,12 @@ int  bcd_hip_multi_create(bcd_hip_multi **m, const int *devices, int n_ranks);
 void bcd_hip_multi_destroy(bcd_hip_multi *m);
 const char *bcd_hip_multi_last_error(const bcd_hip_multi *m);
 int  bcd_hip_multi_get_stats(const bcd_hip_multi *m, bcd_hip_multi_stats *out);
+/* Communication trace of the last frame (debugging / tests): per rank, in the order the rank ENQUEUED them, four values per
+ * operation: channel (scale, or nb_scales for the merges), kind (0 = neighbour exchange, 1 = all-reduce), bytes exchanged with the
+ * rank above, bytes exchanged with the rank below.  All ranks must show the same (channel, kind) sequence and neighbours the same
+ * sizes -- the conditions under which the RCCL transport cannot block.  get returns the number of values (4 per operation). */
+int  bcd_hip_multi_set_comm_trace(bcd_hip_multi *m, int enabled);
+int  bcd_hip_multi_get_comm_trace(bcd_hip_multi *m, int rank, int64_t *out, int capacity);
 int  bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const float *h_nsamples, const float *h_histograms,
                                 const float *h_covariances, int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *h_out);
 /* The same partition with ONE PROCESS PER GPU (MPI-style launchers; what bench.py --gpus N uses): every process creates the handle

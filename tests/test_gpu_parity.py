@@ -806,6 +806,48 @@ def test_native_multi_rank_driver_ordered_communication(hipctx, monkeypatch, ran
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ordered", [True, False])
+@pytest.mark.parametrize("m", [1.0, 0.0])
+def test_native_multi_rank_driver_communication_protocol(hipctx, monkeypatch, ordered, m):
+    """what decides whether the RCCL transport can block, checked on one GPU from the driver's communication trace: every rank
+    enqueues the same sequence of (channel, operation) -- globally with the issue-order rule of the RCCL transport (coarse scales
+    first, the merges' exchanges last), per channel without it -- and neighbouring ranks agree on the size of every message"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    monkeypatch.setenv("BCD_HIP_MULTI_ORDERED", "1" if ordered else "0")
+    W, H, S, ranks = 256, 288, 3, 4
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 21, 0.12, 0.005)
+    prm = bh.default_params(m=m, random_order=1, seed=9, b=6)
+    md = bh.MultiDenoiser([0] * ranks)
+    try:
+        md.set_comm_trace(True)
+        md.denoise_host(col, ns, hist, cov, S, prm)
+        traces = [md.comm_trace(r) for r in range(ranks)]
+    finally:
+        md.close()
+    assert all(len(t) == len(traces[0]) and len(t) > 0 for t in traces)
+    per_channel = lambda t, c: [(k, up, dn) for ch, k, up, dn in t if ch == c]
+    for c in range(S + 1):
+        ops = [per_channel(t, c) for t in traces]
+        assert all([k for k, _, _ in o] == [k for k, _, _ in ops[0]] for o in ops)          # same operations on the channel
+        for i in range(len(ops[0])):
+            assert ops[0][i][1] == 0 and ops[-1][i][2] == 0                                     # nothing beyond the outer ranks
+            for r in range(ranks - 1):
+                assert ops[r][i][2] == ops[r + 1][i][1] and (ops[r][i][0] == 1 or ops[r][i][2] > 0)   # message sizes agree
+    if ordered:
+        seq = [[(ch, k) for ch, k, _, _ in t] for t in traces]
+        assert all(q == seq[0] for q in seq)                                                    # one global sequence
+        chans = [ch for ch, _ in seq[0]]
+        first = {c: chans.index(c) for c in set(chans)}
+        last = {c: len(chans) - 1 - chans[::-1].index(c) for c in set(chans)}
+        for c in range(S - 1):
+            assert last[c + 1] < first[c]                                                       # coarser scales are through first
+        assert first[S] > max(last[c] for c in range(S))                                        # the merges' exchanges come last
+    if m > 0:
+        assert any(k == 1 for _, k, _, _ in traces[0])                                          # the marking all-reduce was there
+
+
+@pytest.mark.gpu
 def test_native_multi_rank_driver_large_window_prefilter_random_order(hipctx):
     """BASELINE configs[4] through the band path at a reduced size: b = 12, spike prefilter (-p 1) and random order (-r 1), 3 scales"""
     import bcd_amd.hip as bh
