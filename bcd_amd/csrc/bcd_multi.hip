@@ -726,6 +726,7 @@ int bcd_hip_multi_rank_step(bcd_hip_multi *m)
     Job job;
     int rc = rank_job(m, job);
     if (rc != BCD_HIP_OK) return rc;
+    { std::lock_guard<std::mutex> lk(m->trace_mutex[m->local_rank]); m->trace[m->local_rank].clear(); }
     if (!rank_compute(job, m->local_rank)) return BCD_HIP_EDEVICE;
     m->stats.frames += 1;
     return BCD_HIP_OK;
