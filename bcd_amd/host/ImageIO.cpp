@@ -525,51 +525,80 @@ namespace bcd
 			if(!r.ok) return fail("truncated EXR offset table");
 
 			planes.assign(channels.size(), vector<float>(size_t(W) * H, 0.f));
-			vector<unsigned char> raw, tmp;
-			for(int b = 0; b < nbOfBlocks; ++b)
+			// the chunks are independent (own offset, own lines): decoded on all host cores -- a 60-channel 1080p histogram file is
+			// half a gigabyte of zlib streams, seconds on one core next to a 7 ms denoise
+			const char* firstError = nullptr;
+			bool outOfMemory = false;
+#pragma omp parallel
 			{
-				if(offsets[b] > data.size() - 8) return fail("EXR chunk offset out of range");
-				r.pos = size_t(offsets[b]);
-				const int y = r.get<int32_t>() - minY;
-				const int32_t chunkSize = r.get<int32_t>();
-				if(!r.ok || chunkSize < 0 || size_t(chunkSize) > data.size() - r.pos || y < 0 || y >= H) return fail("corrupt EXR chunk");
-				const int lines = min(linesPerBlock, H - y);
-				const size_t expected = bytesPerLine * lines;
-				const unsigned char* src = &data[r.pos];
-				if(size_t(chunkSize) == expected || compression == e_none)
+				vector<unsigned char> raw, tmp;
+#pragma omp for schedule(dynamic, 1)
+				for(int b = 0; b < nbOfBlocks; ++b)
 				{
-					if(size_t(chunkSize) != expected) return fail("EXR chunk has an unexpected size");
-					raw.assign(src, src + expected);
-				}
-				else if(compression == e_rle)
-				{
-					if(!rleDecode(src, size_t(chunkSize), raw, expected)) return fail("corrupt RLE data in EXR chunk");
-					undoPredictorAndReorder(raw, tmp);
-				}
-				else if(compression == e_piz)
-				{
-					if(!piz::decodeChunk(src, size_t(chunkSize), W, lines, channelWords, raw) || raw.size() != expected) return fail("corrupt PIZ data in EXR chunk");
-				}
-				else
-				{
-					raw.resize(expected);
-					uLongf outSize = uLongf(expected);
-					if(uncompress(raw.data(), &outSize, src, uLong(chunkSize)) != Z_OK || outSize != expected) return fail("corrupt ZIP data in EXR chunk");
-					undoPredictorAndReorder(raw, tmp);
-				}
-				const unsigned char* p = raw.data();
-				for(int l = 0; l < lines; ++l)
-					for(size_t c = 0; c < channels.size(); ++c)
+					const char* err = nullptr;
+					try
 					{
-						float* dst = &planes[c][size_t(y + l) * W];
-						if(channels[c].type == e_half)
-							for(int x = 0; x < W; ++x, p += 2) { uint16_t h; memcpy(&h, p, 2); dst[x] = halfToFloat(h); }
-						else if(channels[c].type == e_float)
-							for(int x = 0; x < W; ++x, p += 4) memcpy(&dst[x], p, 4);
-						else
-							for(int x = 0; x < W; ++x, p += 4) { uint32_t u; memcpy(&u, p, 4); dst[x] = float(u); }
+						err = [&]() -> const char*
+						{
+							if(offsets[b] > data.size() - 8) return "EXR chunk offset out of range";
+							Reader rb = r;
+							rb.pos = size_t(offsets[b]);
+							const int y = rb.get<int32_t>() - minY;
+							const int32_t chunkSize = rb.get<int32_t>();
+							if(!rb.ok || chunkSize < 0 || size_t(chunkSize) > data.size() - rb.pos || y < 0 || y >= H) return "corrupt EXR chunk";
+							const int lines = min(linesPerBlock, H - y);
+							const size_t expected = bytesPerLine * lines;
+							const unsigned char* src = &data[rb.pos];
+							if(size_t(chunkSize) == expected || compression == e_none)
+							{
+								if(size_t(chunkSize) != expected) return "EXR chunk has an unexpected size";
+								raw.assign(src, src + expected);
+							}
+							else if(compression == e_rle)
+							{
+								if(!rleDecode(src, size_t(chunkSize), raw, expected)) return "corrupt RLE data in EXR chunk";
+								undoPredictorAndReorder(raw, tmp);
+							}
+							else if(compression == e_piz)
+							{
+								if(!piz::decodeChunk(src, size_t(chunkSize), W, lines, channelWords, raw) || raw.size() != expected) return "corrupt PIZ data in EXR chunk";
+							}
+							else
+							{
+								raw.resize(expected);
+								uLongf outSize = uLongf(expected);
+								if(uncompress(raw.data(), &outSize, src, uLong(chunkSize)) != Z_OK || outSize != expected) return "corrupt ZIP data in EXR chunk";
+								undoPredictorAndReorder(raw, tmp);
+							}
+							const unsigned char* p = raw.data();
+							for(int l = 0; l < lines; ++l)
+								for(size_t c = 0; c < channels.size(); ++c)
+								{
+									float* dst = &planes[c][size_t(y + l) * W];
+									if(channels[c].type == e_half)
+										for(int x = 0; x < W; ++x, p += 2) { uint16_t h; memcpy(&h, p, 2); dst[x] = halfToFloat(h); }
+									else if(channels[c].type == e_float)
+										for(int x = 0; x < W; ++x, p += 4) memcpy(&dst[x], p, 4);
+									else
+										for(int x = 0; x < W; ++x, p += 4) { uint32_t u; memcpy(&u, p, 4); dst[x] = float(u); }
+								}
+							return nullptr;
+						}();
 					}
+					catch(const std::bad_alloc&) { err = "out of memory"; }   // (an exception must not leave the parallel region)
+					catch(const std::length_error&) { err = "out of memory"; }
+					if(err)
+					{
+#pragma omp critical(bcd_exr_read_error)
+						{
+							if(!firstError) firstError = err;
+							if(string(err) == "out of memory") outOfMemory = true;
+						}
+					}
+				}
 			}
+			if(outOfMemory) throw std::bad_alloc();
+			if(firstError) return fail(firstError);
 			return true;
 		}
 
@@ -634,37 +663,56 @@ namespace bcd
 			const size_t tablePos = out.size();
 			out.resize(out.size() + size_t(nbOfBlocks) * 8);
 			const size_t bytesPerPixel = pixelType == e_half ? 2 : 4, bytesPerLine = bytesPerPixel * names.size() * W;
-			vector<unsigned char> raw, shuffled, packed;
+			// blocks are compressed on all host cores, then laid out in order
+			vector< vector<unsigned char> > blocks(nbOfBlocks);
+			bool zlibFailed = false;
+#pragma omp parallel
+			{
+				vector<unsigned char> raw, shuffled, packed;
+#pragma omp for schedule(dynamic, 1)
+				for(int b = 0; b < nbOfBlocks; ++b)
+				{
+					const int y = b * linesPerBlock, lines = min(linesPerBlock, H - y);
+					raw.resize(bytesPerLine * lines);
+					unsigned char* p = raw.data();
+					for(int l = 0; l < lines; ++l)
+						for(size_t k : order)
+							for(int x = 0; x < W; ++x, p += bytesPerPixel)
+							{
+								const float value = channelOffsets[k] < 0 ? 1.f : i_pPixels[(size_t(y + l) * W + x) * stride + channelOffsets[k]];
+								if(pixelType == e_half) { const uint16_t h = floatToHalf(value); memcpy(p, &h, 2); }
+								else memcpy(p, &value, 4);
+							}
+					reorderAndPredict(raw.data(), raw.size(), shuffled);
+					uLongf packedSize = compressBound(uLong(shuffled.size()));
+					packed.resize(packedSize);
+					if(compress2(packed.data(), &packedSize, shuffled.data(), uLong(shuffled.size()), Z_DEFAULT_COMPRESSION) != Z_OK)
+					{
+#pragma omp critical(bcd_exr_write_error)
+						zlibFailed = true;
+						continue;
+					}
+					vector<unsigned char>& blk = blocks[b];
+					put<int32_t>(blk, y);
+					if(packedSize < raw.size())
+					{
+						put<int32_t>(blk, int32_t(packedSize));
+						blk.insert(blk.end(), packed.begin(), packed.begin() + packedSize);
+					}
+					else
+					{	// incompressible block: stored raw
+						put<int32_t>(blk, int32_t(raw.size()));
+						blk.insert(blk.end(), raw.begin(), raw.end());
+					}
+				}
+			}
+			if(zlibFailed) return fail("zlib compression failed");
 			for(int b = 0; b < nbOfBlocks; ++b)
 			{
-				const int y = b * linesPerBlock, lines = min(linesPerBlock, H - y);
-				raw.resize(bytesPerLine * lines);
-				unsigned char* p = raw.data();
-				for(int l = 0; l < lines; ++l)
-					for(size_t k : order)
-						for(int x = 0; x < W; ++x, p += bytesPerPixel)
-						{
-							const float value = channelOffsets[k] < 0 ? 1.f : i_pPixels[(size_t(y + l) * W + x) * stride + channelOffsets[k]];
-							if(pixelType == e_half) { const uint16_t h = floatToHalf(value); memcpy(p, &h, 2); }
-							else memcpy(p, &value, 4);
-						}
-				reorderAndPredict(raw.data(), raw.size(), shuffled);
-				uLongf packedSize = compressBound(uLong(shuffled.size()));
-				packed.resize(packedSize);
-				if(compress2(packed.data(), &packedSize, shuffled.data(), uLong(shuffled.size()), Z_DEFAULT_COMPRESSION) != Z_OK) return fail("zlib compression failed");
 				const uint64_t offset = out.size();
 				memcpy(&out[tablePos + size_t(b) * 8], &offset, 8);
-				put<int32_t>(out, y);
-				if(packedSize < raw.size())
-				{
-					put<int32_t>(out, int32_t(packedSize));
-					out.insert(out.end(), packed.begin(), packed.begin() + packedSize);
-				}
-				else
-				{	// incompressible block: stored raw
-					put<int32_t>(out, int32_t(raw.size()));
-					out.insert(out.end(), raw.begin(), raw.end());
-				}
+				out.insert(out.end(), blocks[b].begin(), blocks[b].end());
+				vector<unsigned char>().swap(blocks[b]);
 			}
 			FILE* f = fopen(path, "wb");
 			if(!f) return fail(string("cannot create '") + path + "'");
@@ -720,9 +768,11 @@ namespace bcd
 		const int depth = int(channels.size());
 		o_rImage.resize(w, h, depth);
 		float* dst = o_rImage.getDataPtr();
-		for(size_t i = 0, n = size_t(w) * h; i < n; ++i)
+		const long long n = (long long)w * h;
+#pragma omp parallel for schedule(static)
+		for(long long i = 0; i < n; ++i)
 			for(int z = 0; z < depth; ++z)
-				dst[i * depth + z] = planes[z][i];
+				dst[size_t(i) * depth + z] = planes[z][size_t(i)];
 		return true;
 	}
 
