@@ -912,6 +912,33 @@ int bcd_hip_similarity_masks(bcd_hip_ctx *ctx, const float *d_hist, const float 
     return similarity(ctx, ctx->main, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count);
 }
 
+int bcd_hip_similarity_masks_deferred(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
+                                      uint32_t *d_mask, int32_t *d_count)
+{
+    if (!ctx || !d_hist || !d_ns || !d_mask || !d_count) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
+    bcd_hip_params p; bcd_hip_default_params(&p); p.patch_radius = w; p.search_radius = b;
+    RCCHK(check_params(ctx, W, H, D, &p));
+    return similarity(ctx, ctx->main, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 2);
+}
+
+int bcd_hip_similarity_masks_verdict(bcd_hip_ctx *ctx, int *redo)
+{
+    if (!ctx || !redo) return BCD_HIP_EINVAL;
+    *redo = similarity_needs_redo(ctx->main) ? 1 : 0;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_similarity_masks_exact(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
+                                   uint32_t *d_mask, int32_t *d_count)
+{
+    if (!ctx || !d_hist || !d_ns || !d_mask || !d_count) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
+    bcd_hip_params p; bcd_hip_default_params(&p); p.patch_radius = w; p.search_radius = b;
+    RCCHK(check_params(ctx, W, H, D, &p));
+    return similarity(ctx, ctx->main, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 1);
+}
+
 int bcd_hip_window_distances(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b,
                              int line, int col, float *h_out)
 {

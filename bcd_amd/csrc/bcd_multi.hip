@@ -332,30 +332,59 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
     // the finest scale is the critical path of the band: the coarse scales' persistent estimate kernels keep to a quarter of the CU slots
     ECHK(m, rank, c, bcd_hip_set_cu_share(c, s == 0 || g.S == 1 ? 100 : 25));
     ECHK(m, rank, c, bcd_hip_pixel_cov(c, cov, ns, W, rows, pixcov));
-    ECHK(m, rank, c, bcd_hip_similarity_masks(c, hist, ns, W, rows, D, w, b, job.prm.hist_dist_threshold, mask, nsim));
-    if (m->ordered && g.world > 1 && !m->gate[rank].wait_coarser(s, g.S)) return false;
-    if (job.prm.marked_skip_probability > 0.f && g.world > 1) {
-        // |S| of the b boundary lines comes from their owner (locally their windows are cut by the band edge)
-        if (!exchange(m, rank, s, nsim + (size_t)r0 * W, up ? nsim + (size_t)(r0 - b) * W : nullptr, (size_t)b * W * 4,
-                      nsim + (size_t)(r1 - b) * W, down ? nsim + (size_t)r1 * W : nullptr, (size_t)b * W * 4)) return false;
+    // Similar-patch masks with the production kernels; whether they are valid (inputs inside the guarded range, borderline list not
+    // overflowed) comes back with the first host round trip that follows anyway -- the first marking batch -- instead of one of its own.
+    const float tau = job.prm.hist_dist_threshold;
+    const bool marking = job.prm.marked_skip_probability > 0.f;
+    ECHK(m, rank, c, bcd_hip_similarity_masks_deferred(c, hist, ns, W, rows, D, w, b, tau, mask, nsim));
+    bool verdict_known = false;
+    if (!marking) { // no marking batch: ask now; the masks are local, so every rank decides for itself
+        MCHK(m, rank, hipStreamSynchronize(st));
+        int redo = 0;
+        ECHK(m, rank, c, bcd_hip_similarity_masks_verdict(c, &redo));
+        if (redo) ECHK(m, rank, c, bcd_hip_similarity_masks_exact(c, hist, ns, W, rows, D, w, b, tau, mask, nsim));
+        verdict_known = true;
     }
-    ECHK(m, rank, c, bcd_hip_active_init(c, nsim, W, rows, w, r0, r1, job.prm.marked_skip_probability, seed, row_offset, state));
+    if (m->ordered && g.world > 1 && !m->gate[rank].wait_coarser(s, g.S)) return false;
     int rounds = 0;
-    if (job.prm.marked_skip_probability > 0.f) {
-        long long before = -1;
-        for (;;) {
-            if (g.world > 1 && !exchange(m, rank, s, state + (size_t)r0 * W, up ? state + (size_t)(r0 - b) * W : nullptr, (size_t)b * W,
-                                         state + (size_t)(r1 - b) * W, down ? state + (size_t)r1 * W : nullptr, (size_t)b * W)) return false;
-            int32_t undecided = 0;
-            ECHK(m, rank, c, bcd_hip_active_step(c, mask, nsim, W, rows, w, b, r0, r1, job.prm.use_random_pixel_order, seed, row_offset,
-                                                  rounds == 0 && job.prm.marked_skip_probability >= 1.f, state, &undecided));
-            ++rounds;
-            long long total = undecided;
-            if (g.world > 1 && !allreduce(m, rank, s, &total)) return false;
-            if (total == 0) break;
-            if (before >= 0 && total >= before && rounds > 4 * (W + sb.H) + 64) { fail(m, "marking fixed point made no progress"); return false; }
-            before = total;
+    const long long REDO = 1ll << 40; // added to the all-reduced count of undecided pixels by a rank whose masks are not valid
+    for (;;) { // the marking problem; once more from the start if some rank has to recompute its masks
+        if (marking && g.world > 1) {
+            // |S| of the b boundary lines comes from their owner (locally their windows are cut by the band edge)
+            if (!exchange(m, rank, s, nsim + (size_t)r0 * W, up ? nsim + (size_t)(r0 - b) * W : nullptr, (size_t)b * W * 4,
+                          nsim + (size_t)(r1 - b) * W, down ? nsim + (size_t)r1 * W : nullptr, (size_t)b * W * 4)) return false;
         }
+        ECHK(m, rank, c, bcd_hip_active_init(c, nsim, W, rows, w, r0, r1, job.prm.marked_skip_probability, seed, row_offset, state));
+        rounds = 0;
+        bool restart = false, my_redo = false;
+        if (marking) {
+            long long before = -1;
+            for (;;) {
+                if (g.world > 1 && !exchange(m, rank, s, state + (size_t)r0 * W, up ? state + (size_t)(r0 - b) * W : nullptr, (size_t)b * W,
+                                             state + (size_t)(r1 - b) * W, down ? state + (size_t)r1 * W : nullptr, (size_t)b * W)) return false;
+                int32_t undecided = 0;
+                ECHK(m, rank, c, bcd_hip_active_step(c, mask, nsim, W, rows, w, b, r0, r1, job.prm.use_random_pixel_order, seed, row_offset,
+                                                      rounds == 0 && job.prm.marked_skip_probability >= 1.f, state, &undecided));
+                ++rounds;
+                long long total = undecided;
+                if (!verdict_known) { // the batch synchronised the stream: the flags of the masks are on the host
+                    int redo = 0;
+                    ECHK(m, rank, c, bcd_hip_similarity_masks_verdict(c, &redo));
+                    my_redo = redo != 0;
+                    if (my_redo) total += REDO;
+                }
+                if (g.world > 1 && !allreduce(m, rank, s, &total)) return false;
+                if (!verdict_known) {
+                    verdict_known = true;
+                    if (total >= REDO) { restart = true; break; }
+                }
+                if (total == 0) break;
+                if (before >= 0 && total >= before && rounds > 4 * (W + sb.H) + 64) { fail(m, "marking fixed point made no progress"); return false; }
+                before = total;
+            }
+        }
+        if (!restart) break;
+        if (my_redo) ECHK(m, rank, c, bcd_hip_similarity_masks_exact(c, hist, ns, W, rows, D, w, b, tau, mask, nsim));
     }
     // halo lines are processed by their owner
     if (r0 > 0) MCHK(m, rank, hipMemsetAsync(state, 0, (size_t)r0 * W, st));

@@ -189,6 +189,17 @@ int bcd_hip_pixel_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_nsamp
 int bcd_hip_similarity_masks(bcd_hip_ctx *ctx, const float *d_histograms, const float *d_nsamples,
                              int W, int H, int D, int patch_radius, int search_radius, float threshold,
                              uint32_t *d_mask, int32_t *d_count);
+/* The same in three steps, for callers that have a host round trip of their own coming (the multi-GPU driver: its first marking
+ * batch): _deferred enqueues the production kernels and copies their validity flags to the host WITHOUT waiting; after the caller's
+ * next synchronisation of the context's stream, _verdict says whether the masks have to be recomputed with the exact kernels
+ * (inputs outside the guarded range, borderline list overflowed) -- then call _exact. */
+int bcd_hip_similarity_masks_deferred(bcd_hip_ctx *ctx, const float *d_histograms, const float *d_nsamples,
+                                      int W, int H, int D, int patch_radius, int search_radius, float threshold,
+                                      uint32_t *d_mask, int32_t *d_count);
+int bcd_hip_similarity_masks_verdict(bcd_hip_ctx *ctx, int *redo);
+int bcd_hip_similarity_masks_exact(bcd_hip_ctx *ctx, const float *d_histograms, const float *d_nsamples,
+                                   int W, int H, int D, int patch_radius, int search_radius, float threshold,
+                                   uint32_t *d_mask, int32_t *d_count);
 /* raw patch distances of one main pixel to its window (debug / parity): (2b+1)^2 floats, +inf outside */
 int bcd_hip_window_distances(bcd_hip_ctx *ctx, const float *d_histograms, const float *d_nsamples,
                              int W, int H, int D, int patch_radius, int search_radius,

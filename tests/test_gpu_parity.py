@@ -848,6 +848,36 @@ def test_native_multi_rank_driver_communication_protocol(hipctx, monkeypatch, or
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m", [1.0, 0.0])
+def test_native_multi_rank_driver_recomputes_masks_when_one_band_leaves_the_guarded_range(hipctx, m):
+    """one pixel of ONE band has histogram bins / a sample count outside the range the production distance kernels guard: that
+    rank's verdict arrives with its first marking batch, the all-reduce tells every rank, the marking restarts on exact masks --
+    and the frame is still the single-GPU frame (which takes the same fallback on its own)"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    W, H, S, ranks = 128, 160, 2, 3
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 4, 0.2, 0.0)
+    hist = hist.copy(); ns = ns.copy()
+    hist[H - 20, 33, :] *= 4.0e6    # in the last band only
+    ns[H - 20, 33] *= 4.0e6
+    prm = bh.default_params(m=m, random_order=1, seed=3, b=6)
+    want = hipctx.denoise_host(col, ns, hist, cov, S, prm)
+    assert hipctx.stats(0).similarity_path != 1      # the single-GPU run itself fell back to the exact kernels on scale 0
+    md = bh.MultiDenoiser([0] * ranks)
+    try:
+        md.set_comm_trace(True)
+        got = md.denoise_host(col, ns, hist, cov, S, prm)
+        traces = [md.comm_trace(r) for r in range(ranks)]
+    finally:
+        md.close()
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < 1e-5
+    for c in range(S + 1):   # every rank restarted alike: the same operations on every channel
+        assert all([k for ch, k, _, _ in t if ch == c] == [k for ch, k, _, _ in traces[0] if ch == c] for t in traces)
+
+
+@pytest.mark.gpu
 def test_native_multi_rank_driver_large_window_prefilter_random_order(hipctx):
     """BASELINE configs[4] through the band path at a reduced size: b = 12, spike prefilter (-p 1) and random order (-r 1), 3 scales"""
     import bcd_amd.hip as bh
