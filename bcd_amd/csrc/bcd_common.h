@@ -42,6 +42,8 @@ __host__ __device__ inline int bcd_delta_count(int b) { return (b + 1) + b * (2 
 // >= 0, so the patch distance is within 5.0e-4 of the reference's; pairs inside tau (1 +- 2^-10) are re-evaluated exactly.
 // Thresholds outside [BCD_APPROX_TAU_MIN, BCD_APPROX_TAU_MAX] take the exact kernels: below, binary16 subnormals (absolute error
 // 2^-25 per entry) would matter; above, an entry that overflowed to +inf could belong to a similar pair.
+// (The subnormal figure assumes that binary16 subnormals are kept, which is HIP's default -- float_denorm_mode_16_64 = 3 in the
+// kernel descriptors; do not build these files with -fgpu-flush-denormals-to-zero.)
 #define BCD_APPROX_DELTA 9.765625e-04f /* 2^-10 */
 #define BCD_APPROX_TAU_MIN 0.015625f
 #define BCD_APPROX_TAU_MAX 64.f
