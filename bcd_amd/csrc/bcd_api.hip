@@ -5,6 +5,7 @@
 #include "bcd_common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -100,6 +101,11 @@ struct bcd_hip_ctx {
     bool fast_similarity = true; // approximate distance planes + exact re-evaluation at the threshold (k_similarity_fast.hip)
     int num_cus = 256;
     int cu_share_pct = 100;  // bcd_hip_set_cu_share
+    // share of the CU slots the coarse scales' persistent estimate kernels take inside bcd_hip_denoise (bayes()); adjusted from call to
+    // call on the same geometry so that the coarse scales end shortly before the finest one (see bcd_hip_denoise)
+    int coarse_share = 25;
+    bool coarse_share_fixed = false; // BCD_HIP_COARSE_PCT given
+    int64_t share_key = 0;          // geometry the current value was tuned on
     std::mutex err_mutex;
     std::string err;
     bcd_hip_scale_stats stats[MAX_SCALES];
@@ -384,10 +390,10 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     // The estimate kernels are persistent (a wavefront per CU slot, items from a counter), so whatever they occupy stays
     // occupied until they end.  In a multiscale call the finest scale is the critical path and the coarse scales have slack: they
     // take a quarter of the slots, which leaves LDS and wave slots on every CU to the finest scale's short kernels (masks,
-    // marking, lists) running beside them -- measured 1080p: 306 -> 315 Mpix/s (100 % -> 25 %; 12 %: 320, 6 %: 250).
-    static const int coarse_pct = getenv("BCD_HIP_COARSE_PCT") ? atoi(getenv("BCD_HIP_COARSE_PCT")) : 25;
+    // marking, lists) running beside them -- measured 1080p: 306 -> 315 Mpix/s (100 % -> 25 %; 12 %: 320, 6 %: 250).  The share is
+    // ctx->coarse_share: 25 on a new geometry, then steered by bcd_hip_denoise.
     int cus = std::max(1, ctx->num_cus * ctx->cu_share_pct / 100);
-    if (&wk != &ctx->main) cus = std::max(1, cus * coarse_pct / 100);
+    if (&wk != &ctx->main) cus = std::max(1, cus * ctx->coarse_share / 100);
     const int weak_blocks = (int)std::min<int64_t>(cap, (int64_t)cus * 32);
     // the two paths only meet in the atomic accumulators: the fallback pixels (many cheap items) run on a side stream beside
     // the full estimate (few long items)
@@ -478,6 +484,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     st.processed = ns + nw; st.fallback = nw; st.similar_total = tot;
     st.similarity_path = wk.border_capacity > 0 ? 1 : 0;
     st.borderline_pairs = wk.border_capacity > 0 ? wk.h_counters[43] : 0;
+    st.cu_share = ctx->cu_share_pct * (&wk != &ctx->main ? ctx->coarse_share : 100) / 100;
     if (prof) {
         st.ms_similarity = stage_ms(wk, 0, 1);
         st.ms_active = stage_ms(wk, 1, 2);
@@ -602,6 +609,10 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) ctx->num_cus = cus;
+    }
+    if (const char *pct = getenv("BCD_HIP_COARSE_PCT")) {
+        ctx->coarse_share = std::min(100, std::max(1, atoi(pct)));
+        ctx->coarse_share_fixed = true;
     }
     const char *env = getenv("BCD_HIP_SERIAL_SCALES");
     ctx->concurrent_scales = !(env && env[0] == '1');
@@ -735,6 +746,13 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
     // own pyramid level on its stream (from level s-1, once that is complete), so that the finest scale -- the critical
     // path -- starts at once; after its own chain scale s merges the (already merged) scale s+1 into its output.
     if (ctx->concurrent_scales) {
+        // The coarse scales' share of the CU slots (bayes()) follows the previous call on the same geometry: they should be through when
+        // the finest scale is at 80 - 92 % of its chain -- earlier means their persistent kernels took more room than they needed next to
+        // the finest scale's short kernels, later means they have become the critical path.  Small steps down, larger ones up.
+        const int64_t key = ((int64_t)W << 40) ^ ((int64_t)H << 20) ^ ((int64_t)nb_scales << 12) ^ ((int64_t)prm->search_radius << 4) ^ (prm->marked_skip_probability > 0.f);
+        if (!ctx->coarse_share_fixed && key != ctx->share_key) { ctx->coarse_share = 25; ctx->share_key = key; }
+        const auto t_start = std::chrono::steady_clock::now();
+        double t_done[MAX_SCALES] = { 0 };
         HIPCHK(ctx, hipEventRecord(ctx->ev_pyramid, ctx->stream)); // the caller's inputs are ready
         int rcs[MAX_SCALES];
         std::thread threads[MAX_SCALES];
@@ -763,6 +781,7 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
                     }
                     rc = mono(ctx, *w, col[s], ns[s], hs[s], cv[s], ws[s], hh[s], D, prm, bcd_hip_scale_seed(prm->order_seed, s), s, out[s]);
                     if (rc != BCD_HIP_OK) break;
+                    t_done[s] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); // (mono ends with a stream synchronisation)
                     if (s < nb_scales - 1) {
                         if (await(done[s + 1]) < 0) { rc = BCD_HIP_EDEVICE; break; }
                         if (hipStreamWaitEvent(w->stream, ctx->extra[s + 1].ev_done, 0) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
@@ -782,6 +801,13 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
         }
         for (int s = 1; s < nb_scales; ++s) threads[s].join();
         for (int s = 0; s < nb_scales; ++s) RCCHK(rcs[s]);
+        if (!ctx->coarse_share_fixed && nb_scales > 1 && t_done[0] > 0.0) {
+            double last = 0.0;
+            for (int s = 1; s < nb_scales; ++s) last = std::max(last, t_done[s]);
+            const double frac = last / t_done[0];
+            if (frac < 0.80) ctx->coarse_share = std::max(8, ctx->coarse_share - 2);
+            else if (frac > 0.92) ctx->coarse_share = std::min(60, ctx->coarse_share + 6);
+        }
         return BCD_HIP_OK;
     }
     for (int s = 1; s < nb_scales; ++s)

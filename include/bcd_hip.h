@@ -69,6 +69,8 @@ typedef struct bcd_hip_scale_stats {
     float   ms_total;
     int32_t similarity_path;  /* 1 = approximate planes + exact verification at the threshold, 0 = exact planes */
     int32_t borderline_pairs; /* pairs re-evaluated exactly (similarity_path == 1)  */
+    int32_t cu_share;         /* share (%) of the CU slots this scale's persistent estimate kernels took (100: all)  */
+    int32_t reserved_;
 } bcd_hip_scale_stats;
 
 /* ---- context ------------------------------------------------------------------------------ */
