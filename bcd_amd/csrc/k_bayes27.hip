@@ -288,28 +288,32 @@ __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
 #pragma unroll
     for (int c = 0; c < K; ++c) m[c] = M[r * LD + c];
     bool ok = true;
+    float scale = 1.f; // pending scale of this lane's row: 1 until the row has been the pivot row, 1 / d afterwards
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float d = bcast_lane(m[k], k);
+        const float d = bcast_lane(m[k], k); // (row k has not been scaled yet: its scale is still 1)
         ok = ok && (d > 0.f);
         const float inv_d = 1.f / d;
         const bool pivot_row = (lane == k);
-        // row r != k: a_rc - (a_rk / d) a_kc;  pivot row: a_kc / d  -- one multiply + fma for every lane (h selects the old value).
+        // row r != k: a_rc - (a_rk / d) a_kc -- one fma per element.  The pivot row's own step, a_kc / d, is only recorded in its
+        // scale: a row's scale cancels out of every later update of that row (the multiplier a_rk / d' carries it, the pivot row of
+        // that later step is still unscaled), so it is applied once at the end instead of 26 multiplies per step for every lane.
         // (Sending the pivot row through LDS instead of 27 v_readlane per step was measured: twice as slow, the step then waits
         // for an LDS round trip.)
-        const float f = pivot_row ? -inv_d : m[k] * inv_d, h = pivot_row ? 0.f : 1.f;
+        const float f = pivot_row ? 0.f : m[k] * inv_d;
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             if (c == k) continue;
             const float pkc = bcast_lane(m[c], k); // a_kc (old)
-            m[c] = fmaf(-f, pkc, h * m[c]);
+            m[c] = fmaf(-f, pkc, m[c]);
         }
-        m[k] = f; // -1 / d on the pivot row, a_rk / d elsewhere
+        m[k] = pivot_row ? -1.f : f; // (-1) x scale = -1 / d on the pivot row, a_rk / d elsewhere
+        scale = pivot_row ? inv_d : scale;
     }
     float fro = 0.f;
 #pragma unroll
     for (int c = 0; c < K; ++c) {
-        m[c] = -m[c];
+        m[c] = -scale * m[c];
         fro = fmaf(m[c], m[c], fro);
     }
     if (lane >= K) fro = 0.f;
