@@ -50,14 +50,40 @@ def accumulate(samples, W, H, nbins=20, gamma=2.2, maxval=2.5):
     return ns, mean, cov, hist
 
 
-def denoise(col, ns, hist, cov, nscales=1, tau=1.0, w=1, b=6, min_eig=1e-8, random_order=True, m=1.0, seed=1234, hist_width_override=0):
-    """bcd::Denoiser / bcd::MultiscaleDenoiser via IDenoiser; returns (ok, out, progress_monotone)"""
+def denoise(col, ns, hist, cov, nscales=1, tau=1.0, w=1, b=6, min_eig=1e-8, random_order=True, m=1.0, seed=1234, hist_width_override=0,
+            use_cuda=True, devices=None, prefilter_factor=0.0):
+    """bcd::Denoiser / bcd::MultiscaleDenoiser via IDenoiser; returns (ok, out, progress_monotone).
+    use_cuda -> DenoiserParameters::m_useCuda, devices -> setDevices, prefilter_factor -> setSpikePrefilter"""
     H, W, D = hist.shape
     out = np.zeros((H, W, 3), np.float32)
     p = lambda a: None if a is None else _fp(a)
-    rc = lib().bcdcore_denoise(p(col), p(ns), p(hist), p(cov), W, H, D, nscales, C.c_float(tau), w, b, C.c_float(min_eig),
-                               1 if random_order else 0, C.c_float(m), C.c_uint(seed), _fp(out), int(hist_width_override))
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    rc = lib().bcdcore_denoise_ex(p(col), p(ns), p(hist), p(cov), W, H, D, nscales, C.c_float(tau), w, b, C.c_float(min_eig),
+                                  1 if random_order else 0, C.c_float(m), C.c_uint(seed), _fp(out), int(hist_width_override),
+                                  1 if use_cuda else 0, devs, len(devices) if devices else 0, C.c_float(prefilter_factor))
     return rc != 0, out, rc == 1
+
+
+def last_nb_of_cores():
+    """DenoiserParameters::m_nbOfCores after the last denoise() (the reference writes the actual thread count back)"""
+    return lib().bcdcore_last_nb_of_cores()
+
+
+def release_engines():
+    """bcd::releaseEngines(): destroy the cached engine contexts (device workspaces) of libbcdcore"""
+    lib().bcdcore_release_engines()
+
+
+def accumulate_threadsafe(samples, W, H, threads=4, nbins=20, gamma=2.2, maxval=2.5):
+    """SamplesAccumulatorThreadSafe::addSampleThreadSafely from `threads` OpenMP threads"""
+    samples = np.ascontiguousarray(samples, np.float32)
+    ns = np.empty((H, W, 1), np.float32)
+    mean = np.empty((H, W, 3), np.float32)
+    cov = np.empty((H, W, 6), np.float32)
+    hist = np.empty((H, W, 3 * nbins), np.float32)
+    lib().bcdcore_accumulate_threadsafe(_fp(samples), C.c_longlong(samples.shape[0]), W, H, nbins, C.c_float(gamma), C.c_float(maxval), threads,
+                                        _fp(ns), _fp(mean), _fp(cov), _fp(hist))
+    return ns, mean, cov, hist
 
 
 def spike_filter(col, ns, hist, cov, factor=2.0):

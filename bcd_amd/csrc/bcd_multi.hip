@@ -116,6 +116,13 @@ struct HostBarrier {
         while (gen == generation && !abort_flag->load()) cv.wait_for(lk, std::chrono::milliseconds(50));
         return !abort_flag->load();
     }
+    // after a failed frame some ranks have arrived and others never will: forget the arrivals (no thread is waiting when this runs)
+    void reset()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        count = 0;
+        ++generation;
+    }
 };
 
 // ---- CommGate: scale s of a rank may start communicating once the scales s + 1 .. S - 1 of that rank are through -------------
@@ -192,9 +199,35 @@ struct bcd_hip_multi {
     int local_rank = -1;
     std::vector<ncclUniqueId> ids;
     struct Frame { int W = 0, H = 0, D = 0, S = 0; bcd_hip_params prm; bool set = false; } frame;
+    // failure handling of the RCCL transport: the first fail() aborts every local communicator (ncclCommAbort: their device kernels
+    // stop waiting for peers, so the host threads blocked in stream synchronisations return); prepare() rebuilds them.  A watchdog
+    // thread per frame turns "no progress for frame_timeout_s" into such a failure, which is what ends a frame whose PEER (another
+    // process or device) has died.
+    std::mutex comm_mutex;
+    bool comm_aborted = false;
+    int frame_timeout_s = 600;
+    // progress reporting (IDenoiser::setProgressCallback): every (rank, scale) adds its owned pixels twice, like bcd_hip_denoise
+    bcd_hip_progress_fn progress_fn = nullptr;
+    void *progress_user = nullptr;
+    std::mutex progress_mutex;
+    double progress_done = 0.0, progress_total = 0.0;
 };
 
 namespace {
+
+// RCCL transport: stop the communication kernels of every local communicator (idempotent; prepare() creates new ones)
+void abort_comms(bcd_hip_multi *m)
+{
+    if (!m->use_rccl) return;
+    std::lock_guard<std::mutex> lk(m->comm_mutex);
+    for (int c = 0; c <= MAX_S; ++c) {
+        if (!m->comm_ready[c]) continue;
+        for (int r = 0; r < m->n; ++r)
+            if (m->local_rank < 0 || r == m->local_rank) (void)ncclCommAbort(m->comm[c][r]);
+        m->comm_ready[c] = false;
+        m->comm_aborted = true;
+    }
+}
 
 void fail(bcd_hip_multi *m, const std::string &msg)
 {
@@ -203,7 +236,41 @@ void fail(bcd_hip_multi *m, const std::string &msg)
         if (m->err.empty()) m->err = msg;
     }
     m->abort_flag.store(true);
+    abort_comms(m); // peers blocked in ncclSend / ncclRecv / all-reduce kernels (and the host threads waiting for them) are released
 }
+
+void progress_add(bcd_hip_multi *m, double share)
+{
+    if (!m->progress_fn || !(m->progress_total > 0.0)) return;
+    std::lock_guard<std::mutex> lk(m->progress_mutex);
+    m->progress_done = std::min(m->progress_total, m->progress_done + share);
+    m->progress_fn((float)(m->progress_done / m->progress_total), m->progress_user);
+}
+
+// one per frame on the RCCL transport: a frame that has not finished after frame_timeout_s is failed (which aborts the communicators)
+struct FrameWatchdog {
+    bcd_hip_multi *m;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    std::thread th;
+    explicit FrameWatchdog(bcd_hip_multi *m_) : m(m_)
+    {
+        if (!m->use_rccl || m->n < 2 || m->frame_timeout_s <= 0) return;
+        th = std::thread([this]() {
+            std::unique_lock<std::mutex> lk(mu);
+            if (!cv.wait_for(lk, std::chrono::seconds(m->frame_timeout_s), [this]() { return done; }))
+                fail(m, "frame timed out on the RCCL transport (a peer rank has stopped?): communicators aborted");
+        });
+    }
+    ~FrameWatchdog()
+    {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); done = true; }
+        cv.notify_all();
+        th.join();
+    }
+};
 
 #define MCHK(m, rank, expr)                                                                                            \
     do {                                                                                                               \
@@ -386,6 +453,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
         if (!restart) break;
         if (my_redo) ECHK(m, rank, c, bcd_hip_similarity_masks_exact(c, hist, ns, W, rows, D, w, b, tau, mask, nsim));
     }
+    progress_add(m, 0.5 * (double)(r1 - r0) * W); // similar patches selected, processed set known
     // halo lines are processed by their owner
     if (r0 > 0) MCHK(m, rank, hipMemsetAsync(state, 0, (size_t)r0 * W, st));
     if (r1 < rows) MCHK(m, rank, hipMemsetAsync(state + (size_t)r1 * W, 0, (size_t)(rows - r1) * W, st));
@@ -403,6 +471,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
     ECHK(m, rank, c, bcd_hip_finalize_band(c, sum + (size_t)r0 * W * 3, cnt + (size_t)r0 * W, W, r1 - r0, halo, up ? rx_us : nullptr, up ? rx_uc : nullptr,
                                            down ? rx_ds : nullptr, down ? rx_dc : nullptr, out + (size_t)o0 * W * 3));
     MCHK(m, rank, hipStreamSynchronize(st));
+    progress_add(m, 0.5 * (double)(r1 - r0) * W);
     if (rank == 0) m->stats.marking_rounds[s] = rounds;
     return true;
 }
@@ -544,12 +613,18 @@ int prepare(bcd_hip_multi *m, int S)
         for (int c = 0; c <= S; ++c) {
             if (m->comm_ready[c]) continue;
             ncclResult_t r;
+            if (m->local_rank >= 0 && m->comm_aborted) {
+                // the unique ids were consumed by the communicators that have been aborted, and the other processes hold the other halves
+                fail(m, "the RCCL communicators of this rank were aborted after a failure: destroy the handle and create it again from fresh unique ids (all processes)");
+                return BCD_HIP_EDEVICE;
+            }
             if (m->local_rank >= 0) {
                 if ((size_t)c >= m->ids.size()) { fail(m, "not enough RCCL unique ids for this number of scales"); return BCD_HIP_EINVAL; }
                 r = ncclCommInitRank(&m->comm[c][m->local_rank], m->n, m->ids[c], m->local_rank); // collective: every process, same order
             } else
                 r = ncclCommInitAll(m->comm[c], m->n, m->devices);
             if (r != ncclSuccess) { fail(m, std::string("RCCL communicator creation failed: ") + ncclGetErrorString(r)); return BCD_HIP_EDEVICE; }
+            std::lock_guard<std::mutex> lk(m->comm_mutex);
             m->comm_ready[c] = true;
         }
     return BCD_HIP_OK;
@@ -567,11 +642,20 @@ int make_job(bcd_hip_multi *m, Job &job, int W, int H, int D, int nb_scales, con
     return BCD_HIP_OK;
 }
 
+// start of every entry point that runs a frame: no worker thread of an earlier call is alive here.  A frame that failed left
+// some ranks' arrivals in the barriers and bits in the gates; a retry must not inherit them (it would pair up the wrong phases).
 void reset_error(bcd_hip_multi *m)
 {
-    std::lock_guard<std::mutex> lk(m->err_mutex);
-    m->err.clear();
-    m->abort_flag.store(false);
+    {
+        std::lock_guard<std::mutex> lk(m->err_mutex);
+        m->err.clear();
+        m->abort_flag.store(false);
+    }
+    for (int c = 0; c <= MAX_S; ++c) m->barrier[c].reset();
+    for (int r = 0; r < m->n; ++r) m->gate[r].reset();
+    std::lock_guard<std::mutex> lk(m->progress_mutex);
+    m->progress_done = 0.0;
+    m->progress_total = 0.0;
 }
 
 } // namespace
@@ -602,6 +686,7 @@ int bcd_hip_multi_create(bcd_hip_multi **out, const int *devices, int n_ranks)
     memset(&m->stats, 0, sizeof(m->stats));
     for (int c = 0; c <= MAX_S; ++c) { m->barrier[c].parties = n_ranks; m->barrier[c].abort_flag = &m->abort_flag; }
     for (int r = 0; r < n_ranks; ++r) m->gate[r].abort_flag = &m->abort_flag;
+    if (const char *t = getenv("BCD_HIP_MULTI_TIMEOUT_S")) m->frame_timeout_s = atoi(t);
     const char *ordered = getenv("BCD_HIP_MULTI_ORDERED");
     m->ordered = m->use_rccl || (ordered && atoi(ordered) != 0);
     m->stats.n_ranks = n_ranks;
@@ -640,6 +725,15 @@ int bcd_hip_multi_get_stats(const bcd_hip_multi *m, bcd_hip_multi_stats *out)
     return BCD_HIP_OK;
 }
 
+int bcd_hip_multi_set_progress_callback(bcd_hip_multi *m, bcd_hip_progress_fn fn, void *user)
+{
+    if (!m) return BCD_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(m->progress_mutex);
+    m->progress_fn = fn;
+    m->progress_user = user;
+    return BCD_HIP_OK;
+}
+
 int bcd_hip_multi_set_comm_trace(bcd_hip_multi *m, int enabled)
 {
     if (!m) return BCD_HIP_EINVAL;
@@ -670,6 +764,11 @@ int bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const fl
     rc = prepare(m, nb_scales);
     if (rc != BCD_HIP_OK) return rc;
     for (int r = 0; r < m->n; ++r) m->trace[r].clear();
+    {
+        std::lock_guard<std::mutex> lk(m->progress_mutex);
+        for (int s = 0; s < nb_scales; ++s) m->progress_total += (double)(W >> s) * (double)(H >> s);
+    }
+    FrameWatchdog watchdog(m);
     std::vector<std::thread> th;
     std::vector<char> ok(m->n, 1);
     for (int r = 1; r < m->n; ++r) th.emplace_back([&, r]() { ok[r] = rank_worker(job, r) ? 1 : 0; });
@@ -756,6 +855,7 @@ int bcd_hip_multi_rank_step(bcd_hip_multi *m)
     int rc = rank_job(m, job);
     if (rc != BCD_HIP_OK) return rc;
     { std::lock_guard<std::mutex> lk(m->trace_mutex[m->local_rank]); m->trace[m->local_rank].clear(); }
+    FrameWatchdog watchdog(m);
     if (!rank_compute(job, m->local_rank)) return BCD_HIP_EDEVICE;
     m->stats.frames += 1;
     return BCD_HIP_OK;

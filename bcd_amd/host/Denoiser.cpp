@@ -3,6 +3,7 @@
 // (include/bcd_hip.h) which runs the whole loop on the device.  No CPU fallback: a missing device is an error.
 #include "Denoiser.h"
 #include "MultiscaleDenoiser.h"
+#include "SpikeRemovalFilter.h"
 
 #include "bcd_hip.h"
 
@@ -73,6 +74,13 @@ namespace bcd
 			std::mutex m_mutex;
 			bcd_hip_ctx* m_pCtx = nullptr;
 			bcd_hip_multi* m_pMulti = nullptr;
+			void release()
+			{
+				if(m_pCtx) bcd_hip_ctx_destroy(m_pCtx);
+				if(m_pMulti) bcd_hip_multi_destroy(m_pMulti);
+				m_pCtx = nullptr;
+				m_pMulti = nullptr;
+			}
 		};
 		std::mutex g_registryMutex;
 		std::map< std::vector<int>, std::unique_ptr<EngineSlot> > g_registry;
@@ -86,9 +94,22 @@ namespace bcd
 			return *rSlot;
 		}
 
+		// (the registry is deliberately not torn down by a static destructor: at process exit the HIP runtime may already be gone;
+		//  bcd::releaseEngines() is the orderly way to give the memory back)
+
 		void forwardProgress(float i_progress, void* i_pUser)
 		{
 			(*static_cast< std::function<void(float)>* >(i_pUser))(i_progress);
+		}
+	}
+
+	void releaseEngines()
+	{
+		std::lock_guard<std::mutex> lock(g_registryMutex);
+		for(auto& rEntry : g_registry)
+		{
+			std::lock_guard<std::mutex> slotLock(rEntry.second->m_mutex); // waits for a denoise() in flight on that slot
+			rEntry.second->release();
 		}
 	}
 
@@ -99,10 +120,18 @@ namespace bcd
 		m_width = m_inputs.m_pColors->getWidth();
 		m_height = m_inputs.m_pColors->getHeight();
 		m_nbOfPixels = m_width * m_height;
-		// src/core/Denoiser.cpp:99-121: the flags are requests; this build has one path (the HIP device) and says so
+		// src/core/Denoiser.cpp:99-110,241-265: in the reference m_useCuda = false selects the CPU/OpenMP loop.  This library has exactly
+		// one path, the HIP device; a caller that explicitly asks for the CPU path is told so and gets `false` -- never a silent
+		// substitution (INTEGRATION.md shows where the reference's own CPU loop stays in place when the two are linked together)
 		if(!m_parameters.m_useCuda)
-			cout << "Note: --use-cuda 0 / m_useCuda = false requests the CPU path, which this build does not have; running on the HIP device" << endl;
-		m_parameters.m_nbOfCores = 1 + (i_nbOfScales - 1); // host threads that drive the device: one per scale (reference: actual OpenMP thread count)
+		{
+			cerr << "Aborting denoising: m_useCuda = false (--use-cuda 0) requests the CPU/OpenMP path, which this build does not have; "
+					"set m_useCuda = true (the default) to run on the HIP device" << endl;
+			return false;
+		}
+		// Denoiser.cpp:121 writes the actual OpenMP thread count back.  The loop runs on the device; what the host contributes is one
+		// driver thread per scale and device
+		m_parameters.m_nbOfCores = i_nbOfScales * int(m_devices.size());
 
 		bcd_hip_params prm;
 		bcd_hip_default_params(&prm);
@@ -124,19 +153,36 @@ namespace bcd
 		int rc = BCD_HIP_OK;
 		if(m_devices.size() > 1)
 		{
+			// the prefilter of the band path: SpikeRemovalFilter::filter on copies of the inputs (one device, whole frame: the filter is
+			// 0.1 % of the work), like bcd_cli -p 1 does before denoise() (src/cli/main.cpp:428-441); the caller's images stay untouched
+			Deepimf filtered[4];
 			if(m_prefilterThresholdStDevFactor > 0.f)
 			{
-				cerr << "Aborting denoising: the device-side spike prefilter is only available on a single device (filter on the host first)" << endl;
-				return false;
+				filtered[0] = *m_inputs.m_pColors; filtered[1] = *m_inputs.m_pNbOfSamples;
+				filtered[2] = *m_inputs.m_pHistograms; filtered[3] = *m_inputs.m_pSampleCovariances;
+				if(!SpikeRemovalFilter::filterOnDevice(m_devices[0], filtered[0], filtered[1], filtered[2], filtered[3], m_prefilterThresholdStDevFactor))
+				{
+					cerr << "Aborting denoising: the spike prefilter failed on HIP device " << m_devices[0] << endl;
+					return false;
+				}
+				for(int i = 0; i < 4; ++i)
+					pIn[i] = filtered[i].getDataPtr();
 			}
 			if(!rSlot.m_pMulti && bcd_hip_multi_create(&rSlot.m_pMulti, m_devices.data(), int(m_devices.size())) != BCD_HIP_OK)
 			{
 				cerr << "Aborting denoising: unusable HIP device list (this build has no CPU path)" << endl;
 				return false;
 			}
+			bcd_hip_multi_set_progress_callback(rSlot.m_pMulti, &forwardProgress, &m_progressCallback);
 			rc = bcd_hip_multi_denoise_host(rSlot.m_pMulti, pIn[0], pIn[1], pIn[2], pIn[3], m_width, m_height, depth, i_nbOfScales, &prm, result.getDataPtr());
+			bcd_hip_multi_set_progress_callback(rSlot.m_pMulti, nullptr, nullptr);
 			if(rc != BCD_HIP_OK)
+			{
 				cerr << "Aborting denoising: " << bcd_hip_multi_last_error(rSlot.m_pMulti) << endl;
+				// a failed frame may have left device work or communicators in an unknown state: the next call starts from a new handle
+				bcd_hip_multi_destroy(rSlot.m_pMulti);
+				rSlot.m_pMulti = nullptr;
+			}
 			else if(m_zeroBadOutputValues)
 			{
 				float* p = result.getDataPtr();
@@ -159,7 +205,14 @@ namespace bcd
 			rc = bcd_hip_denoise_host_ex(rSlot.m_pCtx, pIn[0], pIn[1], pIn[2], pIn[3], m_width, m_height, depth, i_nbOfScales, &prm, &opt, result.getDataPtr());
 			bcd_hip_set_progress_callback(rSlot.m_pCtx, nullptr, nullptr);
 			if(rc != BCD_HIP_OK)
+			{
 				cerr << "Aborting denoising: " << bcd_hip_last_error(rSlot.m_pCtx) << endl;
+				if(rc == BCD_HIP_EDEVICE || rc == BCD_HIP_ENOMEM)
+				{	// device error / out of memory: give everything back, the next call builds a new context
+					bcd_hip_ctx_destroy(rSlot.m_pCtx);
+					rSlot.m_pCtx = nullptr;
+				}
+			}
 		}
 		if(rc != BCD_HIP_OK)
 			return false;

@@ -127,4 +127,23 @@ namespace bcd
 		return std::move(m_samplesStatisticsImages);
 	}
 
+	SamplesAccumulatorThreadSafe::SamplesAccumulatorThreadSafe(int i_width, int i_height, const HistogramParameters& i_rHistogramParameters) :
+			SamplesAccumulator(i_width, i_height, i_rHistogramParameters),
+			m_lockWidth(i_width),
+			m_pixelLocks(new std::atomic_flag[size_t(i_width) * size_t(i_height)])
+	{
+		for(size_t i = 0, n = size_t(i_width) * size_t(i_height); i < n; ++i)
+			m_pixelLocks[i].clear();
+	}
+
+	void SamplesAccumulatorThreadSafe::addSampleThreadSafely(int i_line, int i_column, float i_sampleR, float i_sampleG, float i_sampleB, float i_weight)
+	{
+		std::atomic_flag& rLock = m_pixelLocks[size_t(i_line) * size_t(m_lockWidth) + size_t(i_column)];
+		while(rLock.test_and_set(std::memory_order_acquire))
+		{	// another thread is inside addSample for this very pixel: a few dozen instructions, spin
+		}
+		addSample(i_line, i_column, i_sampleR, i_sampleG, i_sampleB, i_weight);
+		rLock.clear(std::memory_order_release);
+	}
+
 } // namespace bcd

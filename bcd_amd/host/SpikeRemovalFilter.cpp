@@ -18,13 +18,29 @@ namespace bcd
 			DeepImage<float>& io_rInputCovImage,
 			float i_thresholdStDevFactor)
 	{
+		// (the reference's signature has no way to report a failure; filterOnDevice has, and has already said why on cerr)
+		(void)filterOnDevice(0, io_rInputColorImage, io_rInputNbOfSamplesImage, io_rInputHistogramImage, io_rInputCovImage, i_thresholdStDevFactor);
+	}
+
+	bool SpikeRemovalFilter::filterOnDevice(
+			int i_device,
+			DeepImage<float>& io_rInputColorImage,
+			DeepImage<float>& io_rInputNbOfSamplesImage,
+			DeepImage<float>& io_rInputHistogramImage,
+			DeepImage<float>& io_rInputCovImage,
+			float i_thresholdStDevFactor)
+	{
 		const int w = io_rInputColorImage.getWidth(), h = io_rInputColorImage.getHeight(), d = io_rInputHistogramImage.getDepth();
 		bcd_hip_ctx* pCtx = nullptr;
-		if(bcd_hip_ctx_create(&pCtx, 0, nullptr) != BCD_HIP_OK)
+		if(bcd_hip_ctx_create(&pCtx, i_device, nullptr) != BCD_HIP_OK)
 		{
-			std::cerr << "SpikeRemovalFilter: no usable HIP device (this build has no CPU path); images left untouched" << std::endl;
-			return;
+			std::cerr << "SpikeRemovalFilter: NOT APPLIED -- no usable HIP device " << i_device << " (this build has no CPU path); images left untouched" << std::endl;
+			return false;
 		}
+		int previousDevice = -1;
+		if(hipGetDevice(&previousDevice) != hipSuccess)
+			previousDevice = -1;
+		(void)hipSetDevice(i_device);
 		DeepImage<float>* images[4] = { &io_rInputColorImage, &io_rInputNbOfSamplesImage, &io_rInputHistogramImage, &io_rInputCovImage };
 		float* in[4] = { nullptr, nullptr, nullptr, nullptr };
 		float* out[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -45,8 +61,11 @@ namespace bcd
 			if(in[i]) (void)hipFree(in[i]);
 			if(out[i]) (void)hipFree(out[i]);
 		}
+		if(previousDevice >= 0)
+			(void)hipSetDevice(previousDevice);
 		if(!ok)
 			std::cerr << "SpikeRemovalFilter: device error, images may be partially filtered" << std::endl;
+		return ok;
 	}
 
 } // namespace bcd

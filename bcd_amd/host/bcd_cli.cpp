@@ -2,7 +2,8 @@
 // (src/cli/main.cpp:122-504 of the reference): -o -i -h -c -d -b -w -r -p --p-factor -m -s --ncores --use-cuda -e.
 // Real defaults are -r 1 and -p 1 (main.cpp:52-53) although the reference's README says 0.  Missing -h / -c are
 // inferred as <input>_hist.exr / <input>_cov.exr (:344-370).  Extra flags of this build: --seed <n> (visiting
-// order), --device <n>.  --ncores and --use-cuda are accepted and ignored (the loop runs on the HIP device).
+// order), --device <n>.  --ncores is accepted and ignored (the loop runs on the HIP device); --use-cuda 0 (a request for the CPU path this
+// build does not have) is refused with an error, never answered by silently running something else.
 // -a <file.bcd.json> (advertised but never parsed by the reference, main.cpp:107) loads a preset; later flags override it.
 #include "Chronometer.h"
 #include "DeepImage.h"
@@ -70,7 +71,7 @@ namespace
 		cout << "    -m <float in [0,1]>  Probability of skipping marked centers of denoised patches (default: " << d.m_markedPixelsSkippingProbability << ")" << endl;
 		cout << "    -s <int>             Number of Scales for Multi-Scaling (default: " << d.m_nbOfScales << ")" << endl;
 		cout << "    --ncores <n>         accepted for compatibility, ignored" << endl;
-		cout << "    --use-cuda <0/1>     accepted for compatibility, ignored (always runs on the HIP device)" << endl;
+		cout << "    --use-cuda <0/1>     1 (default): run on the HIP device; 0 asks for the CPU path, which this build does not have: the run is refused" << endl;
 		cout << "    -e <float>           Minimum eigen value for matrix inversion (default: " << d.m_minEigenValue << ")" << endl;
 		cout << "    --seed <int>         Seed of the random pixel order (default: " << d.m_orderSeed << ")" << endl;
 		cout << "    --device <int>       HIP device index (default: 0)" << endl;

@@ -45,14 +45,54 @@ int bcdcore_accumulate(const float* s, long long n, int W, int H, int nbins, flo
 	return 0;
 }
 
+// the same through SamplesAccumulatorThreadSafe::addSampleThreadSafely from `threads` OpenMP threads that share the sample list
+// round-robin (so that threads do meet on the same pixel)
+int bcdcore_accumulate_threadsafe(const float* s, long long n, int W, int H, int nbins, float gamma, float maxval, int threads, float* ns, float* mean,
+		float* cov, float* hist)
+{
+	HistogramParameters hp;
+	hp.m_nbOfBins = nbins; hp.m_gamma = gamma; hp.m_maxValue = maxval;
+	SamplesAccumulatorThreadSafe acc(W, H, hp);
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+	for(long long i = 0; i < n; ++i)
+	{
+		const float* p = s + 6 * i;
+		acc.addSampleThreadSafely(int(p[0]), int(p[1]), p[2], p[3], p[4], p[5]);
+	}
+	SamplesStatisticsImages st = acc.getSamplesStatistics();
+	st.m_nbOfSamplesImage.copyDataTo(ns);
+	st.m_meanImage.copyDataTo(mean);
+	st.m_covarImage.copyDataTo(cov);
+	st.m_histoImage.copyDataTo(hist);
+	return 0;
+}
+
+void bcdcore_release_engines() { releaseEngines(); }
+
 // runs bcd::Denoiser (nscales == 1) or bcd::MultiscaleDenoiser through the IDenoiser interface; returns denoise()'s bool.
 // Null pointers are forwarded as null images to exercise the validation path.
 static int g_lastProgressValues = 0;
 /// number of distinct progress values the last bcdcore_denoise reported
 int bcdcore_last_progress_values() { return g_lastProgressValues; }
 
+static int g_lastNbOfCores = 0;
+/// m_nbOfCores as the last bcdcore_denoise* left it in the denoiser's parameters (Denoiser.cpp:121 writes it back)
+int bcdcore_last_nb_of_cores() { return g_lastNbOfCores; }
+
+int bcdcore_denoise_ex(const float* col, const float* ns, const float* hist, const float* cov, int W, int H, int D, int nscales,
+		float tau, int w, int b, float minEig, int randomOrder, float skipProbability, unsigned seed, float* out, int histWidthOverride,
+		int useCuda, const int* devices, int nbOfDevices, float prefilterFactor);
+
 int bcdcore_denoise(const float* col, const float* ns, const float* hist, const float* cov, int W, int H, int D, int nscales,
 		float tau, int w, int b, float minEig, int randomOrder, float skipProbability, unsigned seed, float* out, int histWidthOverride)
+{
+	return bcdcore_denoise_ex(col, ns, hist, cov, W, H, D, nscales, tau, w, b, minEig, randomOrder, skipProbability, seed, out, histWidthOverride, 1, nullptr, 0, 0.f);
+}
+
+/// + DenoiserParameters::m_useCuda, HipEngineSettings::setDevices / setSpikePrefilter
+int bcdcore_denoise_ex(const float* col, const float* ns, const float* hist, const float* cov, int W, int H, int D, int nscales,
+		float tau, int w, int b, float minEig, int randomOrder, float skipProbability, unsigned seed, float* out, int histWidthOverride,
+		int useCuda, const int* devices, int nbOfDevices, float prefilterFactor)
 {
 	Deepimf cImg, nImg, hImg, vImg, oImg(W > 0 ? W : 0, H > 0 ? H : 0, 3);
 	DenoiserInputs in;
@@ -66,9 +106,15 @@ int bcdcore_denoise(const float* col, const float* ns, const float* hist, const 
 	DenoiserParameters p;
 	p.m_histogramDistanceThreshold = tau; p.m_patchRadius = w; p.m_searchWindowRadius = b; p.m_minEigenValue = minEig;
 	p.m_useRandomPixelOrder = randomOrder != 0; p.m_markedPixelsSkippingProbability = skipProbability;
+	p.m_useCuda = useCuda != 0;
 	std::unique_ptr<IDenoiser> d;
-	if(nscales > 1) { MultiscaleDenoiser* m = new MultiscaleDenoiser(nscales); m->setOrderSeed(seed); d.reset(m); }
-	else { Denoiser* m = new Denoiser(); m->setOrderSeed(seed); d.reset(m); }
+	HipEngineSettings* pSettings = nullptr;
+	if(nscales > 1) { MultiscaleDenoiser* m = new MultiscaleDenoiser(nscales); pSettings = m; d.reset(m); }
+	else { Denoiser* m = new Denoiser(); pSettings = m; d.reset(m); }
+	pSettings->setOrderSeed(seed);
+	if(devices && nbOfDevices > 0)
+		pSettings->setDevices(std::vector<int>(devices, devices + nbOfDevices));
+	pSettings->setSpikePrefilter(prefilterFactor);
 	IDenoiser* pDenoiser = d.get();
 	pDenoiser->setInputs(in);
 	pDenoiser->setOutputs(o);
@@ -80,6 +126,7 @@ int bcdcore_denoise(const float* col, const float* ns, const float* hist, const 
 	const bool ok = pDenoiser->denoise();
 	if(ok && out) oImg.copyDataTo(out);
 	g_lastProgressValues = distinct;
+	g_lastNbOfCores = pDenoiser->getParameters().m_nbOfCores;
 	return ok ? (monotone ? 1 : 2) : 0;
 }
 

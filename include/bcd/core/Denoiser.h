@@ -40,6 +40,12 @@ namespace bcd
 		bool m_zeroBadOutputValues;
 	};
 
+	/// The engine contexts behind denoise() (device workspaces, pyramids, staging buffers: grow-only, sized by the largest frame seen,
+	/// one set per device / device list) live until the process ends so that a sequence of frames pays for them once.  A long-lived
+	/// host application calls this to give the device memory back; the next denoise() builds what it needs again.  Thread safe; waits
+	/// for calls in flight.
+	void releaseEngines();
+
 	class Denoiser : public IDenoiser, public HipEngineSettings
 	{
 	public:

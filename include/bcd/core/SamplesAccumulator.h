@@ -5,6 +5,9 @@
 
 #include "DeepImage.h"
 
+#include <atomic>
+#include <memory>
+
 namespace bcd
 {
 
@@ -51,6 +54,22 @@ namespace bcd
 		SamplesStatisticsImages m_samplesStatisticsImages;
 		DeepImage<float> m_squaredWeightSumsImage;
 		bool m_isValid;
+	};
+
+	/// Accumulator that several render threads may feed at once (declared by the reference, include/bcd/core/SamplesAccumulator.h:82-97,
+	/// whose constructor is never defined and whose addSampleThreadSafely takes no lock, src/core/SamplesAccumulator.cpp:156-165).
+	/// Here: one spin flag per pixel, held for the duration of one addSample; samples of different pixels never contend.  The
+	/// statistics of a pixel depend on the order its samples arrive in only through fp32 rounding.
+	class SamplesAccumulatorThreadSafe : public SamplesAccumulator
+	{
+	public:
+		SamplesAccumulatorThreadSafe(int i_width, int i_height, const HistogramParameters& i_rHistogramParameters);
+
+		void addSampleThreadSafely(int i_line, int i_column, float i_sampleR, float i_sampleG, float i_sampleB, float i_weight = 1.f);
+
+	private:
+		int m_lockWidth;
+		std::unique_ptr< std::atomic_flag[] > m_pixelLocks;
 	};
 
 } // namespace bcd

@@ -19,6 +19,16 @@ namespace bcd
 				DeepImage<float>& io_rInputHistogramImage,
 				DeepImage<float>& io_rInputCovImage,
 				float i_thresholdStDevFactor = 2.f);
+
+		/// the same on a chosen HIP device, with a result: false = no usable device or a device error (the images are then
+		/// unchanged or partially filtered, and a message is on cerr).  filter() is this on device 0 with the reference's void signature
+		static bool filterOnDevice(
+				int i_device,
+				DeepImage<float>& io_rInputColorImage,
+				DeepImage<float>& io_rInputNbOfSamplesImage,
+				DeepImage<float>& io_rInputHistogramImage,
+				DeepImage<float>& io_rInputCovImage,
+				float i_thresholdStDevFactor = 2.f);
 	};
 
 } // namespace bcd

@@ -84,9 +84,10 @@ int  bcd_hip_set_profiling(bcd_hip_ctx *ctx, int enabled);
 /* multiscale runs drive the (independent) scales concurrently, one HIP stream + host thread each (default on; also
  * disabled by BCD_HIP_SERIAL_SCALES=1).  Results are identical either way. */
 int  bcd_hip_set_concurrent_scales(bcd_hip_ctx *ctx, int enabled);
-/* similar-patch selection through approximate pair-distance planes with an exact re-evaluation of every pair within
- * tau (1 +- 2^-14) (default on for w = 1 and D in {24, 36, 60}; also disabled by BCD_HIP_EXACT_SIMILARITY=1).  The masks are
- * bit-identical either way; 0 forces the exact kernels. */
+/* similar-patch selection through approximate pair-distance planes (binary16 T plane, exact bin counts) with an exact
+ * re-evaluation of every pair within tau (1 +- 2^-10) (BCD_APPROX_DELTA; the approximate distance is within 5e-4 of the exact one).
+ * Default on for w = 1, D in {24, 36, 60} and tau in [2^-6, 64] -- other settings take the exact kernels; also disabled by
+ * BCD_HIP_EXACT_SIMILARITY=1.  The masks are bit-identical either way; 0 forces the exact kernels. */
 int  bcd_hip_set_fast_similarity(bcd_hip_ctx *ctx, int enabled);
 /* share (1..100 %, default 100) of the device's CU slots the persistent estimate kernels of this context occupy.  A caller that
  * runs several contexts on one device at once lowers it for the contexts that have slack, so that the short kernels of the one on
@@ -146,6 +147,15 @@ int  bcd_hip_multi_create(bcd_hip_multi **m, const int *devices, int n_ranks);
 void bcd_hip_multi_destroy(bcd_hip_multi *m);
 const char *bcd_hip_multi_last_error(const bcd_hip_multi *m);
 int  bcd_hip_multi_get_stats(const bcd_hip_multi *m, bcd_hip_multi_stats *out);
+/* IDenoiser::setProgressCallback for the multi-device path: every (rank, scale) reports its owned pixels when its processed set
+ * is known and when its estimate is complete; calls are serialised and monotone, the last value is 1 */
+int  bcd_hip_multi_set_progress_callback(bcd_hip_multi *m, bcd_hip_progress_fn fn, void *user);
+/* Failures.  A call that returns an error leaves the handle usable for the next frame: barriers, gates and the error state are
+ * reset on entry.  On the RCCL transport the first failure of a frame aborts the local communicators (ncclCommAbort -- peers blocked
+ * in a send / receive / all-reduce are released instead of waiting for ever), and a frame that has not finished after
+ * BCD_HIP_MULTI_TIMEOUT_S seconds (default 600; 0 = never) is failed the same way, which is what ends a frame whose peer process
+ * died.  bcd_hip_multi_create handles rebuild their communicators on the next call; a bcd_hip_multi_create_rank handle (one process
+ * per GPU) must be destroyed and created again from fresh unique ids by all processes. */
 /* Communication trace of the last frame (debugging / tests): per rank, in the order the rank ENQUEUED them, four values per
  * operation: channel (scale, or nb_scales for the merges), kind (0 = neighbour exchange, 1 = all-reduce), bytes exchanged with the
  * rank above, bytes exchanged with the rank below.  All ranks must show the same (channel, kind) sequence and neighbours the same
@@ -266,7 +276,8 @@ int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, con
 
 /* self-test of the approximate pair-distance kernel (k_pairdist_rw) on given inputs: *max_rel_dev = largest relative deviation of a
  * patch distance d(p, p + delta) computed from the approximate planes from the one computed from the exact planes, over all pairs of
- * main pixels (must stay far below 2^-14, the half-width of the band that is re-evaluated exactly); *count_mismatches = pairs whose
+ * main pixels (bound 5e-4, measured 2.4e-4; must stay below 2^-10 = 9.8e-4, BCD_APPROX_DELTA, the half-width of the band that is
+ * re-evaluated exactly); *count_mismatches = pairs whose
  * integer bin counts differ (must be 0); *flags as *variant above */
 int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius,
                                      float *max_rel_dev, int64_t *count_mismatches, int *flags);

@@ -524,6 +524,75 @@ static void denoise_patch_and_similar(Unit *u, int pl, int pc, float skip_prob, 
     aggregate(u);
 }
 
+static int check_inputs(const float *a, const float *b, const float *c, const float *d, int W, int H, int D, const BcdoParams *prm);
+
+/* ---- one-patch trace (fixture F3): every intermediate of denoiseSelectedPatches (:388-453) for ONE main pixel, so
+ * that a regression of a single stage is localised instead of showing up only in a whole-frame norm.  Same calls as step1 / step2
+ * above, with copies taken between them.  Returns |S| (>= 0), or -1 for bad arguments; when |S| < 3P + 1 (the fallback case) only
+ * members, x and mean1 (= the fallback estimate of :455-481) are filled. */
+int bcdo_patch_trace(const float *colors, const float *nsamp, const float *hist, const float *cov, int W, int H, int D,
+                     const BcdoParams *prm, int pl, int pc, BcdoPatchTrace *t)
+{
+    if (check_inputs(colors, nsamp, hist, cov, W, H, D, prm) || !t) return -1;
+    int w = prm->patch_radius;
+    if (pl < w || pl > H - 1 - w || pc < w || pc > W - 1 - w) return -1;
+    size_t npix = (size_t)W * H;
+    float *pixcov = (float *)malloc(sizeof(float) * npix * 6);
+    bcdo_pixel_cov_from_sample_cov(cov, nsamp, W, H, pixcov);
+    float *sum = (float *)calloc(npix * 3, sizeof(float));
+    int32_t *cnt = (int32_t *)calloc(npix, sizeof(int32_t));
+    uint8_t *marked = (uint8_t *)calloc(npix, 1);
+    Unit u;
+    unit_init(&u, W, H, D, prm, colors, nsamp, hist, pixcov, sum, cnt, marked);
+    select_similar(&u, pl, pc);
+    const int K = u.K, n = u.nS;
+    const size_t kk = sizeof(float) * K * K, nk = sizeof(float) * (size_t)n * K;
+    if (t->members) for (int i = 0; i < n; ++i) t->members[i] = u.sl[i] * W + u.sc[i];
+    if (n < K + 1) {
+        /* denoiseOnlyMainPatch (:455-481): the estimate is the plain mean of the similar patches */
+        pick_color_patches(&u);
+        if (t->x && n > 0) memcpy(t->x, u.X, nk);
+        if (t->mean1 && n > 0) empirical_mean(t->mean1, u.X, n, K);
+    } else {
+        noise_cov_patches_mean(&u);
+        if (t->noise) memcpy(t->noise, u.noise, sizeof(float) * u.P * 6);
+        /* Step 1 (:421-436) */
+        pick_color_patches(&u);
+        if (t->x) memcpy(t->x, u.X, nk);
+        empirical_mean(u.mean, u.X, n, K);
+        if (t->mean1) memcpy(t->mean1, u.mean, sizeof(float) * K);
+        center_cloud(u.Xc, u.mean, u.X, n, K);
+        empirical_cov(u.C, u.Xc, n, K);
+        if (t->cov1) memcpy(t->cov1, u.C, kk);
+        add_noise_blocks(u.C, u.noise, u.P, K, -1.f);
+        if (t->cov1_minus_noise) memcpy(t->cov1_minus_noise, u.C, kk);
+        spectral_map(&u, u.Cl, u.C, 0);
+        if (t->clamped) memcpy(t->clamped, u.Cl, kk);
+        add_noise_blocks(u.Cl, u.noise, u.P, K, +1.f);
+        if (t->clamped_plus_noise) memcpy(t->clamped_plus_noise, u.Cl, kk);
+        spectral_map(&u, u.Ci, u.Cl, 1);
+        if (t->inverse1) memcpy(t->inverse1, u.Ci, kk);
+        final_multiplication(&u, u.Xd, u.X, u.Ci, u.Xc);
+        if (t->step1) memcpy(t->step1, u.Xd, nk);
+        /* Step 2 (:438-453) */
+        empirical_mean(u.mean, u.Xd, n, K);
+        if (t->mean2) memcpy(t->mean2, u.mean, sizeof(float) * K);
+        center_cloud(u.Xc, u.mean, u.Xd, n, K);
+        empirical_cov(u.C, u.Xc, n, K);
+        if (t->cov2) memcpy(t->cov2, u.C, kk);
+        memcpy(u.Cl, u.C, kk);
+        add_noise_blocks(u.Cl, u.noise, u.P, K, +1.f);
+        spectral_map(&u, u.Ci, u.Cl, 1);
+        if (t->inverse2) memcpy(t->inverse2, u.Ci, kk);
+        center_cloud(u.Xc, u.mean, u.X, n, K);
+        final_multiplication(&u, u.Xd, u.X, u.Ci, u.Xc);
+        if (t->step2) memcpy(t->step2, u.Xd, nk);
+    }
+    unit_free(&u);
+    free(pixcov); free(sum); free(cnt); free(marked);
+    return n;
+}
+
 /* a16 finalAggregation tail (src/core/Denoiser.cpp:458-469) */
 static void final_divide(const float *sum, const int32_t *cnt, size_t npix, float *out)
 {

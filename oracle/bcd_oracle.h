@@ -79,6 +79,28 @@ int bcdo_denoise_mono(const float *colors, const float *nsamp, const float *hist
                       const int32_t *order, int64_t n_order,
                       float *out, const BcdoDiag *diag);
 
+/* ---- one-patch trace (SURVEY.md 8c fixture F3): the intermediates of denoiseSelectedPatches (DenoisingUnit.cpp:388-453) for one
+ * main pixel.  K = 3 (2w+1)^2; every pointer is optional (NULL = not wanted).  Matrices K x K row-major, patch arrays |S| x K in
+ * window order (:196-219), vectors pixel-major RGB (:483-498). ---- */
+typedef struct BcdoPatchTrace {
+    int32_t *members;          /* |S| linear indices line*W+col, capacity (2b+1)^2                               */
+    float *noise;              /* (2w+1)^2 x 6   computeNoiseCovPatchesMean (:400-419), order xx,yy,zz,yz,xz,xy  */
+    float *x;                  /* |S| x K        noisy patches (:483-498)                                        */
+    float *mean1;              /* K              empiricalMean of x (:500-509); the whole estimate when |S| < K+1 */
+    float *cov1;               /* K x K          empiricalCovarianceMatrix (:522-536)                            */
+    float *cov1_minus_noise;   /* K x K          substractCovMatPatchFromMatrix (:558-576)                       */
+    float *clamped;            /* K x K          clampNegativeEigenValues (:606-630)                             */
+    float *clamped_plus_noise; /* K x K          addCovMatPatchToMatrix (:538-556)                               */
+    float *inverse1;           /* K x K          inverseSymmetricMatrix (:578-604)                               */
+    float *step1;              /* |S| x K        finalDenoisingMatrixMultiplication (:656-670)                   */
+    float *mean2;              /* K              mean of the Step-1 estimates (:440)                             */
+    float *cov2;               /* K x K          their covariance (:441-442)                                     */
+    float *inverse2;           /* K x K          inverse of cov2 + noise (:445-446)                              */
+    float *step2;              /* |S| x K        final estimates (:449-450)                                      */
+} BcdoPatchTrace;
+int bcdo_patch_trace(const float *colors, const float *nsamp, const float *hist, const float *cov, int W, int H, int D,
+                     const BcdoParams *prm, int pl, int pc, BcdoPatchTrace *trace);
+
 /* band form for the multi-GPU tests: main pixels on lines [row_begin,row_end), raw accumulators (zeroed here) */
 int bcdo_accumulate_band(const float *colors, const float *nsamp, const float *hist, const float *cov,
                          int W, int H, int D, const BcdoParams *prm, int row_begin, int row_end,

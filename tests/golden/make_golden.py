@@ -6,6 +6,9 @@
                 CovarianceMatrix,MultiscaleDenoiser}.cpp): samples accumulator, pyramid reducers, interpolate, merge,
                 spike filter, histogram/sample-count packing.  These pin the oracle (and, on the GPU box where
                 /root/reference does not exist, the HIP kernels) to the reference bit for bit.
+  core_patch_trace.npz  (`make_golden.py trace`) SURVEY 8c fixture F3: every intermediate of the two Bayesian steps (noise mean, mean, C,
+                C - N, clamped, + N, inverse, Step-1 estimates, Step-2 mean / covariance / inverse / estimates) for three full-estimate
+                pixels (smallest, median and largest similar set) and one fallback pixel of the core_regression frame, by the ORACLE.
   core_*.npz    regression vectors of the Eigen-dependent core (distances, similar sets, processed sets, denoised
                 frames) computed by the ORACLE itself: the reference core cannot be built here (no Eigen), so these
                 are "parity unpinned" snapshots that guard against drift, not reference outputs.
@@ -73,5 +76,32 @@ def main():
     print("fixtures written to", HERE)
 
 
+def trace_pixels(nsim):
+    """three full-estimate pixels (smallest / median / largest similar set) + one fallback pixel of the regression frame"""
+    H, W = nsim.shape
+    strong = [(int(nsim[l, c]), l, c) for l in range(1, H - 1) for c in range(1, W - 1) if nsim[l, c] >= 28]
+    strong.sort()
+    weak = [(l, c) for l in range(1, H - 1) for c in range(1, W - 1) if 0 < nsim[l, c] < 28]
+    picks = [strong[0][1:], strong[len(strong) // 2][1:], strong[-1][1:], weak[len(weak) // 2]]
+    return [(int(l), int(c)) for (l, c) in picks]
+
+
+def make_trace():
+    f = np.load(os.path.join(HERE, "core_regression.npz"))
+    col, ns, hist, cov = f["col"], f["ns"], f["hist"], f["cov"]
+    _, cnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
+    pts = trace_pixels(cnt)
+    out = {"pts": np.array(pts, np.int32)}
+    for i, (l, c) in enumerate(pts):
+        t = ol.patch_trace(col, ns, hist, cov, ol.params(m=0.0), l, c)
+        for k, v in t.items():
+            out["p%d_%s" % (i, k)] = v
+    np.savez_compressed(os.path.join(HERE, "core_patch_trace.npz"), **out)
+    print("trace fixture:", pts, [int(out["p%d_members" % i].size) for i in range(len(pts))])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "trace":
+        make_trace()
+    else:
+        main()

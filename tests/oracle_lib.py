@@ -46,12 +46,21 @@ def oracle():
     return _oracle
 
 
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libbcd_ref.so")
+
+
+def ref_available():
+    """is the compiled reference present?  (a file test: nothing is loaded -- test modules call this at import time, and the GPU
+    box must not map the compiled reference units just because a test file was collected)"""
+    return os.path.exists(REF_SO)
+
+
 def ref():
-    """compiled reference TUs; None when oracle/_ref is absent (e.g. never built)."""
+    """compiled reference TUs; None when oracle/_ref is absent (e.g. never built).  Loaded on first CALL only; used by the CPU
+    tests that pin the oracle and by tests/golden/make_golden.py, never by a GPU test."""
     global _ref
-    so = os.path.join(ORACLE_DIR, "_ref", "libbcd_ref.so")
-    if _ref is None and os.path.exists(so):
-        _ref = C.CDLL(so)
+    if _ref is None and os.path.exists(REF_SO):
+        _ref = C.CDLL(REF_SO)
     return _ref
 
 
@@ -90,6 +99,32 @@ def denoise_multiscale(col, ns, hist, cov, nscales, prm, orders=None, racy=False
     rc = oracle().bcdo_denoise_multiscale(_fp(col), _fp(ns), _fp(hist), _fp(cov), W, H, D, nscales, C.byref(prm),
                                           po, pn, _fp(out), 1 if racy else 0)
     assert rc == 0, rc
+    return out
+
+
+TRACE_FIELDS = ("noise", "x", "mean1", "cov1", "cov1_minus_noise", "clamped", "clamped_plus_noise", "inverse1", "step1", "mean2", "cov2",
+                "inverse2", "step2")
+
+
+class BcdoPatchTrace(C.Structure):
+    _fields_ = [("members", C.POINTER(C.c_int32))] + [(k, _FP) for k in TRACE_FIELDS]
+
+
+def patch_trace(col, ns, hist, cov, prm, pl, pc):
+    """every intermediate of the two Bayesian steps for the main pixel (pl, pc): dict of arrays (SURVEY 8c fixture F3)"""
+    H, W, D = hist.shape
+    K = 3 * (2 * prm.patch_radius + 1) ** 2
+    P = K // 3
+    cap = (2 * prm.search_radius + 1) ** 2
+    shapes = dict(noise=(P, 6), x=(cap, K), mean1=(K,), cov1=(K, K), cov1_minus_noise=(K, K), clamped=(K, K), clamped_plus_noise=(K, K),
+                  inverse1=(K, K), step1=(cap, K), mean2=(K,), cov2=(K, K), inverse2=(K, K), step2=(cap, K))
+    arrs = {k: np.zeros(shapes[k], np.float32) for k in TRACE_FIELDS}
+    members = np.zeros(cap, np.int32)
+    t = BcdoPatchTrace(members.ctypes.data_as(C.POINTER(C.c_int32)), *[_fp(arrs[k]) for k in TRACE_FIELDS])
+    n = oracle().bcdo_patch_trace(_fp(col), _fp(ns), _fp(hist), _fp(cov), W, H, D, C.byref(prm), int(pl), int(pc), C.byref(t))
+    assert n >= 0, n
+    out = {k: (v[:n] if shapes[k][0] == cap else v) for k, v in arrs.items()}
+    out["members"] = members[:n]
     return out
 
 

@@ -781,6 +781,26 @@ def test_native_multi_rank_driver_equals_single_gpu(hipctx, W, H, S, ranks, m, r
     assert st.n_ranks == ranks and st.transport == 0 and st.compute_ms > 0
     assert rel_linf(got, want) < 1e-5
     assert rel_linf(again, want) < 1e-5
+    # ... and the ORACLE's frame: the band path is checked against the CPU restatement of the reference, not only against the
+    # single-GPU HIP path (same explicit visiting order per scale; -m 0 is order-free)
+    oracle_frame = _oracle_frame(("scene", W, H, 16, 21, 0.12, 0.005), (col, ns, hist, cov), S, b, m, random_order, 9)
+    assert rel_linf(got, oracle_frame) < TOL
+
+
+_oracle_frames = {}
+
+
+def _oracle_frame(key, frame, S, b, m, random_order, seed, min_eig=1e-8):
+    """oracle result of one configuration (cached: several rank counts share it)"""
+    col, ns, hist, cov = frame
+    H, W, _ = hist.shape
+    k = (key, S, b, m, random_order, seed, min_eig)
+    if k not in _oracle_frames:
+        op = ol.params(b=b, m=m, min_eig=min_eig, skip_seed=seed)
+        orders = _orders(W, H, 1, random_order, seed, S) if m != 0.0 else None
+        _oracle_frames[k] = (ol.denoise_multiscale(col, ns, hist, cov, S, op, orders=orders) if S > 1 else
+                             ol.denoise_mono(col, ns, hist, cov, op, order=None if orders is None else orders[0]))
+    return _oracle_frames[k]
 
 
 @pytest.mark.gpu
@@ -998,9 +1018,10 @@ def test_one_process_per_gpu_rank_api_with_one_rank(hipctx):
 
 @pytest.mark.gpu
 def test_bcd_cli_baseline_config0_plumbing(hipctx, tmp_path):
-    """BASELINE configs[0] as far as this build goes: `bcd_cli -s 1 -b 6 -w 1 --use-cuda 0 --ncores 1 -r 0` on a 128 x 96 scene (the
-    reference bundles none: data/inputs holds a .gitignore only).  There is no CPU path -- the flag is answered with a note and the
-    HIP device runs -- but the RESULT is the CPU path's: the oracle's single-thread scanline run on the same (half-precision) colours"""
+    """BASELINE configs[0] as far as this build goes: `bcd_cli -s 1 -b 6 -w 1 --ncores 1 -r 0` on a 128 x 96 scene (the reference
+    bundles none: data/inputs holds a .gitignore only).  There is no CPU path: `--use-cuda 0` is REFUSED (exit code 2, message), never
+    silently answered by the device; without it the HIP device runs and the RESULT is the CPU path's -- the oracle's single-thread
+    scanline run on the same (half-precision) colours"""
     import subprocess
     import bcd_amd.core as core
     W, H = 128, 96
@@ -1011,12 +1032,182 @@ def test_bcd_cli_baseline_config0_plumbing(hipctx, tmp_path):
     core.write_exr(stem + "_cov.exr", cov, True)
     exe = _os.path.join(_os.path.dirname(core.LIB_PATH), "bcd_cli")
     out_path = str(tmp_path / "out.exr")
-    r = subprocess.run([exe, "-i", stem + ".exr", "-h", stem + "_hist.exr", "-c", stem + "_cov.exr", "-o", out_path, "-s", "1", "-b", "6", "-w", "1",
-                        "-r", "0", "-p", "0", "-m", "1", "--ncores", "1", "--use-cuda", "0"], capture_output=True, text=True)
+    flags = [exe, "-i", stem + ".exr", "-h", stem + "_hist.exr", "-c", stem + "_cov.exr", "-o", out_path, "-s", "1", "-b", "6", "-w", "1",
+             "-r", "0", "-p", "0", "-m", "1", "--ncores", "1"]
+    r = subprocess.run(flags + ["--use-cuda", "0"], capture_output=True, text=True)
+    assert r.returncode == 2 and "does not have" in r.stderr and not _os.path.exists(out_path)   # the CPU request is refused, loudly
+    r = subprocess.run(flags + ["--use-cuda", "1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "does not have" in r.stdout                                   # the CPU request is declined loudly, not silently
     got = core.read_exr(out_path, False)
     col_h = core.read_exr(stem + ".exr", False)                           # colours as the CLI saw them (half on disk)
     want = ol.denoise_mono(col_h, ns, hist, cov, ol.params(b=6, m=1.0, threads=1))   # 1 thread, -r 0: plain scanline order
     want = np.where(np.isfinite(want) & (want >= 0), want, 0.0).astype(np.float32)
     assert np.max(np.abs(got - want.astype(np.float16).astype(np.float32))) <= 2e-3 * np.max(want)
+
+
+# ---- BASELINE configs[3] and configs[4]: against the ORACLE at reduced size, by properties at full size ------------------------------
+@pytest.mark.gpu
+def test_config4_chain_single_gpu_against_the_oracle(hipctx):
+    """BASELINE configs[4]'s chain on one GPU against the oracle: spike prefilter (-p 1 --p-factor 2; the ORACLE's filter, which is
+    pinned to the reference's compiled unit) -> 3 scales, b = 12, random order (-r 1), -m 1 -- and the same with -m 0.  The HIP side
+    runs its own prefilter kernel inside bcd_hip_denoise_host_ex (what bcd_cli -p 1 uses)"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    W, H, S, b = 176, 232, 3, 12
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 5, 0.3, 0.02)
+    fc, fn, fh, fv = ol.oracle_ops()["spike"](col, ns, hist, cov, 2.0)
+    assert (fc != col).any()                                              # the filter does something on this frame
+    for m in (1.0, 0.0):
+        prm = bh.default_params(m=m, random_order=1, seed=77, b=b)
+        got = hipctx.denoise_host(col, ns, hist, cov, S, prm, spike_factor=2.0)
+        want = _oracle_frame(("config4", W, H), (fc, fn, fh, fv), S, b, m, 1, 77)
+        ok = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), ok)
+        assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+    assert hipctx.stats(0).similarity_path == 1                          # b = 12 went through the production similarity kernels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_config4_chain_row_bands_against_the_oracle(hipctx, ranks):
+    """the same chain through the row-band driver (prefilter on host copies by the C++ class, bands with b + w = 13 halo lines)
+    against the oracle"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    W, H, S, b = 176, 232, 3, 12
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 5, 0.3, 0.02)
+    fc, fn, fh, fv = ol.oracle_ops()["spike"](col, ns, hist, cov, 2.0)
+    prm = bh.default_params(m=1.0, random_order=1, seed=77, b=b)
+    md = bh.MultiDenoiser([0] * ranks)
+    try:
+        got = md.denoise_host(fc, fn, fh, fv, S, prm)
+    finally:
+        md.close()
+    want = _oracle_frame(("config4", W, H), (fc, fn, fh, fv), S, b, 1.0, 1, 77)
+    assert rel_linf(got, want) < TOL
+    # through bcd::MultiscaleDenoiser::setDevices + setSpikePrefilter (what bcd_cli --devices a,b -p 1 does)
+    ok, out, monotone = core.denoise(col, ns, hist, cov, nscales=S, b=b, m=1.0, seed=77, devices=[0] * ranks, prefilter_factor=2.0)
+    assert ok and monotone and rel_linf(out, want) < TOL
+    assert core.last_nb_of_cores() == S * ranks                           # host driver threads: one per scale and device
+    assert core.lib().bcdcore_last_progress_values() > 4                  # the multi-device path reports progress inside the loop
+
+
+def _mask_properties(hipctx, hist, ns, b, random_order, seed):
+    """(a) symmetric masks, counts = popcounts; (b) the processed set is the sequential greedy set of the visiting order"""
+    import torch
+    import bcd_amd.hip as bh
+    H, W, _ = hist.shape
+    mask, cnt = hipctx.similarity_masks(hist, ns, 1, b, 1.0)
+    state, rounds = hipctx.active_set(mask, cnt, 1, b, 1.0, random_order, seed)
+    side = 2 * b + 1
+    order = torch.from_numpy(bh.visit_order(W, H, 1, random_order, seed).astype(np.int64)).cuda()
+    rank = torch.full((H * W,), 1 << 40, dtype=torch.int64, device="cuda")
+    rank[order] = torch.arange(order.numel(), device="cuda")
+    rank = rank.view(H, W)
+    proc = state == 1
+    strong_in = proc & (cnt >= 28)
+    marked = torch.zeros((H, W), dtype=torch.bool, device="cuda")
+    pop = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    m = mask.view(H, W, -1)
+    for k in range(side * side):
+        dl, dc = k // side - b, k % side - b
+        bit = ((m[:, :, k // 32] >> (k % 32)) & 1).bool()
+        pop += bit.int()
+        kk = (b - dl) * side + (b - dc)
+        rbit = ((m[:, :, kk // 32] >> (kk % 32)) & 1).bool()
+        assert torch.equal(bit, _shift(rbit, dl, dc, False)), (dl, dc)
+        marked |= bit & _shift(strong_in, dl, dc, False) & (_shift(rank, dl, dc, 1 << 41) < rank)
+    assert torch.equal(pop, cnt)
+    main = state != 0
+    assert int(main.sum()) == (W - 2) * (H - 2)
+    assert torch.equal(proc, main & ~marked)
+    return rounds
+
+
+@pytest.mark.gpu
+def test_4k_config3_properties_and_eight_row_bands(hipctx):
+    """BASELINE configs[3] at its FULL size (3840 x 2160, 3 scales, b = 6): finite deterministic output that reduces the error, masks
+    symmetric and the processed set the sequential greedy set at scale 0, and the frame cut into EIGHT row bands (the 8-GPU
+    partition: 270 owned lines + 2 x 7 * 2^s halo lines per scale and rank, here as 8 ranks on one device) equal to the single-GPU
+    frame to 1e-5"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H, S = 3840, 2160, 3
+    col, ns, hist, cov = core.synthetic_scene(W, H, 8, 3, 0.15, 0.0)
+    prm = bh.default_params(seed=17)
+    d = dev(col, ns, hist, cov)
+    a = hipctx.denoise(*d, S, prm).cpu().numpy()
+    st = [(hipctx.stats(s).processed, hipctx.stats(s).fallback, hipctx.stats(s).similar_total) for s in range(S)]
+    assert np.isfinite(a).all()
+    assert np.array_equal(a, np.where(np.isfinite(a), a, 0)) and st[0][0] > 0 and st[0][0] > st[0][1] > 0
+    l, c = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([0.2 + 0.6 * c / W, 0.5 + 0.4 * np.sin(12.0 * l / H), np.where(((l // 16 + c // 16) % 2) > 0, 0.8, 0.15)], -1)
+    rmse = lambda x: float(np.sqrt(np.mean((x - base) ** 2)))
+    assert rmse(a) < 0.6 * rmse(col)
+    assert _mask_properties(hipctx, d[2], d[1], 6, 1, bh.scale_seed(17, 0)) >= 1
+    del d
+    md = bh.MultiDenoiser([0] * 8)
+    try:
+        got = md.denoise_host(col, ns, hist, cov, S, prm)
+    finally:
+        md.close()
+    assert rel_linf(got, a) < 1e-5
+
+
+@pytest.mark.gpu
+def test_4k_config4_large_window_prefilter_eight_row_bands(hipctx):
+    """BASELINE configs[4] at its FULL size (3840 x 2160, b = 12, -p 1 --p-factor 2, -r 1, 3 scales): finite output that reduces the
+    error, and eight row bands (13 * 2^s halo lines) equal to the single-GPU frame to 1e-5"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H, S, b = 3840, 2160, 3, 12
+    col, ns, hist, cov = core.synthetic_scene(W, H, 8, 3, 0.25, 0.01)
+    prm = bh.default_params(seed=23, b=b, random_order=1)
+    a = hipctx.denoise_host(col, ns, hist, cov, S, prm, spike_factor=2.0)
+    assert np.isfinite(a).all()
+    l, c = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([0.2 + 0.6 * c / W, 0.5 + 0.4 * np.sin(12.0 * l / H), np.where(((l // 16 + c // 16) % 2) > 0, 0.8, 0.15)], -1)
+    rmse = lambda x: float(np.sqrt(np.mean((x - base) ** 2)))
+    assert rmse(a) < 0.6 * rmse(col)
+    ok, out, _ = core.denoise(col, ns, hist, cov, nscales=S, b=b, m=1.0, seed=23, devices=[0] * 8, prefilter_factor=2.0)
+    assert ok and rel_linf(out, a) < 1e-5
+
+
+@pytest.mark.gpu
+def test_two_gpu_bench_exercises_the_rccl_transport():
+    """first box with two GPUs: `bench.py --gpus 2` under torch.distributed.run drives bcd_hip_multi_rank_* over RCCL (ncclCommInitRank,
+    grouped send / recv with the neighbour, the marking all-reduce) and asserts on rank 0 that the gathered frame equals the single-GPU
+    frame.  Skipped on one-GPU boxes (every other multi-rank test uses the in-process transport there)."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    env = dict(_os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", _os.path.join(root, "bench.py"), "--gpus", "2", "--no-extras", "--steps", "2", "--warmup", "1",
+                        "--watchdog", "300"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["parallelism"] == "rowband2-exactmark-native"
+    assert line["band_check"]["rel_linf_vs_single_gpu"] < 1e-5 and line["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_release_engines_gives_the_memory_back(hipctx):
+    """bcd::releaseEngines(): the cached engine contexts of libbcdcore (grow-only workspaces) are destroyed and rebuilt on demand"""
+    import torch
+    import bcd_amd.core as core
+    col, ns, hist, cov = core.synthetic_scene(640, 360, 8, 3, 0.2, 0.0)
+    ok, a, _ = core.denoise(col, ns, hist, cov, nscales=2, seed=3)
+    assert ok
+    torch.cuda.synchronize()
+    used = lambda: (lambda f, t: t - f)(*torch.cuda.mem_get_info())
+    before = used()
+    core.release_engines()
+    after = used()
+    assert before - after > 640 * 360 * 85 * 3          # at least the distance planes of scale 0 came back
+    ok, b_, _ = core.denoise(col, ns, hist, cov, nscales=2, seed=3)
+    assert ok and rel_linf(b_, a) < 1e-5

@@ -55,3 +55,28 @@ def test_denoiser_rejects_bad_inputs_like_the_reference():
     assert core.denoise(None, ns, hist, cov)[0] is False             # nullptr input (Denoiser.cpp:266-293)
     assert core.denoise(col, ns, hist, cov, hist_width_override=8)[0] is False  # size mismatch (:321-346)
     assert core.denoise(col[:0], ns[:0], hist[:0], cov[:0])[0] is False  # empty (:294-320)
+
+
+def test_explicit_cpu_request_is_refused_not_substituted(capfd):
+    """DenoiserParameters::m_useCuda = false selects the CPU/OpenMP loop in the reference (src/core/Denoiser.cpp:99-110,241-265).  This
+    library has one path, the HIP device: the request is answered with `false` and a message on cerr -- on any host, with or without a
+    GPU, and before any device work -- never by silently running something else (error table)"""
+    col, ns, hist, cov = core.synthetic_scene(16, 12, 2)
+    for nscales in (1, 2):
+        ok, out, _ = core.denoise(col, ns, hist, cov, nscales, use_cuda=False)
+        assert ok is False and not out.any()
+    assert "m_useCuda = false" in capfd.readouterr().err
+
+
+def test_samples_accumulator_thread_safe_variant():
+    """SamplesAccumulatorThreadSafe::addSampleThreadSafely (declared by the reference, include/bcd/core/SamplesAccumulator.h:82-97, but
+    left without a constructor and without a lock, src/core/SamplesAccumulator.cpp:156-165): 8 threads feeding the same pixels give the
+    sequential statistics up to the summation order of each pixel's samples"""
+    samples, _ = ol.synth_samples(9, 7, 64, seed=4, sigma=0.5, spike_prob=0.1)   # 64 samples per pixel, consecutive in the list:
+    a = core.accumulate(samples, 9, 7)                                           # threads (round-robin) meet on every pixel
+    b = core.accumulate_threadsafe(samples, 9, 7, threads=8)
+    assert same(a[0], b[0])                                                      # sample counts: integer-valued sums, exact
+    for x, y in zip(a[1:], b[1:]):
+        assert np.allclose(x, y, rtol=2e-5, atol=1e-6)
+    one = core.accumulate_threadsafe(samples, 9, 7, threads=1)
+    assert all(same(x, y) for x, y in zip(a, one))                               # one thread: the very same sequence

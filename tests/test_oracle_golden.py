@@ -47,7 +47,7 @@ def test_spike_filter_matches_reference_bits():
         assert same(g, f[k]), k
 
 
-@pytest.mark.skipif(ol.ref() is None, reason="oracle/_ref not built (needs /root/reference; authoring container only)")
+@pytest.mark.skipif(not ol.ref_available(), reason="oracle/_ref not built (needs /root/reference; authoring container only)")
 def test_oracle_equals_live_reference_units():
     """fresh seeded inputs through the compiled reference units and the oracle, bit for bit"""
     o, r = ol.oracle_ops(), ol.ref_ops()
@@ -198,3 +198,85 @@ def test_float64_numpy_restatement_of_the_bayesian_steps_agrees_with_the_oracle(
     assert (f["fallback"] > 0).any() and (f["nsim"] >= 28).any()         # both paths are exercised on this frame
     err = np.max(np.abs(got - want)) / np.max(np.abs(want))
     assert err < 1e-5, err
+
+
+def _np64_stages(col, ns, cov, members, W, min_eig=1e-8):
+    """float64 restatement of denoiseSelectedPatches written from /root/reference/src/core/DenoisingUnit.cpp:388-453,483-670 (not from
+    the oracle): every intermediate, numpy.linalg.eigh in place of Eigen's solver"""
+    col, ns, cov = col.astype(np.float64), ns.astype(np.float64), cov.astype(np.float64)
+    pixcov = cov * (1.0 / ns)                                            # Denoiser.cpp:357-373
+    offs = [(a, d) for a in (-1, 0, 1) for d in (-1, 0, 1)]
+    pos = [(int(m) // W, int(m) % W) for m in members]
+    X = np.stack([np.concatenate([col[l + a, c + d] for (a, d) in offs]) for (l, c) in pos])
+    n = len(pos)
+    st = {"x": X, "mean1": X.mean(axis=0)}
+    if n < 28:
+        return st
+    noise6 = np.zeros((9, 6))
+    for (l, c) in pos:
+        for o, (a, d) in enumerate(offs):
+            noise6[o] += pixcov[l + a, c + d]
+    noise6 /= n                                                          # :400-419
+    N = np.zeros((27, 27))
+    for o in range(9):
+        xx, yy, zz, yz, xz, xy = noise6[o]                               # CovarianceMatrix.h:18-27
+        N[3 * o:3 * o + 3, 3 * o:3 * o + 3] = [[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]
+
+    def spectral(M, fn):
+        lam, V = np.linalg.eigh(M)
+        return (V * fn(lam)) @ V.T
+
+    Xc = X - st["mean1"]
+    C = Xc.T @ Xc / (n - 1)                                              # :522-536
+    clamped = spectral(C - N, lambda lam: np.maximum(0.0, lam))          # :606-630
+    inv1 = spectral(clamped + N, lambda lam: 1.0 / np.maximum(min_eig, lam))   # :578-604
+    X1 = X - (N @ (inv1 @ Xc.T)).T                                       # :656-670
+    m2 = X1.mean(axis=0)
+    X1c = X1 - m2
+    C2 = X1c.T @ X1c / (n - 1)
+    inv2 = spectral(C2 + N, lambda lam: 1.0 / np.maximum(min_eig, lam))
+    X2 = X - (N @ (inv2 @ (X - m2).T)).T                                 # :449-450: the NOISY patches centred on the Step-2 mean
+    st.update(noise=noise6, cov1=C, cov1_minus_noise=C - N, clamped=clamped, clamped_plus_noise=clamped + N, inverse1=inv1, step1=X1,
+              mean2=m2, cov2=C2, inverse2=inv2, step2=X2)
+    return st
+
+
+# stage -> tolerance of the fp32 oracle against the float64 restatement, relative to the largest magnitude of the stage: about 5x the
+# measured deviation (noise 2.3e-7, mean1 2.0e-7, cov1 2.0e-7, C - N 2.3e-7, clamped 1.1e-6, inverse1 1.1e-5, step1 1.2e-6, mean2 2.8e-7,
+# cov2 1.1e-6, inverse2 1.4e-5, step2 2.0e-6).  The inverses carry the conditioning of (clamped + N).
+_STAGE_TOL = dict(noise=1e-6, x=0.0, mean1=1e-6, cov1=1e-6, cov1_minus_noise=1e-6, clamped=5e-6, clamped_plus_noise=5e-6, inverse1=6e-5,
+                  step1=6e-6, mean2=1.5e-6, cov2=5e-6, inverse2=7e-5, step2=1e-5)
+
+
+def test_one_patch_trace_fixture_and_stagewise_float64_cross_check():
+    """SURVEY 8c fixture F3.  (1) the oracle reproduces its committed one-patch traces (regression: a change of any stage of
+    oracle/bcd_oracle.c shows up AT that stage); (2) every stage agrees with the float64 NumPy restatement above, so a slip in one
+    stage of either reading is localised instead of being diluted in a whole-frame norm.  Three full-estimate pixels (|S| = 28, 46,
+    91) and one fallback pixel of the 40 x 28 regression frame."""
+    f, t = load("core_regression.npz"), load("core_patch_trace.npz")
+    col, ns, hist, cov = f["col"], f["ns"], f["hist"], f["cov"]
+    H, W, _ = col.shape
+    sizes = []
+    for i, (l, c) in enumerate(t["pts"]):
+        got = ol.patch_trace(col, ns, hist, cov, ol.params(m=0.0), int(l), int(c))
+        members = t["p%d_members" % i]
+        assert np.array_equal(got["members"], members)
+        assert np.array_equal(members, np.nonzero(np.unpackbits(f["mask"][l, c].view(np.uint8), bitorder="little")[:169])[0] // 13 * W
+                              + np.nonzero(np.unpackbits(f["mask"][l, c].view(np.uint8), bitorder="little")[:169])[0] % 13
+                              + (l - 6) * W + (c - 6))                     # window order of the similar set (:196-219)
+        sizes.append(members.size)
+        ref64 = _np64_stages(col, ns, cov, members, W)
+        for k in ol.TRACE_FIELDS:
+            want = t["p%d_%s" % (i, k)]
+            assert np.allclose(got[k], want, rtol=0, atol=1e-6 * max(1e-30, float(np.max(np.abs(want))))), (i, k)   # regression
+            if k in ref64:
+                scale = float(np.max(np.abs(ref64[k])))
+                err = float(np.max(np.abs(got[k].astype(np.float64) - ref64[k]))) / scale
+                assert err <= _STAGE_TOL[k], (i, k, err)
+            else:
+                assert members.size < 28 and not got[k].any()            # fallback pixel: the Bayesian stages are not run
+    assert sorted(sizes) == [7, 28, 46, 91]
+    # the traces are the frame: aggregating the Step-2 estimates / fallback means of EVERY main pixel gives out_m0 (checked on one pixel's
+    # contributions here: the final image test above covers the sum)
+    l, c = [int(v) for v in t["pts"][0]]
+    assert np.allclose(t["p0_step2"][list(t["p0_members"]).index(l * W + c)][12:15], f["out_m0"][l, c], atol=0.2)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# GPU box, round 3 call 1: full GPU test suite, low-noise probe, baseline bench, counter refresh of the shipped kernels
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q --durations=15 > gpurun_out/r3a_tests.log 2>&1
+echo "tests rc=$?" >> gpurun_out/r3a_tests.log
+timeout 300 python tools/dbg_lownoise.py > gpurun_out/r3a_lownoise.log 2>&1
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r3a_bench.log 2>&1
+S1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"
+S2="SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"
+S3="SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL"
+timeout 300 tools/pmc_any.sh r3_pd_s1 "$S1" pairdist_rw python tools/exp_similarity.py --quick > /dev/null 2>&1
+timeout 300 tools/pmc_any.sh r3_pd_s2 "$S2" pairdist_rw python tools/exp_similarity.py --quick > /dev/null 2>&1
+timeout 300 tools/pmc_any.sh r3_eig_s1 "$S1" jacobi27 python tools/exp_eig.py 32768 > /dev/null 2>&1
+timeout 300 tools/pmc_any.sh r3_eig_s2 "$S2" jacobi27 python tools/exp_eig.py 32768 > /dev/null 2>&1
+timeout 300 tools/pmc_any.sh r3_eig_s3 "$S3" jacobi27 python tools/exp_eig.py 32768 > /dev/null 2>&1
+export BCD_HIP_SERIAL_SCALES=1
+timeout 300 tools/pmc_any.sh r3_bay_s1 "$S1" bayes python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 300 tools/pmc_any.sh r3_bay_s2 "$S2" bayes python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 300 tools/pmc_any.sh r3_bay_s3 "$S3" bayes python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
+unset BCD_HIP_SERIAL_SCALES
+tail -5 gpurun_out/r3a_tests.log; tail -12 gpurun_out/r3a_lownoise.log; tail -c 600 gpurun_out/r3a_bench.log
