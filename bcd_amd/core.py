@@ -25,15 +25,16 @@ def _fp(a):
     return a.ctypes.data_as(_F)
 
 
-def synthetic_scene(W, H, spp=32, seed=1234, sigma=0.35, spike_prob=0.01, first_line=0, nb_lines=None):
-    """(colors, nsamples, histograms, covariances) of lines [first_line, first_line+nb_lines) of a W x H frame"""
+def synthetic_scene(W, H, spp=32, seed=1234, sigma=0.35, spike_prob=0.01, first_line=0, nb_lines=None, pattern=0):
+    """(colors, nsamples, histograms, covariances) of lines [first_line, first_line+nb_lines) of a W x H frame;
+    pattern 0 = ramps + 16-pixel checker (SURVEY 8d probe scene), 1 = band-limited texture with oblique soft edges"""
     n = H - first_line if nb_lines is None else nb_lines
     ns = np.empty((n, W, 1), np.float32)
     mean = np.empty((n, W, 3), np.float32)
     cov = np.empty((n, W, 6), np.float32)
     hist = np.empty((n, W, 60), np.float32)
-    rc = lib().bcdcore_synthetic_scene(W, H, spp, C.c_uint(seed), C.c_float(sigma), C.c_float(spike_prob), first_line, n,
-                                       _fp(ns), _fp(mean), _fp(cov), _fp(hist))
+    rc = lib().bcdcore_synthetic_scene_ex(W, H, spp, C.c_uint(seed), C.c_float(sigma), C.c_float(spike_prob), int(pattern), first_line, n,
+                                          _fp(ns), _fp(mean), _fp(cov), _fp(hist))
     if rc != 0:
         raise ValueError("bcdcore_synthetic_scene rc=%d" % rc)
     return mean, ns, hist, cov

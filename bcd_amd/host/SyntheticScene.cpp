@@ -31,8 +31,24 @@ namespace bcd
 			const int line = i_firstLine + localLine;
 			for(int column = 0; column < W; ++column)
 			{
-				const bool checker = ((line / 16 + column / 16) % 2) != 0;
-				const float base[3] = { 0.2f + 0.6f * float(column) / float(W), 0.5f + 0.4f * std::sin(12.f * float(line) / float(H)), checker ? 0.8f : 0.15f };
+				float base[3];
+				if(i_rParams.m_pattern == 1)
+				{
+					const float x = float(column), y = float(line);
+					// soft oblique edges: a smooth step across lines of slope ~ 0.37, every ~90 pixels
+					const float u = std::sin(0.0698f * (x * 0.9397f + y * 0.3420f));
+					const float edge = 0.5f + 0.5f * std::tanh(6.f * u);
+					base[0] = 0.45f + 0.25f * std::sin(0.11f * x + 0.05f * y) * std::cos(0.07f * y - 0.02f * x) + 0.12f * std::sin(0.31f * x - 0.23f * y);
+					base[1] = 0.50f + 0.30f * std::sin(0.045f * (x + y)) * std::sin(0.013f * (x - 2.f * y)) + 0.10f * edge;
+					base[2] = 0.20f + 0.55f * edge + 0.08f * std::cos(0.19f * x + 0.27f * y);
+				}
+				else
+				{
+					const bool checker = ((line / 16 + column / 16) % 2) != 0;
+					base[0] = 0.2f + 0.6f * float(column) / float(W);
+					base[1] = 0.5f + 0.4f * std::sin(12.f * float(line) / float(H));
+					base[2] = checker ? 0.8f : 0.15f;
+				}
 				for(int s = 0; s < i_rParams.m_samplesPerPixel; ++s)
 				{
 					uint64_t state = splitmix((uint64_t(i_rParams.m_seed) << 32) ^ (uint64_t(line) * uint64_t(W) + uint64_t(column)));

@@ -15,12 +15,22 @@ using namespace bcd;
 extern "C" {
 
 // W x i_nbOfLines band of a W x H synthetic frame; outputs: ns [n], mean [n*3], cov [n*6], hist [n*60]
+int bcdcore_synthetic_scene_ex(int W, int H, int spp, unsigned seed, float sigma, float spikeProbability, int pattern, int firstLine, int nbOfLines,
+		float* o_ns, float* o_mean, float* o_cov, float* o_hist);
+
 int bcdcore_synthetic_scene(int W, int H, int spp, unsigned seed, float sigma, float spikeProbability, int firstLine, int nbOfLines,
+		float* o_ns, float* o_mean, float* o_cov, float* o_hist)
+{
+	return bcdcore_synthetic_scene_ex(W, H, spp, seed, sigma, spikeProbability, 0, firstLine, nbOfLines, o_ns, o_mean, o_cov, o_hist);
+}
+
+int bcdcore_synthetic_scene_ex(int W, int H, int spp, unsigned seed, float sigma, float spikeProbability, int pattern, int firstLine, int nbOfLines,
 		float* o_ns, float* o_mean, float* o_cov, float* o_hist)
 {
 	if(W <= 0 || H <= 0 || spp <= 0 || firstLine < 0 || firstLine + nbOfLines > H) return -1;
 	SyntheticSceneParameters p;
 	p.m_width = W; p.m_height = H; p.m_samplesPerPixel = spp; p.m_seed = seed; p.m_noiseSigma = sigma; p.m_spikeProbability = spikeProbability;
+	p.m_pattern = pattern;
 	SamplesStatisticsImages st = generateSyntheticScene(p, firstLine, nbOfLines);
 	st.m_nbOfSamplesImage.copyDataTo(o_ns);
 	st.m_meanImage.copyDataTo(o_mean);

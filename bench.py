@@ -5,7 +5,8 @@ A "step" is one full denoise of one synthetic 1920x1080 frame (BASELINE.json con
 seeded random order): the pyramid build, and per scale the pair-distance / mask kernels, the marking fixed point, the
 Bayesian patch kernel, finalisation and merge.  Inputs are resident in HBM before the timed region.
 After the timed region (N = 1, untimed, skipped by --no-extras): the pair-distance kernel with the scales serialised
-(`roofline.isolated_*`), the low-noise variant of the frame (`low_noise`), the same frame with -m 0 (`m0`), the 3840x2160
+(`roofline.isolated_*`), the host-buffer call a drop-in user makes (`end_to_end`: PCIe both ways inside), the low-noise variant of
+the frame (`low_noise`), a textured frame whose similar sets depend on the noise (`textured`), the same frame with -m 0 (`m0`), the 3840x2160
 frame of BASELINE.json configs[3] (`frame_4k`; at N > 1 the same frame over the same row bands, measured before the timed
 region: the per-N points of the 4K strong-scaling curve) and of configs[4] (`frame_4k_b12_prefilter`, N = 1), and the CPU oracle on all host cores and on one core (`cpu_baseline`).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into horizontal bands of
@@ -55,8 +56,8 @@ def parse():
     ap.add_argument("--band-path", action="store_true", help="use the multi-GPU row-band code path even with one rank (debug)")
     ap.add_argument("--check-size", default="640x576", help="N > 1: frame size of the equality check against a single-GPU run on rank 0")
     ap.add_argument("--watchdog", type=int, default=900, help="N > 1: seconds after which a run that has not reached its JSON line dumps every thread's stack and exits (a blocked collective would otherwise hang the launcher)")
-    ap.add_argument("--cpu-sample", default="960x540", help="frame size of the bounded CPU-baseline sample (all host cores)")
-    ap.add_argument("--cpu-sample-1core", default="160x90", help="frame size of the one-core CPU-baseline sample")
+    ap.add_argument("--cpu-sample", default=None, help="frame size of the CPU-baseline sample on all host cores (default: the headline frame itself on hosts with >= 64 cores, 960x540 below)")
+    ap.add_argument("--cpu-sample-1core", default="320x240", help="frame size of the one-core CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -80,14 +81,17 @@ def cpu_baseline(args):
             best = dt if best is None else min(best, dt)
         return w, h, best
 
-    w, h, best = run(args.cpu_sample, cores, 2)
+    # the headline frame itself when the host can do it inside the bounded sample (~10 s per run on the GPU box's 256 cores)
+    size = args.cpu_sample or ("%dx%d" % (args.width, args.height) if cores >= 64 else "960x540")
+    reps = 3
+    w, h, best = run(size, cores, reps)
     # the reference's schedule(dynamic, (W - 2) * 2b) hands out strips of 2b lines: at most ceil((H - 2) / 2b) threads have work
     strips = [max(1, -(-((h >> s) - 2) // (2 * args.search_radius))) for s in range(args.scales)]
     w1, h1, best1 = run(args.cpu_sample_1core, 1, 1)
     return {"value": round(w * h / 1e6 / best, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
             "effective_parallelism_per_scale": [min(cores, n) for n in strips],
             "sample": "%dx%d synthetic frame (same generator/flags), %d-scale, OpenMP dynamic strips of 2b lines like the reference "
-                      "(Denoiser.cpp:149-205), best of 2, %.2f s" % (w, h, args.scales, best),
+                      "(Denoiser.cpp:149-205), best of %d, %.2f s%s" % (w, h, args.scales, reps, best, " -- the headline frame" if (w, h) == (args.width, args.height) else ""),
             "one_core": {"value": round(w1 * h1 / 1e6 / best1, 5), "unit": "Mpix/s", "cores": 1,
                          "sample": "%dx%d synthetic frame, --ncores 1 (sequential visiting order), %.2f s" % (w1, h1, best1)}}
 
@@ -96,7 +100,9 @@ def per_scale_stats(ctx, S):
     scales = []
     for s in range(S):
         st = ctx.stats(s)
-        scales.append({"scale": s, "w": st.width, "h": st.height, "processed_frac": round(st.processed / max(1, st.main_pixels), 4),
+        scales.append({"scale": s, "w": st.width, "h": st.height, "processed": st.processed, "fallback": st.fallback,
+                       "full_estimates": st.processed - st.fallback, "similar_total": st.similar_total,
+                       "processed_frac": round(st.processed / max(1, st.main_pixels), 4),
                        "fallback_frac": round(st.fallback / max(1, st.processed), 4),
                        "mean_similar": round(st.similar_total / max(1, st.processed), 2), "rounds": st.active_rounds,
                        "borderline_pairs": st.borderline_pairs if st.similarity_path == 1 else None, "cu_share_pct": st.cu_share})
@@ -217,9 +223,10 @@ def main():
             if world > 1:
                 dist.all_reduce(failed, op=dist.ReduceOp.MAX)
             if int(failed.item()):
-                native_error = native_error or "the native driver failed on another rank"
-                step, parallelism = python_bands(True)
-                parallelism += " (native driver unavailable: %s)" % native_error
+                # no silent substitution: the native driver is what --gpus N measures; the torch.distributed band program is a test
+                # harness and has to be asked for (--python-bands)
+                raise SystemExit("bench.py --gpus %d: the native multi-GPU driver failed (%s); rerun with --python-bands to time the "
+                                 "torch.distributed test harness instead" % (world, native_error or "on another rank"))
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -272,10 +279,39 @@ def main():
             ms = (time.perf_counter() - t1) * 1e3 / reps
             return {"value": round(W * H / 1e6 / (ms * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms, 4), "steps": reps,
                     "per_scale": per_scale_stats(ctx, S)}
+        # ---- what a drop-in caller gets: bcd_hip_denoise_host on HOST buffers (pageable, like a DeepImage's std::vector): upload of the
+        # four planes, the same denoise, download of the result.  Never `value`; PCIe moves (D + 10) * 4 + 12 bytes per pixel.
+        h_frame = (col, ns, hist, cov)
+        ctx.denoise_host(*h_frame, S, prm)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ctx.denoise_host(*h_frame, S, prm)
+        ms_e2e = (time.perf_counter() - t1) * 1e3 / 3
+        pcie_bytes = W * H * ((60 + 1 + 3 + 6) * 4 + 12)
+        extras["end_to_end"] = {"value": round(W * H / 1e6 / (ms_e2e * 1e-3), 3), "unit": "Mpix/s", "ms_per_frame": round(ms_e2e, 3), "steps": 3,
+                                "pcie_bytes_per_frame": pcie_bytes, "pcie_gbs_if_all_of_the_time_were_transfer": round(pcie_bytes / (ms_e2e * 1e-3) / 1e9, 1),
+                                "workload": "the headline frame through bcd_hip_denoise_host (pageable host buffers in, host buffer out; engine context and device "
+                                            "staging buffers persistent): what bcd::Denoiser::denoise() / bcd_cli callers see, minus file IO"}
         # on the default frame most processed pixels take the fallback path; the low-noise variant (sigma 0.10, no
-        # spikes) and -m 0 (every main pixel processed) exercise the full Bayesian estimate
-        extras["low_noise"] = dict(leg(core.synthetic_scene(W, H, args.spp, 1234, 0.10, 0.0), prm, 3),
-                                   workload="same frame generator with sigma 0.10, no spikes")
+        # spikes), the textured frame and -m 0 (every main pixel processed) exercise the full Bayesian estimate
+        head = [(sc["processed"], sc["fallback"], sc["similar_total"]) for sc in scales]
+        low = leg(core.synthetic_scene(W, H, args.spp, 1234, 0.10, 0.0), prm, 3)
+        low_c = [(sc["processed"], sc["fallback"], sc["similar_total"]) for sc in low["per_scale"]]
+        # The frames differ (checked on the coarse scales' counters).  Scale 0 may legitimately show the headline's counters: at 32 spp
+        # the similar sets of the checker scene are decided by the checker geometry -- pairs inside a 16-pixel cell are similar at both
+        # noise levels, pairs across a cell edge are not (0 borderline pairs on both frames; tools/dbg_lownoise.py prints the identical
+        # |S| histograms) -- so what the low-noise leg changes is scales 1..2 and the estimates themselves, not scale 0's processed set.
+        assert low_c[1:] != head[1:] or S == 1, "the low-noise leg reported the headline frame's counters on every scale"
+        extras["low_noise"] = dict(low, workload="same frame generator with sigma 0.10, no spikes",
+                                   scale0_counters_equal_headline=bool(low_c[0] == head[0]),
+                                   note="scale 0's similar sets follow the 16-pixel checker geometry at both noise levels (DESIGN.md 8); the legs "
+                                        "whose similar sets depend on the noise are `textured` and `textured_low_noise`")
+        tex = leg(core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes, pattern=1), prm, 3)
+        tex_low = leg(core.synthetic_scene(W, H, args.spp, 1234, 0.10, 0.0, pattern=1), prm, 3)
+        assert [sc["similar_total"] for sc in tex["per_scale"]] != [sc["similar_total"] for sc in tex_low["per_scale"]]
+        extras["textured"] = dict(tex, workload="band-limited texture with oblique soft edges (SyntheticScene pattern 1), same sigma / spikes / flags: "
+                                                "similar sets depend on the noise, most processed pixels take the full estimate")
+        extras["textured_low_noise"] = dict(tex_low, workload="the textured frame with sigma 0.10, no spikes")
         extras["m0"] = dict(leg((col, ns, hist, cov), bh.default_params(b=b, w=w, m=0.0, random_order=args.random_order, seed=1234), 2),
                             workload="the default frame with -m 0 (no marking: every main pixel is processed)")
         # BASELINE configs[3]'s frame on this one GPU: the N = 1 point of the 4K strong-scaling curve (north_star), untimed leg
