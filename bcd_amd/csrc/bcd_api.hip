@@ -57,6 +57,7 @@ hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t 
                                    int, float, float *, int32_t *, float *, size_t, hipStream_t);
 hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, const int32_t *, int, int, int, int, int, float *,
                                  int32_t *, hipStream_t);
+hipError_t bcd_launch_bayes_weak_tiles(const float *, const uint32_t *, const uint8_t *, const int32_t *, int, int, int, int, float *, int32_t *, hipStream_t);
 
 namespace {
 
@@ -399,7 +400,11 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     // the full estimate (few long items)
     HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
     HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
-    HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, d_c + 1, weak_blocks, W, H, w, b, d_sum, d_count, wk.aux));
+    static const bool weak_lists = [] { const char *e = getenv("BCD_HIP_WEAK_LISTS"); return e && e[0] == '1'; }();
+    if (w == 1 && !weak_lists) // 3 x 3 patches: the tiled kernel (members out of an LDS colour window; finds the fallback pixels itself)
+        HIPCHK(ctx, bcd_launch_bayes_weak_tiles(d_colors, d_mask, d_state, d_nsim, K + 1, W, H, b, d_sum, d_count, wk.aux));
+    else
+        HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, d_c + 1, weak_blocks, W, H, w, b, d_sum, d_count, wk.aux));
     HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
     if (w == 1) {
         HIPCHK(ctx, hipStreamSynchronize(wk.stream));

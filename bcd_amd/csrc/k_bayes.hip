@@ -413,6 +413,115 @@ __global__ __launch_bounds__(64) void k_bayes_weak_w1(const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// denoiseOnlyMainPatch for the 3 x 3 patch, TILED: one workgroup per 16 x 16 pixel tile stages the colours of the tile plus the
+// (b + 1)-pixel frame every member patch can reach -- (16 + 2 b + 2)^2 pixels, 10.8 KB for b = 6 -- in LDS with coalesced row
+// loads, finds the tile's fallback pixels itself (state == IN and |S| < 28: no list needed), and averages their similar patches
+// out of LDS.  Fallback pixels cluster (on the bench frames they are the pixels next to an edge), so neighbouring fallback pixels
+// read the same members: the list kernels above gather every member patch from global memory once per fallback pixel -- 730 MB of
+// 36-byte segments at 1080p, bound by the L1 tag rate (r3: 0.41 ms at 1080p scale 0, all wave slots of the chip taken meanwhile,
+// which is what the full-estimate kernels started beside it were really waiting for).  The estimates are summed into an 18 x 18
+// LDS window and flushed with one global atomic per touched value.
+// Lane layout as k_bayes_weak_w1: one lane per (fallback pixel, patch row), 21 pixels per wavefront, sums in window order.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WT = 16; // tile edge
+__global__ __launch_bounds__(256) void k_bayes_weak_tile(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
+                                                         const uint8_t *__restrict__ state, const int32_t *__restrict__ nsim, int min_strong,
+                                                         BayesGeom g, float *sum, int32_t *cnt)
+{
+    extern __shared__ float lds[];
+    const int b1 = g.b + 1, TW = WT + 2 * b1, row3 = TW * 3;
+    float *win = lds;                                         // TW x TW x 3 colours
+    float *accS = win + ((TW * row3 + 3) & ~3);               // (WT + 2)^2 x 3 sums
+    int *accC = reinterpret_cast<int *>(accS + (WT + 2) * (WT + 2) * 3);
+    uint16_t *wlist = reinterpret_cast<uint16_t *>(accC + (WT + 2) * (WT + 2)); // local indices of the tile's fallback pixels
+    __shared__ int n_weak;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx0 = blockIdx.x * WT, ty0 = blockIdx.y * WT;
+    const int W = g.W, H = g.H;
+    // ---- fallback pixels of the tile
+    const int lx = tid & (WT - 1), ly = tid >> 4, gx = tx0 + lx, gy = ty0 + ly;
+    const bool inside = gx < W && gy < H;
+    const long long pg = (long long)gy * W + gx;
+    const bool weak = inside && state[pg] == BCD_ST_IN && nsim[pg] < min_strong;
+    if (tid == 0) n_weak = 0;
+    __syncthreads();
+    {
+        const unsigned long long bal = __ballot(weak);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&n_weak, __popcll(bal));
+        base = __shfl(base, 0);
+        if (weak) wlist[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    }
+    __syncthreads();
+    const int nw = n_weak;
+    if (nw == 0) return;                                      // (uniform)
+    // ---- colour window (cells outside the image are never part of a member's patch: clamped addresses, no branches) and accumulators
+    for (int e = tid; e < TW * row3; e += 256) {
+        const int wy = e / row3, r = e - wy * row3, px = r / 3, ch = r - px * 3;
+        const int yy = min(max(ty0 - b1 + wy, 0), H - 1), xx = min(max(tx0 - b1 + px, 0), W - 1);
+        win[e] = colors[((long long)yy * W + xx) * 3 + ch];
+    }
+    for (int e = tid; e < (WT + 2) * (WT + 2) * 4; e += 256) accS[e] = 0.f; // (sums and counts are contiguous)
+    __syncthreads();
+    // ---- 21 fallback pixels per wavefront and pass, one lane per patch row
+    constexpr int PER_WAVE = 21;
+    const int slot = lane / 3, prow = lane - slot * 3;
+    const float inv_side = 1.f / (float)g.side;
+    for (int base = wave * PER_WAVE; base < nw; base += 4 * PER_WAVE) {
+        const int item = base + slot;
+        if (slot < PER_WAVE && item < nw) {
+            const int lp = wlist[item], plx = lp & (WT - 1), ply = lp >> 4;
+            const long long p = (long long)(ty0 + ply) * W + tx0 + plx;
+            // first float of this lane's patch row for the member at window offset (0, 0), i.e. the pixel itself
+            const float *src = win + ((ply + b1 + prow - 1) * TW + plx + b1 - 1) * 3;
+            const uint32_t *mw = mask + (size_t)p * g.words;
+            float a[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) a[e] = 0.f;
+            int n = 0;
+            for (int w0 = 0; w0 < g.words; w0 += 6) {
+                uint32_t mreg[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) mreg[u] = (w0 + u < g.words) ? mw[w0 + u] : 0u; // the words of the pass travel together
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    uint32_t m = mreg[u];
+                    while (m) {
+                        const int k = (w0 + u) * 32 + __ffs(m) - 1;
+                        m &= m - 1;
+                        const int kl = (int)(((float)k + 0.5f) * inv_side), kc = k - kl * g.side; // k / side, see k_bayes_weak
+                        const float *q = src + ((kl - g.b) * TW + (kc - g.b)) * 3;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) a[e] += q[e];
+                        ++n;
+                    }
+                }
+            }
+            const float n_inv = 1.f / (float)n;
+            float *dS = accS + ((ply + prow) * (WT + 2) + plx) * 3;        // patch row prow of the pixel in the 18 x 18 window
+            int *dC = accC + (ply + prow) * (WT + 2) + plx;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) unsafeAtomicAdd(dS + e, n_inv * a[e]);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) atomicAdd(dC + e, 1);
+        }
+    }
+    __syncthreads();
+    // ---- flush: one global atomic per touched value
+    for (int e = tid; e < (WT + 2) * (WT + 2); e += 256) {
+        const int c = accC[e];
+        if (c != 0) {
+            const int wy = e / (WT + 2), wx = e - wy * (WT + 2);
+            const long long q = (long long)(ty0 - 1 + wy) * W + (tx0 - 1 + wx);
+            unsafeAtomicAdd(sum + q * 3, accS[e * 3]);
+            unsafeAtomicAdd(sum + q * 3 + 1, accS[e * 3 + 1]);
+            unsafeAtomicAdd(sum + q * 3 + 2, accS[e * 3 + 2]);
+            atomicAdd(cnt + q, c);
+        }
+    }
+}
+
 BayesGeom make_geom(int W, int H, int w, int b)
 {
     BayesGeom g;
@@ -476,6 +585,19 @@ hipError_t bcd_launch_bayes_strong(const float *colors, const float *pixcov, con
     }
     hipLaunchKernelGGL(k_bayes_strong_generic, dim3(blocks), dim3(64), lds, st, colors, pixcov, mask, list, g, d_nlist, min_eig, sum, cnt,
                        per_block ? gscratch : nullptr);
+    return hipGetLastError();
+}
+
+// the tiled fallback kernel (3 x 3 patches): needs no list -- it reads the marking states and |S| itself
+hipError_t bcd_launch_bayes_weak_tiles(const float *colors, const uint32_t *mask, const uint8_t *state, const int32_t *nsim, int min_strong,
+                                       int W, int H, int b, float *sum, int32_t *cnt, hipStream_t st)
+{
+    BayesGeom g = make_geom(W, H, 1, b);
+    if (g.words > 32) return hipErrorInvalidValue;
+    const int TW = WT + 2 * (b + 1);
+    const size_t lds = (size_t)((TW * TW * 3 + 3) & ~3) * 4 + (size_t)(WT + 2) * (WT + 2) * 16 + 256 * sizeof(uint16_t);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bayes_weak_tile, dim3((W + WT - 1) / WT, (H + WT - 1) / WT), dim3(256), lds, st, colors, mask, state, nsim, min_strong, g, sum, cnt);
     return hipGetLastError();
 }
 

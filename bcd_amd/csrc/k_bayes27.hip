@@ -792,6 +792,337 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
   }
 }
 
+
+// =====================================================================================================================
+// Windowed variant for the default search radius (b = 6): every patch of every member of S(p) lies inside the 15 x 15 pixel
+// window around p.  The kernels stage that window ONCE per pixel -- colours (2.7 KB; PHASE 1 also the per-pixel covariances,
+// 5.4 KB) with 33 / 11 fully coalesced loads (window rows are contiguous in the image) -- and every per-member access becomes
+// an LDS read: the r2 kernels gathered 108 scattered floats per member from global memory in PHASE 1 (half of its wave cycles
+// waited for them; r3 counters) and 27 per member in the output pass of PHASE 2.  Members are kept as WINDOW PIXEL INDICES
+// (kl + 1) * 15 + (kc + 1), which index the colour / covariance windows and the aggregation window alike.
+// =====================================================================================================================
+constexpr int WB = 6, WSIDE = 2 * WB + 1, WAW = WSIDE + 2, WPIX = WAW * WAW;   // 13, 15, 225
+constexpr int WMEM = ((WSIDE * WSIDE + 7) / 8) * 8;                             // member list, padded to whole 16-byte reads
+// LDS layout of PHASE 1 (floats): colour window | covariance window | noise | mean | members (16-byte aligned)
+constexpr int W1_NWIN = (WPIX * 3 + 3) / 4 * 4, W1_NOISE = W1_NWIN + (WPIX * 6 + 3) / 4 * 4, W1_MEM = W1_NOISE + 56 + 28;
+constexpr int W2_MEM = 4 * 784 + 56 + 56 + 28 + 28;                              // PHASE 2: four matrix buffers | cs | noise | mean | fl | members
+static_assert(W1_MEM % 4 == 0 && W2_MEM % 4 == 0 && 28 * 29 <= WPIX * 6, "aligned member lists; the covariance tile fits the covariance window");
+
+// similar set of p in window order -> mem[i] = window pixel index of member i; returns |S|.  The mask words of p are wave-uniform
+// (scalar loads); lane l looks at the bits l, l + 64, l + 128 and places its members by prefix population counts.
+__device__ inline int decode_members_win(const uint32_t *__restrict__ mask, int p, int words, uint16_t *mem, int lane)
+{
+    uint32_t wd[6];
+    int pre[7];
+    pre[0] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        wd[i] = i < words ? mask[(size_t)p * words + i] : 0u;
+        pre[i + 1] = pre[i] + __popc(wd[i]);
+    }
+    const int hi = lane >> 5, bit = lane & 31;
+    const uint32_t below = (1u << bit) - 1u;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t w = hi ? wd[2 * j + 1] : wd[2 * j];
+        const int base = hi ? pre[2 * j + 1] : pre[2 * j];
+        if ((w >> bit) & 1u) {
+            const int k = lane + 64 * j;
+            const int kl = (k * 79) >> 10, kc = k - kl * WSIDE;           // k / 13 for k < 169 (79 / 1024 = 1 / 12.96; exact up to k = 181)
+            mem[base + __popc(w & below)] = (uint16_t)((kl + 1) * WAW + kc + 1);
+        }
+    }
+    __syncthreads();
+    return pre[6];
+}
+
+// one 15 x 15 window of an interleaved image with D floats per pixel -> LDS (cells outside the image: unspecified; no member patch touches them),
+// in slices of WIN_SLICE loads per lane: win_issue puts the loads of slice `first` in flight, win_commit stores them
+constexpr int WIN_SLICE = 11;
+template <int D>
+__device__ inline void win_issue(float (&v)[WIN_SLICE], const float *__restrict__ img, int first, int pr, int pc, int W, int H, int lane)
+{
+    constexpr int ROW = WAW * D, N = WAW * ROW;
+    const int row0 = pr - (WB + 1), col0 = pc - (WB + 1);
+#pragma unroll
+    for (int u = 0; u < WIN_SLICE; ++u) {
+        // (cells outside the image are never part of a member's patch: their content is irrelevant, so the address is clamped
+        // into the image instead of branching around the load)
+        const int e = min(lane + 64 * (first + u), N - 1);
+        const int wy = e / ROW, r = e - wy * ROW, px = r / D, ch = r - px * D;
+        const int gy = min(max(row0 + wy, 0), H - 1), gx = min(max(col0 + px, 0), W - 1);
+        v[u] = img[(gy * W + gx) * D + ch]; // (32-bit index: DeepImage indices are ints, checked by the host)
+    }
+}
+template <int D>
+__device__ inline void win_commit(float *win, const float (&v)[WIN_SLICE], int first, int lane)
+{
+    constexpr int N = WAW * WAW * D;
+#pragma unroll
+    for (int u = 0; u < WIN_SLICE; ++u) {
+        const int e = lane + 64 * (first + u);
+        if (e < N) win[e] = v[u];
+    }
+}
+static_assert(WIN_SLICE * 64 >= WPIX * 3 && 2 * WIN_SLICE * 64 >= WPIX * 6, "one slice holds the colour window, two the covariance window");
+
+// offset (floats, D per pixel) of component k of a patch vector relative to the member's centre pixel in a window image
+template <int D> __device__ inline int patch_off(int o) { return ((o / 3 - 1) * WAW + (o % 3 - 1)) * D; }
+
+// ---- PHASE 1 of the windowed kernel, in out-of-line steps (each gets the register file to itself) ----
+// the colour window travels while the members are decoded, then the covariance window in two slices; returns |S|
+__device__ __attribute__((noinline)) int win_stage_phase1(float *cwin, float *nwin, uint16_t *mem, const float *__restrict__ colors,
+                                                          const float *__restrict__ pixcov, const uint32_t *__restrict__ mask, int p, int pr, int pc,
+                                                          int W, int H, int words, int lane)
+{
+    LDS_POINTER(cwin); LDS_POINTER(nwin); LDS_POINTER(mem);
+    float wv[WIN_SLICE];
+    win_issue<3>(wv, colors, 0, pr, pc, W, H, lane);
+    const int n = decode_members_win(mask, p, words, mem, lane);
+    win_commit<3>(cwin, wv, 0, lane);
+    win_issue<6>(wv, pixcov, 0, pr, pc, W, H, lane);
+    win_commit<6>(nwin, wv, 0, lane);
+    win_issue<6>(wv, pixcov, WIN_SLICE, pr, pc, W, H, lane);
+    win_commit<6>(nwin, wv, WIN_SLICE, lane);
+    __syncthreads();
+    return n;
+}
+
+// computeNoiseCovPatchesMean (:400-419) and empiricalMean (:500-509): lanes 0..53 own one noise component, lanes 0..26 also one
+// colour component; sums in member order
+__device__ __attribute__((noinline)) void win_noise_mean(float *noise, float *mean, const float *cwin, const float *nwin, const uint16_t *mem, int n, int lane)
+{
+    LDS_POINTER(noise); LDS_POINTER(mean); LDS_POINTER(cwin); LDS_POINTER(nwin); LDS_POINTER(mem);
+    const float n_inv = 1.f / (float)n;
+    const int ln = min(lane, P * 6 - 1), lc = min(lane, K - 1);
+    const int noff = patch_off<6>(ln / 6) + ln % 6, coff = patch_off<3>(lc / 3) + lc % 3;
+    float accn = 0.f, accm = 0.f;
+    for (int i = 0; i < n; i += 8) {
+        const uint4 c8 = *reinterpret_cast<const uint4 *>(mem + i);
+        const uint32_t cw[4] = { c8.x, c8.y, c8.z, c8.w };
+        float vn[8], vm[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int wp = (int)((cw[u >> 1] >> (16 * (u & 1))) & 0xffffu);
+            vn[u] = nwin[wp * 6 + noff];
+            vm[u] = cwin[wp * 3 + coff];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { // (x + 0.f == x: the padding slots of the last group leave the sums untouched)
+            accn += (i + u < n) ? vn[u] : 0.f;
+            accm += (i + u < n) ? vm[u] : 0.f;
+        }
+    }
+    __syncthreads(); // (every lane is done with the previous pixel's means)
+    if (lane < P * 6) noise[lane] = accn * n_inv;
+    if (lane < K) mean[lane] = accm * n_inv;
+    __syncthreads();
+}
+
+// centerPointCloud + empiricalCovarianceMatrix (:511-536) on the matrix core, operands straight from the colour window: lane l feeds
+// element i = l & 31 of member 2 s + (l >> 5) (rows / columns 27..31 zero); a chain of fma in member order, i.e. the reference's
+// sequential sum with the product fused; A and B operands are the same centred value, so the result is bitwise symmetric.
+// The product (x 1 / (n - 1)) leaves the accumulators for a 28 x 29 tile in LDS (row / column 27 exactly zero).
+__device__ __attribute__((noinline)) void win_covariance(float *tile, const float *cwin, const float *mean, const uint16_t *mem, int n, int lane)
+{
+    LDS_POINTER(tile); LDS_POINTER(cwin); LDS_POINTER(mean); LDS_POINTER(mem);
+    const int mi = lane & 31, mk = lane >> 5, mic = min(mi, K - 1);
+    const float my_mean = mean[mic];
+    const int aoff = patch_off<3>(mic / 3) + mic % 3;
+    v16f acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int s8 = 0; s8 < n; s8 += 8) {
+        const uint4 c8 = *reinterpret_cast<const uint4 *>(mem + s8);
+        const uint32_t cw[4] = { c8.x, c8.y, c8.z, c8.w };
+        float av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int wp = (int)((cw[t] >> (16 * mk)) & 0xffffu);       // member s8 + 2 t + mk
+            av[t] = cwin[wp * 3 + aoff];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (s8 + 2 * t < n) {                                       // (wave-uniform)
+                const float a = (s8 + 2 * t + mk < n && mi < K) ? av[t] - my_mean : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
+            }
+        }
+    }
+    const float inv = 1.f / (float)(n - 1);
+    // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * mk;
+        if (r < KP && mi < LD) tile[r * LD + mi] = acc[e] * inv;
+    }
+    __syncthreads();
+}
+
+// the records of PHASE 1 from the covariance tile: C (LD layout), A = C - N in the eigensolver's 28 x 28 layout (the matrix whose negative
+// eigenvalues are clamped, Step 1 (:421-436); padding row / column zero), noise and mean -- whole 256-byte lines per store instruction
+__device__ __attribute__((noinline)) void win_write_records(float *__restrict__ recA, float *__restrict__ recC, float *__restrict__ recX,
+                                                            const float *tile, const float *noise, const float *mean, int lane)
+{
+    LDS_POINTER(tile); LDS_POINTER(noise); LDS_POINTER(mean);
+    for (int e = lane; e < K * LD; e += 64) recC[e] = tile[e];
+    for (int e = lane; e < KP * JLD; e += 64) {
+        const int r = e / JLD, c = e - r * JLD, ro = r / 3, co = c / 3;
+        // the block-diagonal noise covariance: 3 x 3 block of pixel ro (symmetric storage xx,yy,zz,yz,xz,xy)
+        const float nv = (ro == co && r < K && c < K) ? noise[ro * 6 + noise_idx(r - 3 * ro, c - 3 * co)] : 0.f;
+        recA[e] = tile[r * LD + c] - nv;
+    }
+    if (lane < P * 6) recX[lane] = noise[lane];
+    if (lane < K) recX[P * 6 + lane] = mean[lane];
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float *__restrict__ colors, const float *__restrict__ pixcov,
+                                                 const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
+                                                 int first_item, int nb_items, int *work, Geom27 g, float min_eig, Records27 rec, float *sum,
+                                                 int32_t *cnt)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x;
+    // PHASE 1: colour window | covariance window | noise | mean | members            (8.8 KB: 18 wavefronts per CU)
+    // PHASE 2: Cm | A | V | Bm (matrix scratch, then the colour window) | cs | noise | mean | fl | members   (as the gather kernel)
+    float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ;
+    float *cwin = PHASE == 1 ? lds : Bm;
+    float *nwin = cwin + W1_NWIN;                  // PHASE 1 only (later the 28 x 29 covariance tile)
+    float *cs = Bm + MSZ;                          // PHASE 2 only
+    float *noise = PHASE == 1 ? lds + W1_NOISE : cs + 2 * KP;
+    float *mean = noise + 56;                      // (54 noise components; offsets stay multiples of 16 bytes)
+    float *fl = mean + KP;                         // PHASE 2 only
+    uint16_t *mem = reinterpret_cast<uint16_t *>(PHASE == 1 ? lds + W1_MEM : fl + KP);
+    static_assert(WPIX * 3 <= MSZ, "the colour window fits a matrix buffer");
+    for (int e = lane; e < WMEM; e += 64) mem[e] = (uint16_t)(WAW + 1); // (entries past |S| are read, never used: keep them inside the window)
+    if (lane == 0) mean[K] = 0.f;
+    __syncthreads();
+    const int W = g.W, H = g.H;
+
+  // Items come from a work counter.  One counter serves ~50 same-address atomics per microsecond (measured: 36 000 grabs = 0.72 ms,
+  // which was the whole duration of PHASE 1 at 1080p), so the short PHASE 1 items are taken two at a time; the PHASE 2 items are longer
+  // and differ in length, one at a time balances better (two: +1 %, four: +9 %; a static split: +46 %).
+  const int grab = PHASE == 1 ? 2 : 1;
+  int slot_base = 0, slot_i = grab;
+  for (;;) {
+    if (slot_i >= grab) {
+        if (lane == 0) slot_base = atomicAdd(work, grab);
+        slot_base = __builtin_amdgcn_readfirstlane(slot_base);
+        slot_i = 0;
+    }
+    const int slot = slot_base + slot_i++;
+    if (slot >= nb_items) break;
+    const int p = __builtin_amdgcn_readfirstlane(list[first_item + slot]);
+    const int pr = p / W, pc = p - pr * W;
+    float *recA = rec.A + (size_t)slot * MSZ, *recC = rec.C + (size_t)slot * MSZ, *recX = rec.aux + (size_t)slot * AUX27;
+
+  if (PHASE == 1) {
+    const int n = win_stage_phase1(cwin, nwin, mem, colors, pixcov, mask, p, pr, pc, W, H, g.words, lane);
+    win_noise_mean(noise, mean, cwin, nwin, mem, n, lane);
+    win_covariance(nwin /* tile: the covariance window is dead by then */, cwin, mean, mem, n, lane);
+    win_write_records(recA, recC, recX, nwin, noise, mean, lane);
+    __syncthreads(); // the next item reuses the LDS
+  } else {
+    const int n = decode_members_win(mask, p, g.words, mem, lane);
+    {
+        const float *recV = rec.V + (size_t)slot * MSZ;
+        for (int e = lane; e < MSZ / 4; e += 64) {
+            reinterpret_cast<float4 *>(Cm)[e] = reinterpret_cast<const float4 *>(recC)[e];
+            reinterpret_cast<float4 *>(V)[e] = reinterpret_cast<const float4 *>(recV)[e];
+        }
+        if (lane < P * 6) noise[lane] = recX[lane];
+        if (lane < K) mean[lane] = recX[P * 6 + lane];
+        if (lane < KP) fl[lane] = fmaxf(0.f, rec.eig[(size_t)slot * KP + lane]); // clampNegativeEigenValues (:606-630)
+        __syncthreads();
+    }
+    // ---- Step 1 (:421-436), second half, and Step 2 (:438-453): as in k_bayes27<2>
+    mfma27<true, true>(Bm, LD, V, JLD, V, JLD, fl, KP, lane); // V max(0, lambda) V^T
+    add_noise27(Bm, noise, lane, +1.f);
+    inverse27(Bm, A, V, fl, cs, lane, min_eig);
+    noise_times27(V, noise, Bm, lane, true);       // V  = F = I - N Cinv1
+    mfma27<false, false>(A, LD, V, LD, Cm, LD, nullptr, K, lane);  // A  = F C
+    mfma27<true, false>(Bm, LD, A, LD, V, LD, nullptr, K, lane);   // Bm = F C F^T
+    for (int e = lane; e < K * K; e += 64) {       // exact symmetry (lower triangle wins)
+        int r = e / K, c = e - r * K;
+        if (r < c) Cm[r * LD + c] = Bm[c * LD + r];
+    }
+    __syncthreads();
+    for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; if (r < c) Bm[r * LD + c] = Cm[r * LD + c]; }
+    __syncthreads();
+    add_noise27(Bm, noise, lane, +1.f);
+    inverse27(Bm, A, V, fl, cs, lane, min_eig);
+    // finalDenoisingMatrixMultiplication (:656-670) as xhat = m + F2 (x - m), F2 = I - N Cinv2 (the same affine map as x - G2 (x - m))
+    noise_times27(Cm, noise, Bm, lane, true);      // Cm = F2
+    // Bm is free: the colour window of p; A / V are dead: the aggregation window (sums 15 x 15 x 3, then counts 15 x 15)
+    {
+        float wv[WIN_SLICE];
+        win_issue<3>(wv, colors, 0, pr, pc, W, H, lane);
+        win_commit<3>(cwin, wv, 0, lane);
+    }
+    float *accS = A;
+    int *accC = reinterpret_cast<int *>(A + WPIX * 3);
+    for (int e = lane; e < WPIX * 4; e += 64) A[e] = 0.f;
+    __syncthreads();
+    // ---- output pass, 32 members per matrix-core product: D[r][j] = sum_k F2[r][k] (x_j[k] - m[k]); lane l feeds A = F2[l & 31][k] and
+    // B = x - m of member l & 31, k = 2 s + (l >> 5); it gets back components r = (e & 3) + 8 (e >> 2) + 4 (l >> 5) of member l & 31
+    {
+        const int mj = lane & 31, kh = lane >> 5;
+        const float *frow = Cm + min(mj, K - 1) * LD + kh;      // (rows 27..31 of the A operand only reach rows 27..31 of D: unused)
+        const float *mk_ = mean + kh;
+        for (int i0 = 0; i0 < n; i0 += 32) {
+            const bool valid = i0 + mj < n;
+            const int wp = mem[valid ? i0 + mj : 0];
+            const int base = (wp - WAW - 1) * 3;                // top-left pixel of the member's patch in the window, floats
+            const float *xb = cwin + base + kh;
+            v16f y;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) y[e] = 0.f;
+#pragma unroll
+            for (int k0 = 0; k0 < KP; k0 += 2) {
+                // component k = k0 + kh of a patch vector sits at k + 36 (k / 9) floats from the patch's top-left pixel
+                const int j0 = k0 / 9, j1 = (k0 + 1) / 9;
+                float a = frow[k0];
+                float bq = (j0 == j1 ? xb[k0 + 36 * j0] : cwin[base + (kh ? k0 + 1 + 36 * j1 : k0 + 36 * j0)]) - mk_[k0];
+                if (k0 + 1 >= K) { a = kh ? 0.f : a; bq = kh ? 0.f : bq; }   // k = 27: padding
+                y = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, y, 0, 0, 0);
+            }
+            if (valid) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r0 = (e & 3) + 8 * (e >> 2);        // r = r0 + 4 kh
+                    const int ja = r0 / 9, jb = (r0 + 4) / 9;
+                    const bool ok = kh ? (r0 + 4 < K) : (r0 < K);
+                    if (ok) {
+                        const float v = mean[r0 + 4 * kh] + y[e];
+                        const int idx = base + (kh ? r0 + 4 + 36 * jb : r0 + 36 * ja);
+                        unsafeAtomicAdd(accS + idx, v);
+                        const bool first_channel = kh ? ((r0 + 4) % 3 == 0) : (r0 % 3 == 0);
+                        if (first_channel) atomicAdd(accC + idx / 3, 1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // aggregateOutputPatches (:672-693): one global atomic per touched value of the window, rows contiguous
+    {
+        constexpr int row3 = WAW * 3;
+        const long long base = (long long)p - (long long)(WB + 1) * W - (WB + 1); // window origin; untouched cells may lie outside the image
+        for (int e = lane; e < WAW * row3; e += 64) {
+            int wy = e / row3, r = e - wy * row3, wx = r / 3;
+            if (accC[wy * WAW + wx] != 0) unsafeAtomicAdd(sum + (base + (long long)wy * W) * 3 + r, accS[e]);
+        }
+        for (int e = lane; e < WPIX; e += 64) {
+            int wy = e / WAW, wx = e - wy * WAW, c = accC[e];
+            if (c != 0) atomicAdd(cnt + (base + (long long)wy * W + wx), c);
+        }
+    }
+    __syncthreads(); // the next item reuses the LDS
+  }
+  }
+}
+
 } // namespace
 
 // LDS of the widest phase (PHASE 2: four matrix buffers)
@@ -824,6 +1155,19 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     rec.eig = rec.aux + (size_t)nb_items * AUX27;
     const size_t lds2 = bcd_bayes27_lds_bytes(b), lds1 = lds2 - 3 * MSZ * sizeof(float);
     const int per_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / lds1), per_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / lds2);
+    static const bool gather_only = [] { const char *e = getenv("BCD_HIP_BAYES_GATHER"); return e && e[0] == '1'; }();
+    if (b == WB && !gather_only) {
+        // default search radius: the windowed kernels (members read from LDS windows)
+        const size_t wl1 = (size_t)W1_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
+        const size_t wl2 = (size_t)W2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
+        const int w_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / wl1), w_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / wl2);
+        hipLaunchKernelGGL(k_bayes27w<1>, dim3(std::min(nb_items, num_cus * w_cu1)), dim3(64), wl1, st, colors, pixcov, mask, list, first_item, nb_items,
+                           d_work, g, min_eig, rec, sum, cnt);
+        { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + 1, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * w_cu2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
+                           d_work + 2, g, min_eig, rec, sum, cnt);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
                        d_work, g, min_eig, rec, sum, cnt);
     { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + 1, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
