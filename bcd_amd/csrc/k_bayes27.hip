@@ -1,11 +1,15 @@
-// k_bayes27.hip -- Bayesian patch estimate for the default patch radius w = 1 (K = 27): persistent wavefronts (one
-// workgroup = one wavefront, 13.2 KB of LDS and 148 VGPRs: 12 per CU), one processed pixel at a time.
+// k_bayes27.hip -- full Bayesian estimate of a processed pixel for the default patch radius w = 1 (K = 27): three kernels with a
+// per-pixel record in HBM between them (persistent single-wavefront workgroups, items from a work counter):
+//   k_bayes27w<1> / k_bayes27<1>  PREPARE  members of S(p), noise mean, colour mean, covariance C on the f32 matrix core;
+//                                          record: A = C - N (28 x 28, zero padded), C, N, m
+//   k_jacobi27_batch              SOLVE    eigen-decomposition of every A (clampNegativeEigenValues), two matrices per wavefront
+//   k_bayes27w<2> / k_bayes27<2>  FINISH   clamp, inverses, Step 2, final estimates, aggregation
+// The `w` kernels serve the default search radius b = 6: the 15 x 15 pixel window around p is staged in LDS once and every member
+// access is an LDS read; other radii take the gather kernels (members fetched from global memory).
 //
 // Same mathematics as DenoisingUnit::denoiseSelectedPatches (src/core/DenoisingUnit.cpp:388-453) and
 // aggregateOutputPatches (:672-693), reorganised for the GPU:
-//   * the noise mean and the colour mean are summed straight from global memory; the similar patches are then streamed
-//     through a 29-member LDS chunk twice (covariance, final estimate) instead of being held as n x 27 clouds; sums keep
-//     the reference's sequential member order;
+//   * sums over the members keep the reference's sequential member order;
 //   * the covariance, the spectral rebuild, the Step-2 products and the final estimate run on the f32 matrix core
 //     (v_mfma_f32_32x32x2_f32: exact f32, a chain of fma over k);
 //   * Step 2's covariance of the Step-1 estimates (:441-443) is obtained without touching the members
@@ -15,7 +19,7 @@
 //   * inverseSymmetricMatrix (:578-604) = V diag(1/max(minEig, lambda)) V^T equals the plain inverse
 //     whenever lambda_min >= minEig.  The inverse is computed with the symmetric sweep operator and
 //     accepted only if every pivot is positive and ||M^-1||_F * minEig <= 1 (which proves
-//     lambda_min(M) >= minEig); otherwise the spectral form is evaluated with the Jacobi solver.
+//     lambda_min(M) >= minEig); otherwise the spectral form is evaluated with a compact Jacobi solver.
 #include "bcd_common.h"
 #include <cstdio>
 #include <algorithm>

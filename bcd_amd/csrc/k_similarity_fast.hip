@@ -322,7 +322,9 @@ hipError_t bcd_launch_pairdist_rw(const float *hist, const float *ns, int W, int
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
 #define BCD_RW_LAUNCH(DD, UU)                                                                                        \
     {                                                                                                                \
-        const size_t lds = (size_t)RwLayout<DD>::LDS_DWORDS * 4;                                                     \
+        /* (experiment hook: BCD_HIP_RW_EXTRA_LDS=bytes pads the allocation -- the occupancy a kernel with more LDS would get) */ \
+        static const size_t extra = [] { const char *e = getenv("BCD_HIP_RW_EXTRA_LDS"); return e ? (size_t)atol(e) : (size_t)0; }(); \
+        const size_t lds = (size_t)RwLayout<DD>::LDS_DWORDS * 4 + extra;                                             \
         static std::atomic<int> granted[64]; /* per instantiation and device */                                     \
         if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || granted[dev].load() == 0)) {                                 \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist_rw<DD, UU>),               \
