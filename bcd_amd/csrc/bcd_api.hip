@@ -29,6 +29,10 @@ hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, 
                             const BcdBorderline *, const float *, const float *, int);
 int bcd_pairdist_rw_supported(int D);
 hipError_t bcd_launch_pairdist_rw(const float *, const float *, int, int, int, int, void * /* binary16 T planes */, uint8_t *, int *, float, hipStream_t);
+hipError_t bcd_launch_pairdist_rw_rows(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, int, int, hipStream_t);
+int bcd_pairdist_rw_tile_lines();
+hipError_t bcd_launch_spike_rows(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *, float *, float *, int, int,
+                                 hipStream_t);
 hipError_t bcd_launch_max_rel_dev(const float *, const float *, const uint8_t *, const uint8_t *, int, int, int, unsigned int *, hipStream_t);
 hipError_t bcd_launch_window_distances(const float *, const uint8_t *, int, int, int, int, int, int, float *, hipStream_t);
 hipError_t bcd_launch_pixel_cov(const float *, const float *, int64_t, float *, hipStream_t);
@@ -91,6 +95,9 @@ struct Work {
     hipEvent_t ev_built = nullptr; // this scale's pyramid level is complete
     hipStream_t aux = nullptr;     // side stream: the fallback-pixel kernel runs beside the (latency-bound) full estimate kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // approximate distance planes computed ahead of similarity() by a caller that streams the frame in (bcd_hip_denoise_host_ex): valid for
+    // exactly this problem; similarity() consumes the note
+    struct { bool ready = false; const float *hist = nullptr, *ns = nullptr; int W = 0, H = 0, D = 0, b = 0; float tau = 0.f, uni_n = 0.f; } planes;
 };
 
 struct bcd_hip_ctx {
@@ -116,6 +123,9 @@ struct bcd_hip_ctx {
     DevBuf pyr[MAX_SCALES][5]; // colours, nsamples, hist, cov, out
     DevBuf host_stage[9];      // host-buffer entry points: device copies of the four inputs, the output, the prefiltered inputs (grow-only)
     hipEvent_t ev_pyramid = nullptr;
+    hipStream_t upload_stream = nullptr;        // host-buffer entry points: uploads run beside the kernels of the lines that have arrived
+    std::vector<hipEvent_t> ev_upload;
+    bool stream_uploads = true;                 // BCD_HIP_STREAM_UPLOADS=0: upload everything, then compute
     // progress reporting (IDenoiser::setProgressCallback; Denoiser.cpp:181-192 of the reference): every scale adds its share when
     // its marking is done and when its estimate is done; calls are serialised and monotone
     bcd_hip_progress_fn progress_fn = nullptr;
@@ -217,6 +227,12 @@ bool similarity_needs_redo(const Work &wk)
     return wk.h_counters[40] != 0 || (wk.border_capacity > 0 && wk.h_counters[43] > wk.border_capacity);
 }
 
+// can the approximate-planes path serve this problem?  (w = 1, a supported depth, a threshold binary16 can decide: bcd_common.h)
+bool fast_similarity_applies(const bcd_hip_ctx *ctx, int D, int w, float tau)
+{
+    return ctx->fast_similarity && w == 1 && bcd_pairdist_rw_supported(D) && tau >= BCD_APPROX_TAU_MIN && tau <= BCD_APPROX_TAU_MAX;
+}
+
 // exact_mode: 0 = production kernels, flags checked here (one stream synchronisation); 1 = exact kernels with the compiler's division;
 // 2 = production kernels, flags copied to wk.h_counters[40] / [43] but NOT checked: the caller validates after its own
 // synchronisation with similarity_needs_redo().
@@ -244,14 +260,19 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     }
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int *d_flag = (int *)wk.counters.p + 40; // [0] range / count flag, [1] uniform-count scan, [3] borderline pairs
-    HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream));
+    // planes of exactly this problem already computed by the caller (its launches raised the flags in d_flag[0] themselves)?
+    const bool pre = wk.planes.ready && exact_mode != 1 && wk.planes.hist == d_hist && wk.planes.ns == d_ns && wk.planes.W == W && wk.planes.H == H &&
+                     wk.planes.D == D && wk.planes.b == b && wk.planes.tau == tau && w == 1;
+    wk.planes.ready = false;
+    if (pre) HIPCHK(ctx, hipMemsetAsync(d_flag + 1, 0, 3 * sizeof(int), wk.stream));
+    else HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream));
     wk.h_counters[40] = 0;
     wk.h_counters[43] = 0;
     wk.border_capacity = 0;
     // fixed samples per pixel, a power of two (the usual case): the distance kernel drops the sample-count products (exactly,
     // see k_pairdist).  One small reduction and one host round trip at the head of the chain (~30 us).
-    float uni_n = 0.f;
-    if (exact_mode != 1) {
+    float uni_n = pre ? wk.planes.uni_n : 0.f;
+    if (exact_mode != 1 && !pre) {
         HIPCHK(ctx, bcd_launch_uniform_n(d_ns, (int64_t)npix, d_flag + 1, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 41, d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 42, d_ns, sizeof(float), hipMemcpyDeviceToHost, wk.stream));
@@ -262,15 +283,17 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         if (wk.h_counters[41] == 0 && n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
     }
     // the approximate path keeps its T plane in binary16: thresholds it cannot decide safely take the exact kernels (bcd_common.h)
-    const bool fast = exact_mode != 1 && ctx->fast_similarity && w == 1 && bcd_pairdist_rw_supported(D) && tau >= BCD_APPROX_TAU_MIN &&
-                      tau <= BCD_APPROX_TAU_MAX;
+    const bool fast = exact_mode != 1 && fast_similarity_applies(ctx, D, w, tau);
     if (fast) {
         const int capacity = (int)std::min<size_t>(std::max<size_t>(npix, 1u << 16), 1u << 28);
         RCCHK(ensure(ctx, wk.border, (size_t)capacity * sizeof(uint2)));
         wk.border_capacity = capacity;
-        if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
-        HIPCHK(ctx, bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream));
-        if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
+        if (pre) { if (e0) --wk.ev_used; } // (nothing to time: the planes are there)
+        else {
+            if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
+            HIPCHK(ctx, bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream));
+            if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
+        }
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         BcdBorderline bl = { 0.f, (uint2 *)wk.border.p, d_flag + 3, capacity };
         HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream,
@@ -623,6 +646,8 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
     ctx->concurrent_scales = !(env && env[0] == '1');
     env = getenv("BCD_HIP_EXACT_SIMILARITY");
     ctx->fast_similarity = !(env && env[0] == '1');
+    env = getenv("BCD_HIP_STREAM_UPLOADS");
+    ctx->stream_uploads = !(env && env[0] == '0');
     *out = ctx;
     return BCD_HIP_OK;
 }
@@ -639,6 +664,8 @@ void bcd_hip_ctx_destroy(bcd_hip_ctx *ctx)
     for (int s = 0; s < MAX_SCALES; ++s)
         for (int k = 0; k < 5; ++k) if (ctx->pyr[s][k].p) (void)hipFree(ctx->pyr[s][k].p);
     if (ctx->ev_pyramid) (void)hipEventDestroy(ctx->ev_pyramid);
+    for (hipEvent_t ev : ctx->ev_upload) (void)hipEventDestroy(ev);
+    if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -898,10 +925,79 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
         d[5 + i] = d[i];
         if (prefilter) { RCCHK(ensure(ctx, ctx->host_stage[5 + i], sz[i] * sizeof(float))); d[5 + i] = (float *)ctx->host_stage[5 + i].p; }
     }
-    for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    // SpikeRemovalFilter::filter (src/cli/main.cpp:428-441) on the device copies: no second trip over PCIe
-    if (prefilter) HIPCHK(ctx, bcd_launch_spike(d[0], d[1], d[2], d[3], W, H, D, opt->spike_factor, d[5], d[6], d[7], d[8], ctx->stream));
-    RCCHK(bcd_hip_denoise(ctx, d[5], d[6], d[7], d[8], W, H, D, nb_scales, prm, d[4]));
+    // The frame arrives in row chunks on an upload stream; the lines that have arrived are prefiltered (SpikeRemovalFilter::filter,
+    // src/cli/main.cpp:428-441, on the device copies: no second trip over PCIe) and the finest scale's approximate distance planes -- the
+    // largest single kernel of the frame, and a function of the histograms alone -- are computed for them while the next chunk travels.
+    // Everything else needs the whole frame (pyramid, the marking order) and follows the last chunk.
+    const int b = prm->search_radius, tile = bcd_pairdist_rw_tile_lines();
+    const bool stream_in = ctx->stream_uploads && fast_similarity_applies(ctx, D, prm->patch_radius, prm->hist_dist_threshold) && H >= 256;
+    if (!stream_in) {
+        for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        if (prefilter) HIPCHK(ctx, bcd_launch_spike(d[0], d[1], d[2], d[3], W, H, D, opt->spike_factor, d[5], d[6], d[7], d[8], ctx->stream));
+    } else {
+        Work &wk = ctx->main;
+        if (!ctx->upload_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+        const int nd = bcd_delta_count(b);
+        RCCHK(ensure(ctx, wk.T, np * nd * sizeof(float)));
+        RCCHK(ensure(ctx, wk.Cn, np * nd));
+        RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+        int *d_flag = (int *)wk.counters.p + 40;
+        HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), ctx->stream));
+        // uniform power-of-two sample count: taken from the first pixel; the distance kernel checks every pixel against it and raises the
+        // flag that sends the scale to the exact kernels if the guess was wrong (k_pairdist_rw, range_flag bit 1)
+        // (a strided sample of 1024 pixels settles the usual non-uniform case -- adaptive sampling -- on the host at no cost)
+        float uni_n = 0.f;
+        {
+            int e = 0;
+            const float n0 = h_ns[0];
+            if (n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
+            const size_t stride = std::max<size_t>(1, np / 1024);
+            for (size_t i = 0; i < np && uni_n > 0.f; i += stride)
+                if (h_ns[i] != n0) uni_n = 0.f;
+        }
+        const int chunk = std::max(64, ((H + 7) / 8 + tile - 1) / tile * tile); // ~8 chunks, whole tile rows
+        const int tile_rows = (H + tile - 1) / tile;
+        int filtered = 0, tiles_done = 0, k = 0;
+        // the upload stream must not overwrite device copies an earlier frame's kernels may still read
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        // colours, sample counts and covariances first, whole (83 MB at 1080p; the prefilter and the distance kernel need them with the
+        // first histogram lines), then the histograms -- 87 % of the bytes -- in row chunks
+        for (int i : { 0, 1, 3 }) HIPCHK(ctx, hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->upload_stream));
+        for (int r0 = 0; r0 < H; r0 += chunk, ++k) {
+            const int r1 = std::min(H, r0 + chunk);
+            {
+                const size_t off = (size_t)r0 * W * D, n = (size_t)(r1 - r0) * W * D;
+                HIPCHK(ctx, hipMemcpyAsync(d[2] + off, h_hist + off, n * sizeof(float), hipMemcpyHostToDevice, ctx->upload_stream));
+            }
+            if ((int)ctx->ev_upload.size() <= k) {
+                hipEvent_t ev;
+                HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                ctx->ev_upload.push_back(ev);
+            }
+            HIPCHK(ctx, hipEventRecord(ctx->ev_upload[k], ctx->upload_stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload[k], 0));
+            int avail = r1;
+            if (prefilter) { // a filtered line reads its own and the two adjacent input lines (clamped inward at the frame border)
+                const int upto = r1 == H ? H : std::max(0, r1 - 1);
+                HIPCHK(ctx, bcd_launch_spike_rows(d[0], d[1], d[2], d[3], W, H, D, opt->spike_factor, d[5], d[6], d[7], d[8], filtered, upto, ctx->stream));
+                filtered = std::max(filtered, upto);
+                avail = filtered;
+            }
+            // a tile row reads its own lines and the b lines below them
+            const int t_end = avail == H ? tile_rows : std::max(0, (avail - b) / tile);
+            if (t_end > tiles_done) {
+                HIPCHK(ctx, bcd_launch_pairdist_rw_rows(d[7], d[6], W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, tiles_done, t_end, ctx->stream));
+                tiles_done = t_end;
+            }
+        }
+        wk.planes.ready = true; wk.planes.hist = d[7]; wk.planes.ns = d[6]; wk.planes.W = W; wk.planes.H = H; wk.planes.D = D; wk.planes.b = b;
+        wk.planes.tau = prm->hist_dist_threshold; wk.planes.uni_n = uni_n;
+    }
+    {
+        const int rc = bcd_hip_denoise(ctx, d[5], d[6], d[7], d[8], W, H, D, nb_scales, prm, d[4]);
+        ctx->main.planes.ready = false; // (consumed by the finest scale's similarity stage; never left behind by a call that failed earlier)
+        if (rc != BCD_HIP_OK) return rc;
+    }
     // checkAndPutToZeroNegativeInfNaNValues (src/cli/main.cpp:389-420, 470)
     if (opt && opt->zero_bad_values) HIPCHK(ctx, bcd_launch_zero_bad(d[4], (int64_t)np * 3, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_out, d[4], sz[4] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

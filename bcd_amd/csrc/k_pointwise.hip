@@ -128,9 +128,9 @@ __global__ void k_interpolate(const float *__restrict__ lo, int w, int h, int D,
 // SpikeRemovalFilter::filter (src/core/SpikeRemovalFilter.cpp:18-116), float-abs semantics; out of place.
 __global__ void k_spike(const float *__restrict__ col, const float *__restrict__ ns, const float *__restrict__ hist,
                         const float *__restrict__ cov, int W, int H, int D, float factor,
-                        float *__restrict__ ocol, float *__restrict__ ons, float *__restrict__ ohist, float *__restrict__ ocov)
+                        float *__restrict__ ocol, float *__restrict__ ons, float *__restrict__ ohist, float *__restrict__ ocov, int row_begin)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    int c = blockIdx.x * blockDim.x + threadIdx.x, l = row_begin + blockIdx.y;
     if (c >= W) return;
     int cl = l < 1 ? 1 : (l > H - 2 ? H - 2 : l);
     int cc = c < 1 ? 1 : (c > W - 2 ? W - 2 : c);
@@ -273,11 +273,19 @@ hipError_t bcd_launch_interpolate(int mode, const float *lo, int w, int h, int D
     else hipLaunchKernelGGL(k_interpolate<2>, dim3(nblk(n, 256)), dim3(256), 0, st, lo, w, h, D, hi, W, H);
     return hipGetLastError();
 }
+// lines [row_begin, row_end) of the filtered images (a line reads its own and the two adjacent input lines, clamped inward)
+hipError_t bcd_launch_spike_rows(const float *col, const float *ns, const float *hist, const float *cov, int W, int H, int D,
+                                 float factor, float *ocol, float *ons, float *ohist, float *ocov, int row_begin, int row_end, hipStream_t st)
+{
+    if (row_end <= row_begin) return hipSuccess;
+    hipLaunchKernelGGL(k_spike, dim3((W + 63) / 64, row_end - row_begin), dim3(64), 0, st, col, ns, hist, cov, W, H, D, factor, ocol, ons, ohist, ocov, row_begin);
+    return hipGetLastError();
+}
+
 hipError_t bcd_launch_spike(const float *col, const float *ns, const float *hist, const float *cov, int W, int H, int D,
                             float factor, float *ocol, float *ons, float *ohist, float *ocov, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_spike, dim3((W + 63) / 64, H), dim3(64), 0, st, col, ns, hist, cov, W, H, D, factor, ocol, ons, ohist, ocov);
-    return hipGetLastError();
+    return bcd_launch_spike_rows(col, ns, hist, cov, W, H, D, factor, ocol, ons, ohist, ocov, 0, H, st);
 }
 
 hipError_t bcd_launch_accumulate_samples(const float *samples, const float *weights, int64_t npix, int spp, int nbins, float gamma,

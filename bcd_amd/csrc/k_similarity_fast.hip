@@ -70,7 +70,7 @@ template <int D> struct RwLayout {
 template <int D, bool UNI>
 __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H,
                                                               int b, __half *__restrict__ T, uint8_t *__restrict__ Cn, int *range_flag,
-                                                              float uni_n)
+                                                              float uni_n, int tile_row0 /* first tile row of this launch */)
 {
     using L = RwLayout<D>;
     constexpr int Q = D / 4, NPRE = L::NPRE;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
         const int xcd = id & 7, k = id >> 3, q = nt >> 3, rem = nt & 7;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
     }
-    const int col0 = (tile % gridDim.x) * RW_TW, row0 = (tile / gridDim.x) * RW_TH; // row0 % 4 == 0: line g of the image lives in slot g & 3
+    const int col0 = (tile % gridDim.x) * RW_TW, row0 = (tile / gridDim.x + tile_row0) * RW_TH; // row0 % 4 == 0: line g of the image lives in slot g & 3
     const int c = col0 + lane, r = row0 + ty;
     const bool inside = (c < W) && (r < H);
     const size_t plane = (size_t)W * H;
@@ -314,10 +314,18 @@ __global__ __launch_bounds__(256) void k_max_rel_dev(const __half *__restrict__ 
 // 1 if the fast (approximate + verify) path has a kernel for this histogram depth
 int bcd_pairdist_rw_supported(int D) { return D == 60 || D == 36 || D == 24; }
 
-hipError_t bcd_launch_pairdist_rw(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,
-                                  float uni_n, hipStream_t st)
+// tile rows [tile_row_begin, tile_row_end) of the frame (a tile row = RW_TH image lines; end < 0: to the last one).  A launch reads the
+// histogram lines of its tile rows and the b lines below them: callers that stream the frame in (bcd_hip_denoise_host_ex) launch the tile rows
+// whose lines have arrived.
+int bcd_pairdist_rw_tile_lines() { return RW_TH; }
+
+hipError_t bcd_launch_pairdist_rw_rows(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,
+                                       float uni_n, int tile_row_begin, int tile_row_end, hipStream_t st)
 {
-    dim3 grid((W + RW_TW - 1) / RW_TW, (H + RW_TH - 1) / RW_TH), block(RW_THREADS);
+    const int tile_rows = (H + RW_TH - 1) / RW_TH;
+    if (tile_row_end < 0 || tile_row_end > tile_rows) tile_row_end = tile_rows;
+    if (tile_row_begin < 0 || tile_row_begin >= tile_row_end) return tile_row_begin == tile_row_end ? hipSuccess : hipErrorInvalidValue;
+    dim3 grid((W + RW_TW - 1) / RW_TW, tile_row_end - tile_row_begin), block(RW_THREADS);
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
 #define BCD_RW_LAUNCH(DD, UU)                                                                                        \
@@ -332,7 +340,7 @@ hipError_t bcd_launch_pairdist_rw(const float *hist, const float *ns, int W, int
             if (e != hipSuccess) return e;                                                                           \
             if (dev >= 0 && dev < 64) granted[dev].store(1);                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, static_cast<__half *>(T), Cn, d_range_flag, uni_n); \
+        hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, static_cast<__half *>(T), Cn, d_range_flag, uni_n, tile_row_begin); \
         return hipGetLastError();                                                                                    \
     }
 #define BCD_RW_DEPTH(DD) case DD: if (uni_n > 0.f) BCD_RW_LAUNCH(DD, true) else BCD_RW_LAUNCH(DD, false)
@@ -345,6 +353,12 @@ hipError_t bcd_launch_pairdist_rw(const float *hist, const float *ns, int W, int
 #undef BCD_RW_DEPTH
 #undef BCD_RW_LAUNCH
     return hipErrorInvalidValue;
+}
+
+hipError_t bcd_launch_pairdist_rw(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,
+                                  float uni_n, hipStream_t st)
+{
+    return bcd_launch_pairdist_rw_rows(hist, ns, W, H, D, b, T, Cn, d_range_flag, uni_n, 0, -1, st);
 }
 
 hipError_t bcd_launch_verify_pairs(const float *hist, const float *ns, int W, int H, int D, int b, float tau, const void *list, const int *d_count,

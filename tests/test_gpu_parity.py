@@ -1211,3 +1211,34 @@ def test_release_engines_gives_the_memory_back(hipctx):
     assert before - after > 640 * 360 * 85 * 3          # at least the distance planes of scale 0 came back
     ok, b_, _ = core.denoise(col, ns, hist, cov, nscales=2, seed=3)
     assert ok and rel_linf(b_, a) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spike_factor", [0.0, 2.0])
+def test_streamed_host_upload_equals_the_resident_path(hipctx, spike_factor):
+    """bcd_hip_denoise_host_ex on frames of >= 256 lines uploads in row chunks and computes the finest scale's distance planes (and
+    the prefilter) for the lines that have arrived: the result must be the resident-input result -- same kernels, another launch
+    partition -- with and without the prefilter, and also when the uniform-sample-count guess taken from the first pixel is wrong
+    (the kernel's own check sends the scale to the exact kernels)"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H = 200, 300
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 9, 0.2, 0.01)
+    prm = bh.default_params(m=1.0, random_order=1, seed=5)
+    for variant in ("uniform", "one pixel differs"):
+        if variant != "uniform":
+            ns = ns.copy(); hist = hist.copy()
+            ns[211, 77] = 15.0                       # (the first pixel still says 16)
+            hist[211, 77] *= 15.0 / 16.0
+        got = hipctx.denoise_host(col, ns, hist, cov, 3, prm, spike_factor=spike_factor)
+        path = hipctx.stats(0).similarity_path
+        d = dev(col, ns, hist, cov)
+        if spike_factor > 0:
+            d = hipctx.spike_filter(*d, spike_factor)
+        want = hipctx.denoise(*d, 3, prm).cpu().numpy()
+        assert rel_linf(got, want) < 1e-5
+        # uniform counts: both paths ran the approximate-planes kernels; a single odd pixel the host's sample misses: the streamed planes
+        # were computed with the uniform formula, the kernel's per-pixel check caught it and the scale was redone with the exact kernels
+        # (with the prefilter the odd pixel may itself be replaced by a neighbour: both outcomes are legitimate there)
+        if variant == "uniform" or spike_factor == 0.0:
+            assert (path, hipctx.stats(0).similarity_path) == ((1, 1) if variant == "uniform" else (0, 1))
