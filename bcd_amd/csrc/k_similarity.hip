@@ -315,10 +315,43 @@ __device__ inline int lane_down(int v)     { return __shfl_down(v, 1); }
 constexpr int FWD_RB = 4;
 // APPROX: the planes come from k_pairdist_rw (k_similarity_fast.hip); tau is then tau (1 - delta), pairs up to bl.tau_hi are
 // appended to the borderline list (their bit is decided by k_verify_pairs)
-__device__ inline void borderline_append(const BcdBorderline &bl, uint32_t pix, uint32_t didx)
+// The borderline pairs of a wavefront are collected as bit words (one bit per displacement, like the forward words) and appended at
+// the end of the kernel with ONE atomic on the list counter per wavefront: a counter serves ~50 same-address atomics per microsecond,
+// and a textured 1080p frame has 2e5 borderline pairs at scale 0 (one atomic per pair: 2.2 ms in this kernel, r3 profile).
+__device__ inline int wave_exclusive_sum(int v, int lane, int *total)
 {
-    const int slot = atomicAdd(bl.counter, 1);
-    if (slot < bl.capacity) bl.list[slot] = make_uint2(pix, didx);
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    *total = __shfl(incl, 63);
+    return incl - v;
+}
+template <int NW>
+__device__ inline void borderline_flush(const BcdBorderline &bl, const uint32_t (&bword)[NW], const uint32_t (&pix)[NW], int word_index, int lane)
+{
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) mine += __popc(bword[i]);
+    if (__ballot(mine != 0) == 0) return; // (the usual case: nothing near the threshold)
+    int total = 0;
+    const int before = wave_exclusive_sum(mine, lane, &total);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(bl.counter, total);
+    base = __shfl(base, 0);
+    int slot = base + before;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        uint32_t m = bword[i];
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            if (slot < bl.capacity) bl.list[slot] = make_uint2(pix[i], (uint32_t)(32 * word_index + bit));
+            ++slot;
+        }
+    }
 }
 
 // plane element type: the approximate planes hold T in binary16 (bcd_common.h), the exact ones in fp32
@@ -344,9 +377,9 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const typename PlaneT<APPRO
     size_t off[FWD_RB + 2];
 #pragma unroll
     for (int i = 0; i < FWD_RB + 2; ++i) off[i] = (size_t)min(max(rb - 1 + i, 0), H - 1) * W + cc;
-    uint32_t word[FWD_RB];
+    uint32_t word[FWD_RB], bword[FWD_RB];
 #pragma unroll
-    for (int i = 0; i < FWD_RB; ++i) word[i] = 0;
+    for (int i = 0; i < FWD_RB; ++i) { word[i] = 0; bword[i] = 0; }
     const int d_end = min(nd, 32 * wi + 32);
     for (int didx = 32 * wi; didx < d_end; ++didx) {
         int dl = 0, dc = didx;
@@ -378,7 +411,7 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const typename PlaneT<APPRO
                     // absorbs (its half-width is 2^-10, the planes' error 5e-4); n == 0 (0 / 0 in the reference) is never similar
                     const float fn = (float)n;
                     if (n > 0 && s <= tau * fn) word[i] |= 1u << (didx & 31);
-                    else if (n > 0 && writer && s <= bl.tau_hi * fn) borderline_append(bl, (uint32_t)(r * W + c), (uint32_t)didx);
+                    else if (n > 0 && writer && s <= bl.tau_hi * fn) bword[i] |= 1u << (didx & 31);
                 } else {
                     const float d = s / (float)n; // 0/0 = NaN -> not similar
                     if (d <= tau) word[i] |= 1u << (didx & 31);
@@ -389,6 +422,12 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const typename PlaneT<APPRO
 #pragma unroll
     for (int i = 0; i < FWD_RB; ++i)
         if (writer && rb + i < H) fwd[((size_t)(rb + i) * W + c) * fwords + wi] = word[i];
+    if (APPROX) {
+        uint32_t pix[FWD_RB];
+#pragma unroll
+        for (int i = 0; i < FWD_RB; ++i) pix[i] = (uint32_t)((rb + i) * W + c);
+        borderline_flush<FWD_RB>(bl, bword, pix, wi, lane);
+    }
 }
 
 // The same with four columns per lane (image widths that are multiples of 4): 16-byte plane loads instead of 4-byte ones -- the
@@ -409,11 +448,11 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APP
     size_t off[FWD_RB + 2];
 #pragma unroll
     for (int i = 0; i < FWD_RB + 2; ++i) off[i] = (size_t)min(max(rb - 1 + i, 0), H - 1) * W + cc;
-    uint32_t word[FWD_RB][4];
+    uint32_t word[FWD_RB][4], bword[FWD_RB * 4];
 #pragma unroll
     for (int i = 0; i < FWD_RB; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) word[i][j] = 0;
+        for (int j = 0; j < 4; ++j) { word[i][j] = 0; bword[i * 4 + j] = 0; }
     const int d_end = min(nd, 32 * wi + 32);
     for (int didx = 32 * wi; didx < d_end; ++didx) {
         int dl = 0, dc = didx;
@@ -455,7 +494,7 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APP
                     if (APPROX) { // (no division: see k_fwd_masks_w1)
                         const float fn = (float)n;
                         if (n > 0 && s <= tau * fn) word[i][j] |= 1u << (didx & 31);
-                        else if (n > 0 && writer && s <= bl.tau_hi * fn) borderline_append(bl, (uint32_t)(r * W + cj), (uint32_t)didx);
+                        else if (n > 0 && writer && s <= bl.tau_hi * fn) bword[i * 4 + j] |= 1u << (didx & 31);
                     } else {
                         const float d = s / (float)n; // 0/0 = NaN -> not similar
                         if (d <= tau) word[i][j] |= 1u << (didx & 31);
@@ -471,6 +510,14 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APP
 #pragma unroll
                 for (int j = 0; j < 4; ++j) fwd[((size_t)(rb + i) * W + c + j) * fwords + wi] = word[i][j];
             }
+    }
+    if (APPROX) {
+        uint32_t pix[FWD_RB * 4];
+#pragma unroll
+        for (int i = 0; i < FWD_RB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pix[i * 4 + j] = (uint32_t)((rb + i) * W + c + j);
+        borderline_flush<FWD_RB * 4>(bl, bword, pix, wi, lane);
     }
 }
 

@@ -258,13 +258,27 @@ __global__ __launch_bounds__(64) void k_verify_pairs(const float *__restrict__ h
             const size_t x = (size_t)xr * W + xc, y = (size_t)(xr + dl) * W + (xc + dc);
             const float *h1 = hist + x * D, *h2 = hist + y * D;
             const float n1 = ns[x], n2 = ns[y], n12 = n1 * n2;
-            for (int k = 0; k < D; ++k) {
-                const float b1 = h1[k], b2 = h2[k], s = b1 + b2;
-                if (s <= 1.f) continue;
+            // one bin of DenoisingUnit.cpp:379-383, in the reference's order
+            auto bin = [&](float b1, float b2) __attribute__((always_inline)) {
+                const float s = b1 + b2;
+                if (s <= 1.f) return;
                 ++cnt;
                 const float diff = n2 * b1 - n1 * b2;
                 sum += diff * diff / (n12 * s);
-            }
+            };
+            if ((D & 3) == 0) { // whole 16-byte groups (pixel strides are multiples of 16 bytes then): five groups of each histogram in flight
+                const float4 *v1 = reinterpret_cast<const float4 *>(h1), *v2 = reinterpret_cast<const float4 *>(h2);
+                const int Q = D >> 2;
+                for (int q0 = 0; q0 < Q; q0 += 5) {
+                    float4 a[5], c[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { const int q = min(q0 + u, Q - 1); a[u] = v1[q]; c[u] = v2[q]; }
+#pragma unroll
+                    for (int u = 0; u < 5; ++u)
+                        if (q0 + u < Q) { bin(a[u].x, c[u].x); bin(a[u].y, c[u].y); bin(a[u].z, c[u].z); bin(a[u].w, c[u].w); }
+                }
+            } else
+                for (int k = 0; k < D; ++k) bin(h1[k], h2[k]);
         }
         // patch order: ((((t0 + t1) + t2) + ...) + t8), counts as integers
         float tot = 0.f;
@@ -365,7 +379,8 @@ hipError_t bcd_launch_verify_pairs(const float *hist, const float *ns, int W, in
                                    int capacity, uint32_t *fwd, hipStream_t st)
 {
     const int fwords = (bcd_delta_count(b) + 31) / 32;
-    hipLaunchKernelGGL(k_verify_pairs, dim3(2048), dim3(64), 0, st, hist, ns, W, H, D, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
+    // (the number of pairs is on the device: a fixed grid of 16 wavefronts per CU; with nothing listed every wavefront leaves at once)
+    hipLaunchKernelGGL(k_verify_pairs, dim3(4096), dim3(64), 0, st, hist, ns, W, H, D, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
     return hipGetLastError();
 }
 

@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--spp", type=int, default=32)
     ap.add_argument("--sigma", type=float, default=0.35, help="synthetic noise level (0.35 + 1%% spikes = SURVEY probe)")
     ap.add_argument("--spikes", type=float, default=0.01)
+    ap.add_argument("--pattern", type=int, default=0, help="synthetic scene: 0 = ramps + 16-pixel checker (the SURVEY probe scene, headline), 1 = band-limited texture")
     ap.add_argument("--search-radius", type=int, default=6)
     ap.add_argument("--skip-prob", type=float, default=1.0, help="-m of bcd_cli")
     ap.add_argument("--random-order", type=int, default=1, help="-r of bcd_cli")
@@ -142,7 +143,7 @@ def main():
     extras = {}   # untimed legs reported next to the headline
     parallelism = "single"
     if world == 1 and not args.band_path:
-        col, ns, hist, cov = core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes)
+        col, ns, hist, cov = core.synthetic_scene(W, H, args.spp, 1234, args.sigma, args.spikes, pattern=args.pattern)
         d_in = [torch.from_numpy(a).cuda() for a in (col, ns, hist, cov)]
         out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 
@@ -373,8 +374,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic frame (%d spp, sigma %.2f, spikes %.2f), %d-scale, b=%d w=1 d=1 e=1e-8, -m %g -r %d (seeded), no prefilter"
-                                   % (W, H, args.spp, args.sigma, args.spikes, S, b, args.skip_prob, args.random_order),
+            "config": {"workload": "%dx%d synthetic frame (%s%d spp, sigma %.2f, spikes %.2f), %d-scale, b=%d w=1 d=1 e=1e-8, -m %g -r %d (seeded), no prefilter"
+                                   % (W, H, "texture pattern, " if args.pattern else "", args.spp, args.sigma, args.spikes, S, b, args.skip_prob, args.random_order),
                        "parallelism": parallelism, "per_scale": scales},
             "roofline": roofline,
         }

@@ -1242,3 +1242,25 @@ def test_streamed_host_upload_equals_the_resident_path(hipctx, spike_factor):
         # (with the prefilter the odd pixel may itself be replaced by a neighbour: both outcomes are legitimate there)
         if variant == "uniform" or spike_factor == 0.0:
             assert (path, hipctx.stats(0).similarity_path) == ((1, 1) if variant == "uniform" else (0, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sigma,spp", [(0.35, 32), (0.10, 32), (0.35, 8)])
+def test_textured_frame_masks_and_parity(hipctx, sigma, spp):
+    """the band-limited texture scene (SyntheticScene pattern 1): distances spread continuously across the threshold, so the approximate
+    planes leave thousands of borderline pairs to the exact re-evaluation (wave-aggregated list appends, k_verify_pairs) -- masks and
+    counts must still be the oracle's bit for bit, and the denoised frame within tolerance"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H = 200, 120
+    col, ns, hist, cov = core.synthetic_scene(W, H, spp, 1234, sigma, 0.0, pattern=1)
+    d = dev(col, ns, hist, cov)
+    mask, cnt = hipctx.similarity_masks(d[2], d[1], 1, 6, 1.0)
+    wmask, wcnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask) and np.array_equal(cnt.cpu().numpy(), wcnt)
+    prm = bh.default_params(m=1.0, random_order=1, seed=3)
+    got = hipctx.denoise(*d, 1, prm).cpu().numpy()
+    st = hipctx.stats(0)
+    assert st.similarity_path == 1 and st.borderline_pairs > 100          # the threshold band was populated, and decided exactly
+    want = ol.denoise_mono(col, ns, hist, cov, ol.params(m=1.0), order=_orders(W, H, 1, 1, 3, 1)[0])
+    assert rel_linf(got, want) < TOL

@@ -1,16 +1,32 @@
 #!/bin/bash
-# GPU box: regenerate the round's evidence under gpurun_out/ (copied into profiles/ afterwards)
+# GPU box: regenerate the round's evidence under gpurun_out/ (copied into profiles/ afterwards by tools/collect_profiles.py)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 tools/prof.sh final_noextras --no-extras --steps 10 --warmup 2 > /dev/null
 tools/prof.sh final_default --steps 10 --warmup 2 > /dev/null
 BCD_HIP_SERIAL_SCALES=1 tools/prof.sh final_serial --no-extras --steps 10 --warmup 2 > /dev/null
 DB=$(ls gpurun_out/prof_final_noextras/*.db | head -1)
-python tools/timeline.py $DB 6.75 > gpurun_out/final_timeline.txt
+python tools/timeline.py $DB 6.2 > gpurun_out/final_timeline.txt
 for t in final_noextras final_default final_serial; do grep '^{' gpurun_out/${t}_bench.log | tail -1 > gpurun_out/${t}_line.json; done
 python bench.py --steps 30 --warmup 5 > gpurun_out/final_bench_unprofiled.log 2>&1
 grep '^{' gpurun_out/final_bench_unprofiled.log | tail -1 > gpurun_out/final_unprofiled_line.json
-python tools/exp_host.py 1280 720 2>&1 | tail -1; python tools/exp_host.py 1920 1080 2>&1 | tail -1
+# HBM traffic of the pair-distance kernel (TCC counters, separate passes)
+tools/pmc_traffic.sh > gpurun_out/final_pmc_traffic.log 2>&1
+# SQ counters of the kernels that ship
+S1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"
+S2="SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"
+S3="SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT"
+i=1
+for S in "$S1" "$S2" "$S3"; do
+  timeout 300 tools/pmc_any.sh final_pd_s$i "$S" pairdist_rw python $R/tools/exp_similarity.py --quick > /dev/null 2>&1
+  timeout 300 tools/pmc_any.sh final_eig_s$i "$S" jacobi27 python $R/tools/exp_eig.py 32768 > /dev/null 2>&1
+  BCD_HIP_SERIAL_SCALES=1 timeout 300 tools/pmc_any.sh final_est_s$i "$S" bayes python $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
+  i=$((i+1))
+done
+python tools/exp_eig.py 32768 > gpurun_out/final_eig.log 2>&1
+python tools/exp_eig.py 65536 >> gpurun_out/final_eig.log 2>&1
+for cfg in "1280 720" "1920 1080" "3840 2160"; do python tools/exp_host.py $cfg 2>&1 | tail -1; BCD_HIP_STREAM_UPLOADS=0 python tools/exp_host.py $cfg 2>&1 | tail -1; done > gpurun_out/final_host.log
 for cfg in "--width 1280 --height 720" "--width 3840 --height 2160 --steps 6" "--width 3840 --height 2160 --search-radius 12 --steps 4"; do
   python bench.py --no-extras --no-cpu-baseline $cfg 2>&1 | tail -1 | cut -c1-260
-done
+done > gpurun_out/final_sizes.log
+cat gpurun_out/final_host.log gpurun_out/final_sizes.log; tail -3 gpurun_out/final_eig.log
