@@ -334,7 +334,10 @@ __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
     for (int k = 0; k < K; ++k) {
         const float d = bcast_lane(m[k], k); // (row k has not been scaled yet: its scale is still 1)
         ok = ok && (d > 0.f);
-        const float inv_d = 1.f / d;
+        // 1 / d to an ulp (hardware reciprocal + one Newton step): the pivots of a Gauss-Jordan sweep need no correctly rounded quotient,
+        // and the compiler's IEEE division is a dozen instructions on the critical path of each of the 27 steps
+        float inv_d = __builtin_amdgcn_rcpf(d);
+        inv_d = fmaf(fmaf(-d, inv_d, 1.f), inv_d, inv_d);
         const bool pivot_row = (lane == k);
         // row r != k: a_rc - (a_rk / d) a_kc -- one fma per element.  The pivot row's own step, a_kc / d, is only recorded in its
         // scale: a row's scale cancels out of every later update of that row (the multiplier a_rk / d' carries it, the pivot row of
@@ -453,6 +456,8 @@ __device__ void inverse27(float *M, float *S0, float *S1, float *fl, float *prm,
 }
 
 // out[3o+i][c] = delta*(r==c) - sign * sum_j N_o[i][j] * in[3o+j][c]   (block-diagonal noise covariance times a dense matrix)
+// (one element per lane and pass.  A column-per-lane form with compile-time block indices -- a third of the instructions, 27 lanes of
+// each half busy -- was measured in r3: the finish kernel went from 0.79 to 0.86 ms; the phase waits on LDS latency, not on issue slots)
 __device__ void noise_times27(float *out, const float *noise, const float *in, int lane, bool identity_minus)
 {
     for (int e = lane; e < K * K; e += 64) {
@@ -755,12 +760,10 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     noise_times27(V, noise, Bm, lane, true);       // V  = F
     mfma27<false, false>(A, LD, V, LD, Cm, LD, nullptr, K, lane);  // A  = F C
     mfma27<true, false>(Bm, LD, A, LD, V, LD, nullptr, K, lane);   // Bm = F C F^T
-    for (int e = lane; e < K * K; e += 64) {       // exact symmetry (lower triangle wins)
+    for (int e = lane; e < K * K; e += 64) {       // exact symmetry (lower triangle wins; reads and writes touch different elements)
         int r = e / K, c = e - r * K;
-        if (r < c) Cm[r * LD + c] = Bm[c * LD + r];
+        if (r < c) Bm[r * LD + c] = Bm[c * LD + r];
     }
-    __syncthreads();
-    for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; if (r < c) Bm[r * LD + c] = Cm[r * LD + c]; }
     __syncthreads();
     add_noise27(Bm, noise, lane, +1.f);
     inverse27(Bm, A, V, fl, cs, lane, min_eig);
@@ -1047,12 +1050,10 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float
     noise_times27(V, noise, Bm, lane, true);       // V  = F = I - N Cinv1
     mfma27<false, false>(A, LD, V, LD, Cm, LD, nullptr, K, lane);  // A  = F C
     mfma27<true, false>(Bm, LD, A, LD, V, LD, nullptr, K, lane);   // Bm = F C F^T
-    for (int e = lane; e < K * K; e += 64) {       // exact symmetry (lower triangle wins)
+    for (int e = lane; e < K * K; e += 64) {       // exact symmetry (lower triangle wins; reads and writes touch different elements)
         int r = e / K, c = e - r * K;
-        if (r < c) Cm[r * LD + c] = Bm[c * LD + r];
+        if (r < c) Bm[r * LD + c] = Bm[c * LD + r];
     }
-    __syncthreads();
-    for (int e = lane; e < K * K; e += 64) { int r = e / K, c = e - r * K; if (r < c) Bm[r * LD + c] = Cm[r * LD + c]; }
     __syncthreads();
     add_noise27(Bm, noise, lane, +1.f);
     inverse27(Bm, A, V, fl, cs, lane, min_eig);
