@@ -164,6 +164,8 @@ struct DBuf {
 
 } // namespace
 
+namespace { struct Watchdog; }
+
 struct bcd_hip_multi {
     int n = 0;
     int devices[MAX_RANKS];
@@ -205,7 +207,8 @@ struct bcd_hip_multi {
     // process or device) has died.
     std::mutex comm_mutex;
     bool comm_aborted = false;
-    int frame_timeout_s = 600;
+    Watchdog *watchdog = nullptr;             // created with the first RCCL frame, joined by bcd_hip_multi_destroy
+    int frame_timeout_ms = 600 * 1000;        // BCD_HIP_MULTI_TIMEOUT_S / bcd_hip_multi_set_frame_timeout
     // progress reporting (IDenoiser::setProgressCallback): every (rank, scale) adds its owned pixels twice, like bcd_hip_denoise
     bcd_hip_progress_fn progress_fn = nullptr;
     void *progress_user = nullptr;
@@ -247,30 +250,58 @@ void progress_add(bcd_hip_multi *m, double share)
     m->progress_fn((float)(m->progress_done / m->progress_total), m->progress_user);
 }
 
-// one per frame on the RCCL transport: a frame that has not finished after frame_timeout_s is failed (which aborts the communicators)
-struct FrameWatchdog {
-    bcd_hip_multi *m;
+// A frame of several ranks that has not finished after frame_timeout_s is failed (which releases the host barriers and, on the RCCL
+// transport, aborts the communicators).  One watchdog thread
+// per handle, started with the first such frame and parked between frames; a frame arms it on entry and disarms it on exit (two
+// mutex sections: nothing a 3 ms step would notice, unlike a thread per frame).
+struct Watchdog {
     std::mutex mu;
     std::condition_variable cv;
-    bool done = false;
     std::thread th;
-    explicit FrameWatchdog(bcd_hip_multi *m_) : m(m_)
+    bool armed = false, quit = false;
+    unsigned long long epoch = 0; // frames armed so far: a wait that times out only fires if its own frame is still the armed one
+    void run(bcd_hip_multi *m)
     {
-        if (!m->use_rccl || m->n < 2 || m->frame_timeout_s <= 0) return;
-        th = std::thread([this]() {
-            std::unique_lock<std::mutex> lk(mu);
-            if (!cv.wait_for(lk, std::chrono::seconds(m->frame_timeout_s), [this]() { return done; }))
-                fail(m, "frame timed out on the RCCL transport (a peer rank has stopped?): communicators aborted");
-        });
-    }
-    ~FrameWatchdog()
-    {
-        if (!th.joinable()) return;
-        { std::lock_guard<std::mutex> lk(mu); done = true; }
-        cv.notify_all();
-        th.join();
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this]() { return armed || quit; });
+            if (quit) return;
+            const unsigned long long mine = epoch;
+            const bool released = cv.wait_for(lk, std::chrono::milliseconds(m->frame_timeout_ms), [this, mine]() { return quit || !armed || epoch != mine; });
+            if (quit) return;
+            if (!released) {
+                armed = false;
+                lk.unlock();
+                fail(m, "frame timed out (a peer rank has stopped?): the frame is abandoned, RCCL communicators aborted");
+                lk.lock();
+            }
+        }
     }
 };
+
+struct FrameWatchdog { // scope guard of one frame
+    Watchdog *w = nullptr;
+    explicit FrameWatchdog(bcd_hip_multi *m);
+    ~FrameWatchdog()
+    {
+        if (!w) return;
+        { std::lock_guard<std::mutex> lk(w->mu); w->armed = false; }
+        w->cv.notify_all();
+    }
+};
+
+FrameWatchdog::FrameWatchdog(bcd_hip_multi *m)
+{
+    if (m->n < 2 || m->frame_timeout_ms <= 0) return; // (both transports: a rank that stops also stalls the in-process barriers)
+    if (!m->watchdog) {
+        m->watchdog = new Watchdog();
+        Watchdog *wd = m->watchdog;
+        wd->th = std::thread([wd, m]() { wd->run(m); });
+    }
+    w = m->watchdog;
+    { std::lock_guard<std::mutex> lk(w->mu); w->armed = true; ++w->epoch; }
+    w->cv.notify_all();
+}
 
 #define MCHK(m, rank, expr)                                                                                            \
     do {                                                                                                               \
@@ -686,7 +717,7 @@ int bcd_hip_multi_create(bcd_hip_multi **out, const int *devices, int n_ranks)
     memset(&m->stats, 0, sizeof(m->stats));
     for (int c = 0; c <= MAX_S; ++c) { m->barrier[c].parties = n_ranks; m->barrier[c].abort_flag = &m->abort_flag; }
     for (int r = 0; r < n_ranks; ++r) m->gate[r].abort_flag = &m->abort_flag;
-    if (const char *t = getenv("BCD_HIP_MULTI_TIMEOUT_S")) m->frame_timeout_s = atoi(t);
+    if (const char *t = getenv("BCD_HIP_MULTI_TIMEOUT_S")) m->frame_timeout_ms = atoi(t) * 1000;
     const char *ordered = getenv("BCD_HIP_MULTI_ORDERED");
     m->ordered = m->use_rccl || (ordered && atoi(ordered) != 0);
     m->stats.n_ranks = n_ranks;
@@ -698,6 +729,13 @@ int bcd_hip_multi_create(bcd_hip_multi **out, const int *devices, int n_ranks)
 void bcd_hip_multi_destroy(bcd_hip_multi *m)
 {
     if (!m) return;
+    if (m->watchdog) {
+        { std::lock_guard<std::mutex> lk(m->watchdog->mu); m->watchdog->quit = true; }
+        m->watchdog->cv.notify_all();
+        m->watchdog->th.join();
+        delete m->watchdog;
+        m->watchdog = nullptr;
+    }
     for (int c = 0; c <= MAX_S; ++c)
         if (m->comm_ready[c])
             for (int r = 0; r < m->n; ++r)
@@ -731,6 +769,13 @@ int bcd_hip_multi_set_progress_callback(bcd_hip_multi *m, bcd_hip_progress_fn fn
     std::lock_guard<std::mutex> lk(m->progress_mutex);
     m->progress_fn = fn;
     m->progress_user = user;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_multi_set_frame_timeout(bcd_hip_multi *m, int milliseconds)
+{
+    if (!m || milliseconds < 0) return BCD_HIP_EINVAL;
+    m->frame_timeout_ms = milliseconds; // (read when a frame arms the watchdog: takes effect with the next frame)
     return BCD_HIP_OK;
 }
 

@@ -41,7 +41,7 @@ SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
     "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_set_cu_share", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_set_progress_callback",
-    "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_set_progress_callback", "bcd_hip_multi_set_comm_trace", "bcd_hip_multi_get_comm_trace", "bcd_hip_multi_denoise_host",
+    "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_set_progress_callback", "bcd_hip_multi_set_frame_timeout", "bcd_hip_multi_set_comm_trace", "bcd_hip_multi_get_comm_trace", "bcd_hip_multi_denoise_host",
     "bcd_hip_multi_unique_id", "bcd_hip_multi_create_rank", "bcd_hip_multi_rank_configure", "bcd_hip_multi_rank_upload", "bcd_hip_multi_rank_step",
     "bcd_hip_multi_rank_download",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_similarity_masks_deferred", "bcd_hip_similarity_masks_verdict", "bcd_hip_similarity_masks_exact", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
@@ -388,6 +388,9 @@ class MultiDenoiser:
 
     def set_comm_trace(self, on):
         lib().bcd_hip_multi_set_comm_trace(self.h, 1 if on else 0)
+
+    def set_frame_timeout(self, milliseconds):
+        lib().bcd_hip_multi_set_frame_timeout(self.h, int(milliseconds))
 
     def comm_trace(self, rank):
         """[(channel, kind, bytes_up, bytes_down), ...] of the last frame, in the order `rank` enqueued its operations"""

@@ -150,11 +150,12 @@ int  bcd_hip_multi_get_stats(const bcd_hip_multi *m, bcd_hip_multi_stats *out);
 /* IDenoiser::setProgressCallback for the multi-device path: every (rank, scale) reports its owned pixels when its processed set
  * is known and when its estimate is complete; calls are serialised and monotone, the last value is 1 */
 int  bcd_hip_multi_set_progress_callback(bcd_hip_multi *m, bcd_hip_progress_fn fn, void *user);
+int  bcd_hip_multi_set_frame_timeout(bcd_hip_multi *m, int milliseconds);
 /* Failures.  A call that returns an error leaves the handle usable for the next frame: barriers, gates and the error state are
  * reset on entry.  On the RCCL transport the first failure of a frame aborts the local communicators (ncclCommAbort -- peers blocked
  * in a send / receive / all-reduce are released instead of waiting for ever), and a frame that has not finished after
- * BCD_HIP_MULTI_TIMEOUT_S seconds (default 600; 0 = never) is failed the same way, which is what ends a frame whose peer process
- * died.  bcd_hip_multi_create handles rebuild their communicators on the next call; a bcd_hip_multi_create_rank handle (one process
+ * BCD_HIP_MULTI_TIMEOUT_S seconds (default 600; 0 = never; bcd_hip_multi_set_frame_timeout sets it in milliseconds) is failed the
+ * same way by the handle's watchdog thread, which is what ends a frame whose peer process died.  bcd_hip_multi_create handles rebuild their communicators on the next call; a bcd_hip_multi_create_rank handle (one process
  * per GPU) must be destroyed and created again from fresh unique ids by all processes. */
 /* Communication trace of the last frame (debugging / tests): per rank, in the order the rank ENQUEUED them, four values per
  * operation: channel (scale, or nb_scales for the merges), kind (0 = neighbour exchange, 1 = all-reduce), bytes exchanged with the

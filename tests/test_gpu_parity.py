@@ -1264,3 +1264,27 @@ def test_textured_frame_masks_and_parity(hipctx, sigma, spp):
     assert st.similarity_path == 1 and st.borderline_pairs > 100          # the threshold band was populated, and decided exactly
     want = ol.denoise_mono(col, ns, hist, cov, ol.params(m=1.0), order=_orders(W, H, 1, 1, 3, 1)[0])
     assert rel_linf(got, want) < TOL
+
+
+@pytest.mark.gpu
+def test_multi_rank_frame_timeout_fails_the_frame_and_the_handle_recovers(hipctx):
+    """a frame of several ranks that does not finish within the handle's limit (BCD_HIP_MULTI_TIMEOUT_S, bcd_hip_multi_set_frame_timeout)
+    is failed by the watchdog thread -- host barriers released; on the RCCL transport the communicators are aborted -- instead of
+    hanging; the next frame on the same handle starts from clean barriers and gates and gives the right result"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    W, H, S = 1280, 720, 3
+    frame = core.synthetic_scene(W, H, 8, 3, 0.25, 0.01)
+    prm = bh.default_params(m=1.0, random_order=1, seed=9)
+    md = bh.MultiDenoiser([0] * 4)
+    try:
+        md.denoise_host(*frame, S, prm)                 # (allocations done)
+        md.set_frame_timeout(1)                         # one millisecond: no frame of this size makes it
+        with pytest.raises(bh.BcdHipError, match="timed out"):
+            md.denoise_host(*frame, S, prm)
+        md.set_frame_timeout(600000)
+        got = md.denoise_host(*frame, S, prm)           # same handle, after the failure
+    finally:
+        md.close()
+    want = hipctx.denoise_host(*frame, S, prm)
+    assert rel_linf(got, want) < 1e-5
