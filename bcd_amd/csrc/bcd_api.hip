@@ -50,6 +50,7 @@ hipError_t bcd_launch_active_init(const int32_t *, int, int, int, int, int, floa
 hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_mark_deps(const uint32_t *, const int32_t *, uint8_t *, uint32_t *, int, int, int, int, int, uint32_t, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_mark_round(const uint32_t *, uint8_t *, int, int, int, int, int, int, int *, hipStream_t);
+hipError_t bcd_launch_sum_counter_lines(const int *, int, int *, hipStream_t);
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
 hipError_t bcd_launch_jacobi27_batch(const float *, int, int *, int, float *, float *, hipStream_t);
 size_t bcd_bayes_lds_bytes(int w, int b);
@@ -81,7 +82,7 @@ struct DevBuf {
 struct Work {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, pixcov, sum, cnt, gscratch, dep, tmp_lo, border; // grow-only
+    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, cnt_lines, pixcov, sum, cnt, gscratch, dep, tmp_lo, border; // grow-only
     int border_capacity = 0;       // entries of `border` offered to the last fast similarity pass (0: the exact kernels ran)
     int rounds_hint = 0;           // marking launches the last problem needed
     bool dep_ready = false;        // dependency lists of the current marking problem are in `dep` (reset by active_init)
@@ -329,6 +330,12 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
     const int K = 3 * (2 * w + 1) * (2 * w + 1);
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int *d_cnt = (int *)wk.counters.p;
+    // every launch counts the pixels it leaves undecided into its own set of BCD_CNT_LINES sub-counters (one per cache line: a single
+    // counter is a serial resource, k_active.hip); one small kernel folds them into d_cnt[launch] for the host
+    constexpr size_t LINE_INTS = (size_t)BCD_CNT_LINES * BCD_CNT_STRIDE;
+    RCCHK(ensure(ctx, wk.cnt_lines, ROUND_BATCH * LINE_INTS * sizeof(int)));
+    int *d_lines = (int *)wk.cnt_lines.p;
+    HIPCHK(ctx, hipMemsetAsync(d_lines, 0, ROUND_BATCH * LINE_INTS * sizeof(int), wk.stream));
     // b = 6 / 12: dependency lists extracted once per marking problem, then cheap tile rounds (in-tile chains are resolved
     // inside a launch: few launches for a random order, more for the long chains of the scanline order);
     // other radii: the generic one-level-per-launch kernel
@@ -344,7 +351,7 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
         if (!wk.dep_ready) {
             RCCHK(ensure(ctx, wk.dep, (size_t)W * H * words * sizeof(uint32_t)));
             HIPCHK(ctx, bcd_launch_mark_deps(d_mask, d_nsim, d_state, (uint32_t *)wk.dep.p, W, H, b, K + 1, random_order, seed,
-                                             row_begin, row_end, row_offset, d_cnt + i++, wk.stream));
+                                             row_begin, row_end, row_offset, d_lines + LINE_INTS * i++, wk.stream));
             wk.dep_ready = true;
             wk.dep_mask = d_mask;
             wk.dep_state = d_state;
@@ -353,12 +360,13 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
             if (random_order) batch = std::min(ROUND_BATCH, std::max(5, wk.rounds_hint + 1));
         }
         for (; i < batch; ++i)
-            HIPCHK(ctx, bcd_launch_mark_round((const uint32_t *)wk.dep.p, d_state, W, H, b, row_begin, row_end, iters, d_cnt + i, wk.stream));
+            HIPCHK(ctx, bcd_launch_mark_round((const uint32_t *)wk.dep.p, d_state, W, H, b, row_begin, row_end, iters, d_lines + LINE_INTS * i, wk.stream));
     } else {
         for (int i = 0; i < batch; ++i)
             HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, row_begin, row_end, row_offset,
-                                                d_cnt + i, wk.stream));
+                                                d_lines + LINE_INTS * i, wk.stream));
     }
+    HIPCHK(ctx, bcd_launch_sum_counter_lines(d_lines, batch, d_cnt, wk.stream));
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, wk.stream));
     HIPCHK(ctx, hipStreamSynchronize(wk.stream));
     int n = batch;
@@ -576,7 +584,7 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
 
 void work_destroy(Work &w)
 {
-    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep, &w.tmp_lo, &w.border };
+    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.cnt_lines, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep, &w.tmp_lo, &w.border };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (w.h_counters) (void)hipHostFree(w.h_counters);
     for (auto &pr : w.ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

@@ -27,6 +27,10 @@ __host__ __device__ inline float bcd_unit_hash(uint32_t idx, uint32_t seed)
     return (float)(bcd_mix32(idx * 0x9E3779B1u + bcd_mix32(seed ^ 0x51ed270bu)) >> 8) * (1.0f / 16777216.0f);
 }
 
+// counters of undecided pixels are spread over BCD_CNT_LINES sub-counters, one per 128-byte line (k_active.hip)
+#define BCD_CNT_LINES 64
+#define BCD_CNT_STRIDE 32 /* ints */
+
 // ---- displacement tables -----------------------------------------------------------------------------
 // half-plane displacement set used by the pair-distance planes: (dl,dc) with dl in [0,b];
 // dc in [0,b] for dl == 0 and [-b,b] otherwise.  index(dl,dc):
