@@ -99,6 +99,10 @@ struct Work {
     // approximate distance planes computed ahead of similarity() by a caller that streams the frame in (bcd_hip_denoise_host_ex): valid for
     // exactly this problem; similarity() consumes the note
     struct { bool ready = false; const float *hist = nullptr, *ns = nullptr; int W = 0, H = 0, D = 0, b = 0; float tau = 0.f, uni_n = 0.f; } planes;
+    // uniform-sample-count speculation of the approximate distance kernel (similarity()): did the last frames on this workspace fail it?
+    bool nonuniform = false;
+    unsigned uni_probe = 0;
+    bool speculated = false;       // the current pass launched the uniform kernel on the first pixel's count, unchecked by the host
 };
 
 struct bcd_hip_ctx {
@@ -225,7 +229,21 @@ int check_params(bcd_hip_ctx *ctx, int W, int H, int D, const bcd_hip_params *pr
 // stream has been synchronised; the caller then repeats the pass with exact_mode = 1)
 bool similarity_needs_redo(const Work &wk)
 {
-    return wk.h_counters[40] != 0 || (wk.border_capacity > 0 && wk.h_counters[43] > wk.border_capacity);
+    return wk.h_counters[40] != 0 || (wk.border_capacity > 0 && (wk.h_counters[42] != 0 || wk.h_counters[43] > wk.border_capacity));
+}
+
+// ... and with which kernels: 0 = no redo; 3 = the approximate kernels again with the general (non-uniform) formula -- the only complaint
+// was that the sample counts are not one power of two (flag bit 1 of k_pairdist_rw); 1 = the exact kernels.  Also keeps the workspace's
+// memory of whether its frames have uniform counts (valid after the stream has been synchronised).
+int similarity_redo_mode(Work &wk)
+{
+    const int flag = wk.h_counters[40];
+    const bool fast = wk.border_capacity > 0;
+    const bool other_count = fast && wk.h_counters[42] != 0; // a pixel carries another sample count than the uniform kernel was launched for
+    const bool overflow = fast && wk.h_counters[43] > wk.border_capacity;
+    if (fast && (wk.speculated || other_count)) wk.nonuniform = other_count;
+    if (flag == 0 && !other_count && !overflow) return 0;
+    return (flag == 0 && other_count) ? 3 : 1; // (a void launch has no meaningful list count: other_count alone decides)
 }
 
 // can the approximate-planes path serve this problem?  (w = 1, a supported depth, a threshold binary16 can decide: bcd_common.h)
@@ -236,7 +254,7 @@ bool fast_similarity_applies(const bcd_hip_ctx *ctx, int D, int w, float tau)
 
 // exact_mode: 0 = production kernels, flags checked here (one stream synchronisation); 1 = exact kernels with the compiler's division;
 // 2 = production kernels, flags copied to wk.h_counters[40] / [43] but NOT checked: the caller validates after its own
-// synchronisation with similarity_needs_redo().
+// synchronisation with similarity_needs_redo() / similarity_redo_mode(); 3 = like 2 with the general (non-uniform) formula forced.
 // Production kernels: w = 1 and a supported depth -> approximate planes (k_pairdist_rw) + exact verification of the borderline
 // pairs; otherwise the exact planes with the scale-free division (k_pairdist<FAST>).
 int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
@@ -265,15 +283,25 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     const bool pre = wk.planes.ready && exact_mode != 1 && wk.planes.hist == d_hist && wk.planes.ns == d_ns && wk.planes.W == W && wk.planes.H == H &&
                      wk.planes.D == D && wk.planes.b == b && wk.planes.tau == tau && w == 1;
     wk.planes.ready = false;
-    if (pre) HIPCHK(ctx, hipMemsetAsync(d_flag + 1, 0, 3 * sizeof(int), wk.stream));
-    else HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream));
+    if (pre) { // (flags [0] and [2] belong to the launches that made the planes)
+        HIPCHK(ctx, hipMemsetAsync(d_flag + 1, 0, sizeof(int), wk.stream));
+        HIPCHK(ctx, hipMemsetAsync(d_flag + 3, 0, sizeof(int), wk.stream));
+    } else HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream));
     wk.h_counters[40] = 0;
+    wk.h_counters[42] = 0;
     wk.h_counters[43] = 0;
     wk.border_capacity = 0;
     // fixed samples per pixel, a power of two (the usual case): the distance kernel drops the sample-count products (exactly,
     // see k_pairdist).  One small reduction and one host round trip at the head of the chain (~30 us).
     float uni_n = pre ? wk.planes.uni_n : 0.f;
-    if (exact_mode != 1 && !pre) {
+    const bool fast_path = exact_mode != 1 && fast_similarity_applies(ctx, D, w, tau);
+    wk.speculated = false;
+    if (fast_path && !pre) {
+        // No scan and no round trip at the head of the chain: the approximate kernel takes the first pixel's count as THE count and checks
+        // every pixel against it itself (flag bit 1 -> the pass is repeated with the general formula).  A workspace whose recent frames were
+        // not uniform (adaptive sampling) goes to the general formula directly and looks again every 32nd pass.
+        if (exact_mode != 3 && (!wk.nonuniform || (++wk.uni_probe & 31u) == 0u)) { uni_n = -1.f; wk.speculated = true; }
+    } else if (exact_mode != 1 && !pre) {
         HIPCHK(ctx, bcd_launch_uniform_n(d_ns, (int64_t)npix, d_flag + 1, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 41, d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 42, d_ns, sizeof(float), hipMemcpyDeviceToHost, wk.stream));
@@ -284,7 +312,7 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         if (wk.h_counters[41] == 0 && n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
     }
     // the approximate path keeps its T plane in binary16: thresholds it cannot decide safely take the exact kernels (bcd_common.h)
-    const bool fast = exact_mode != 1 && fast_similarity_applies(ctx, D, w, tau);
+    const bool fast = fast_path;
     if (fast) {
         const int capacity = (int)std::min<size_t>(std::max<size_t>(npix, 1u << 16), 1u << 28);
         RCCHK(ensure(ctx, wk.border, (size_t)capacity * sizeof(uint2)));
@@ -296,13 +324,20 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
             if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
         }
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
+        HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 42, d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, wk.stream)); // "another sample count" (plain-store flag)
         BcdBorderline bl = { 0.f, (uint2 *)wk.border.p, d_flag + 3, capacity };
         HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream,
                                      &bl, d_hist, d_ns, D));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 43, d_flag + 3, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         if (exact_mode == 0) {
             HIPCHK(ctx, hipStreamSynchronize(wk.stream));
-            if (similarity_needs_redo(wk)) return similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 1);
+            const int redo = similarity_redo_mode(wk);
+            if (redo == 3) {
+                RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 3));
+                HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+                if (similarity_needs_redo(wk)) return similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 1);
+            } else if (redo == 1)
+                return similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 1);
         }
         return BCD_HIP_OK;
     }
@@ -496,14 +531,16 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     // memory, the finalisation is enqueued before the last synchronisation.
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[0], wk.stream));
     HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, wk.stream));
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, attempt == 0 ? 2 : 1));
+    for (int attempt = 0, mode = 2; attempt < 3; ++attempt) { // production kernels; if they complain: general formula, then exact kernels
+        RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, mode));
         if (prof && attempt == 0) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
         RCCHK(active_set(ctx, wk, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, W, H, w, b, row_begin, row_end,
                          prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)wk.state.p, &st.active_rounds));
-        if (attempt == 1) break;
+        if (mode == 1) break;
         if (!(prm->marked_skip_probability > 0.f)) HIPCHK(ctx, hipStreamSynchronize(wk.stream)); // no marking batch brought the flag back
-        if (!similarity_needs_redo(wk)) break; // inputs inside the guarded range, borderline list not overflowed
+        const int redo = similarity_redo_mode(wk);
+        if (redo == 0) break; // inputs inside the guarded range, uniform-count guess right, borderline list not overflowed
+        mode = (redo == 3 && mode == 2) ? 3 : 1;
     }
     progress_add(ctx, 0.5 * (double)npix); // similar patches selected, processed set known
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
@@ -1060,7 +1097,7 @@ int bcd_hip_similarity_masks_deferred(bcd_hip_ctx *ctx, const float *d_hist, con
 int bcd_hip_similarity_masks_verdict(bcd_hip_ctx *ctx, int *redo)
 {
     if (!ctx || !redo) return BCD_HIP_EINVAL;
-    *redo = similarity_needs_redo(ctx->main) ? 1 : 0;
+    *redo = similarity_redo_mode(ctx->main) != 0 ? 1 : 0; // (also keeps the workspace's memory of non-uniform sample counts)
     return BCD_HIP_OK;
 }
 

@@ -92,8 +92,16 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
     const size_t plane = (size_t)W * H;
     const size_t pix = (size_t)r * W + c;
 
+    // UNI with uni_n < 0: the caller did not look -- the count of the first pixel is taken as the uniform count here, and checked like a
+    // given one: it must be a power of two in [1, 65536] (then the count products drop out exactly) and every pixel must carry it
+    float un = uni_n;
+    if (UNI && uni_n < 0.f) {
+        un = ns[0];
+        const bool pow2 = (__float_as_uint(un) & 0x7fffffu) == 0u && un >= 1.f && un <= 65536.f;
+        if (!pow2) { if (threadIdx.x == 0) range_flag[2] = 1; return; } // (the same for every workgroup: nothing of this launch is used)
+    }
     float h1[D];
-    float n1 = UNI ? uni_n : 1.f;
+    float n1 = UNI ? un : 1.f;
     {
         const float4 *src = reinterpret_cast<const float4 *>(hist + (inside ? pix * D : 0));
 #pragma unroll
@@ -101,6 +109,7 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
             float4 v = inside ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
             h1[4 * q] = v.x; h1[4 * q + 1] = v.y; h1[4 * q + 2] = v.z; h1[4 * q + 3] = v.w;
         }
+        bool other_count = false;
         if (hv == 0) { // every pixel of the image is the own pixel of exactly one (line, half 0) wavefront: this covers the whole input
             bool bad = false;
 #pragma unroll
@@ -108,10 +117,14 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
             if (inside) {
                 const float nv = ns[pix];
                 bad = bad || !(nv >= RW_N_MIN && nv <= RW_N_MAX);
-                if (UNI && nv != uni_n) atomicOr(range_flag, 2);
+                other_count = UNI && nv != un;
             }
             if (bad) atomicOr(range_flag, 1);
         }
+        // a pixel with another sample count: the launch is void (the host repeats the pass with the general formula).  One plain store per
+        // workgroup into a flag word of its own -- on a frame without a uniform count every pixel would otherwise queue up on one atomic --
+        // and the workgroup leaves at once
+        if (UNI && __syncthreads_or(other_count)) { if (threadIdx.x == 0) range_flag[2] = 1; return; }
         if (!UNI && inside) n1 = ns[pix];
     }
 
@@ -357,7 +370,7 @@ hipError_t bcd_launch_pairdist_rw_rows(const float *hist, const float *ns, int W
         hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, static_cast<__half *>(T), Cn, d_range_flag, uni_n, tile_row_begin); \
         return hipGetLastError();                                                                                    \
     }
-#define BCD_RW_DEPTH(DD) case DD: if (uni_n > 0.f) BCD_RW_LAUNCH(DD, true) else BCD_RW_LAUNCH(DD, false)
+#define BCD_RW_DEPTH(DD) case DD: if (uni_n != 0.f) BCD_RW_LAUNCH(DD, true) else BCD_RW_LAUNCH(DD, false)
     switch (D) {
     BCD_RW_DEPTH(60)
     BCD_RW_DEPTH(36)
