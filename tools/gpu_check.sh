@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: tests + eigensolver timing + bench for one build.  usage: tools/r3_run.sh <tag> [quick]
+# GPU box: tests + eigensolver timing + bench for one build.  usage: tools/gpu_check.sh <tag> [quick]
 TAG=$1
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
