@@ -450,6 +450,17 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     RCCHK(ensure(ctx, wk.weak, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int32_t *d_c = (int32_t *)wk.counters.p + 16; // [0] strong, [1] weak, [2..3] sum |S|, [4..6] work counters of the estimate kernels
+    static const bool weak_lists = [] { const char *e = getenv("BCD_HIP_WEAK_LISTS"); return e && e[0] == '1'; }();
+    const bool weak_tiles = w == 1 && !weak_lists;
+    // the two paths only meet in the atomic accumulators: the fallback pixels run on a side stream.  The tiled fallback kernel needs no
+    // list (it reads states and |S| itself), so it starts at once -- beside the list compaction and the host round trip for the number of
+    // full estimates, during which this scale would otherwise leave the chip idle -- and is out of the way when the prepare kernel arrives
+    if (weak_tiles) {
+        HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
+        HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
+        HIPCHK(ctx, bcd_launch_bayes_weak_tiles(d_colors, d_mask, d_state, d_nsim, K + 1, W, H, b, d_sum, d_count, wk.aux));
+        HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
+    }
     HIPCHK(ctx, hipMemsetAsync(d_c, 0, 8 * sizeof(int32_t), wk.stream));
     HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)wk.strong.p, (int32_t *)wk.weak.p, d_c, wk.stream));
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream));
@@ -462,16 +473,12 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     int cus = std::max(1, ctx->num_cus * ctx->cu_share_pct / 100);
     if (&wk != &ctx->main) cus = std::max(1, cus * ctx->coarse_share / 100);
     const int weak_blocks = (int)std::min<int64_t>(cap, (int64_t)cus * 32);
-    // the two paths only meet in the atomic accumulators: the fallback pixels (many cheap items) run on a side stream beside
-    // the full estimate (few long items)
-    HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
-    HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
-    static const bool weak_lists = [] { const char *e = getenv("BCD_HIP_WEAK_LISTS"); return e && e[0] == '1'; }();
-    if (w == 1 && !weak_lists) // 3 x 3 patches: the tiled kernel (members out of an LDS colour window; finds the fallback pixels itself)
-        HIPCHK(ctx, bcd_launch_bayes_weak_tiles(d_colors, d_mask, d_state, d_nsim, K + 1, W, H, b, d_sum, d_count, wk.aux));
-    else
+    if (!weak_tiles) { // the list kernel (other patch radii): many cheap items beside the full estimate's few long ones
+        HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
+        HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
         HIPCHK(ctx, bcd_launch_bayes_weak(d_colors, d_mask, (const int32_t *)wk.weak.p, d_c + 1, weak_blocks, W, H, w, b, d_sum, d_count, wk.aux));
-    HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
+        HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
+    }
     if (w == 1) {
         HIPCHK(ctx, hipStreamSynchronize(wk.stream));
         const int n_strong = wk.h_counters[16];
