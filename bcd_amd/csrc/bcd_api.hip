@@ -82,7 +82,7 @@ struct DevBuf {
 struct Work {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, cnt_lines, pixcov, sum, cnt, gscratch, dep, tmp_lo, border; // grow-only
+    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, cnt_lines, work_q, pixcov, sum, cnt, gscratch, dep, tmp_lo, border; // grow-only
     int border_capacity = 0;       // entries of `border` offered to the last fast similarity pass (0: the exact kernels ran)
     int rounds_hint = 0;           // marking launches the last problem needed
     bool dep_ready = false;        // dependency lists of the current marking problem are in `dep` (reset by active_init)
@@ -485,10 +485,11 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
         const size_t rec = bcd_bayes27_record_bytes();
         const int chunk_max = 1 << 17; // 131072 pixels = 1.3 GB of records
         if (n_strong > 0) RCCHK(ensure(ctx, wk.gscratch, rec * (size_t)std::min(n_strong, chunk_max)));
+        RCCHK(ensure(ctx, wk.work_q, BCD_WORK_INTS * sizeof(int32_t)));
         for (int first = 0; first < n_strong; first += chunk_max) {
             const int n = std::min(chunk_max, n_strong - first);
-            if (first > 0) HIPCHK(ctx, hipMemsetAsync(d_c + 4, 0, 3 * sizeof(int32_t), wk.stream)); // (zeroed with the list counters for the first chunk)
-            HIPCHK(ctx, bcd_launch_bayes27(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, first, n, d_c + 4, cus, W, H, b, min_eig,
+            HIPCHK(ctx, hipMemsetAsync(wk.work_q.p, 0, BCD_WORK_INTS * sizeof(int32_t), wk.stream)); // the work queues of the three kernels
+            HIPCHK(ctx, bcd_launch_bayes27(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, first, n, (int *)wk.work_q.p, cus, W, H, b, min_eig,
                                            (float *)wk.gscratch.p, d_sum, d_count, wk.stream));
         }
     } else {
@@ -628,7 +629,7 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
 
 void work_destroy(Work &w)
 {
-    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.cnt_lines, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep, &w.tmp_lo, &w.border };
+    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.cnt_lines, &w.work_q, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep, &w.tmp_lo, &w.border };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (w.h_counters) (void)hipHostFree(w.h_counters);
     for (auto &pr : w.ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1380,8 +1381,9 @@ int bcd_hip_eig27_batch(bcd_hip_ctx *ctx, const float *d_A, int n, float *d_eig,
     DEVICE_GUARD(ctx);
     Work &wk = ctx->main;
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
-    int32_t *d_c = (int32_t *)wk.counters.p + 48; // work counter
-    HIPCHK(ctx, hipMemsetAsync(d_c, 0, sizeof(int32_t), wk.stream));
+    RCCHK(ensure(ctx, wk.work_q, BCD_WORK_INTS * sizeof(int32_t)));
+    int32_t *d_c = (int32_t *)wk.work_q.p; // work queues
+    HIPCHK(ctx, hipMemsetAsync(d_c, 0, BCD_WORK_INTS * sizeof(int32_t), wk.stream));
     HIPCHK(ctx, hipEventRecord(wk.ev_stage[0], wk.stream));
     HIPCHK(ctx, bcd_launch_jacobi27_batch(d_A, n, d_c, std::min(ctx->num_cus * 12, (n + 1) / 2), d_eig, d_V, wk.stream));
     HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));

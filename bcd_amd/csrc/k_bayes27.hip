@@ -46,6 +46,27 @@ __device__ inline float wsum(float v)
     return v;
 }
 
+// Work distribution of the persistent kernels.  One counter serves 50-90 same-address atomics per microsecond: with a single counter per
+// kernel the 36 000 grabs of a 1080p scale were 0.4 ms (finish kernel with its body skipped) to 0.7 ms (prepare kernel) on their own.
+// Items are dealt round-robin to BCD_WORK_QUEUES counters in cache lines of their own (item = queue + 8 k); a wavefront starts on
+// the queue of its XCD (workgroups go round-robin over the 8 XCDs) and moves on to the next queue when one is empty, so nothing is
+// left behind and the tail stays balanced.
+struct WorkCursor { int q, tried; };
+__device__ inline WorkCursor work_begin() { return WorkCursor{ (int)(blockIdx.x % BCD_WORK_QUEUES), 0 }; }
+__device__ inline int work_next(int *work, int nb_items, int lane, WorkCursor &c)
+{
+    while (c.tried < BCD_WORK_QUEUES) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(work + c.q * BCD_WORK_STRIDE, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        const int item = c.q + BCD_WORK_QUEUES * k;
+        if (item < nb_items) return item;
+        c.q = (c.q + 1) % BCD_WORK_QUEUES;
+        ++c.tried;
+    }
+    return -1;
+}
+
 __device__ inline int noise_idx(int i, int j)
 {
     // 3x3 symmetric block from xx,yy,zz,yz,xz,xy
@@ -132,11 +153,11 @@ __global__ __launch_bounds__(64, 3) void k_jacobi27_batch(const float *__restric
     const bool isRow = r < KP;
     const float *src = Ah + jrow(isRow ? r : (PAD ? 16 : 0)); // (idle lanes: the address of a lane of their own ds_read_b128 group)
     float *dst = Ah + jrow(isRow ? sigma_slot(r) : 0);
+    WorkCursor cursor = work_begin();
     for (;;) {
-        int first = 0;
-        if (lane == 0) first = atomicAdd(work, 2);
-        first = __builtin_amdgcn_readfirstlane(first);
-        if (first >= n) break;
+        const int pair = work_next(work, (n + 1) / 2, lane, cursor);
+        if (pair < 0) break;
+        const int first = 2 * pair;
         const int item = first + h;
         const bool live = item < n;
         // matrix -> LDS (an absent second matrix is the identity: converged from the start)
@@ -691,12 +712,11 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     float *fl = mean + K + 1;
     uint16_t *mem = reinterpret_cast<uint16_t *>(fl + KP);
 
-    // persistent wavefronts: items are handed out through an atomic counter
+    // persistent wavefronts: items are handed out through the work queues
+  WorkCursor cursor = work_begin();
   for (;;) {
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(work, 1);
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    if (slot >= nb_items) break;
+    const int slot = work_next(work, nb_items, lane, cursor);
+    if (slot < 0) break;
     const int p = list[first_item + slot];
     const int n = decode_members27(mask, p, g, mem, lane);
     const int W = g.W;
@@ -1007,19 +1027,10 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float
     __syncthreads();
     const int W = g.W, H = g.H;
 
-  // Items come from a work counter.  One counter serves ~50 same-address atomics per microsecond (measured: 36 000 grabs = 0.72 ms,
-  // which was the whole duration of PHASE 1 at 1080p), so the short PHASE 1 items are taken two at a time; the PHASE 2 items are longer
-  // and differ in length, one at a time balances better (two: +1 %, four: +9 %; a static split: +46 %).
-  const int grab = PHASE == 1 ? 2 : 1;
-  int slot_base = 0, slot_i = grab;
+  WorkCursor cursor = work_begin();
   for (;;) {
-    if (slot_i >= grab) {
-        if (lane == 0) slot_base = atomicAdd(work, grab);
-        slot_base = __builtin_amdgcn_readfirstlane(slot_base);
-        slot_i = 0;
-    }
-    const int slot = slot_base + slot_i++;
-    if (slot >= nb_items) break;
+    const int slot = work_next(work, nb_items, lane, cursor);
+    if (slot < 0) break;
     const int p = __builtin_amdgcn_readfirstlane(list[first_item + slot]);
     const int pr = p / W, pc = p - pr * W;
     float *recA = rec.A + (size_t)slot * MSZ, *recC = rec.C + (size_t)slot * MSZ, *recX = rec.aux + (size_t)slot * AUX27;
@@ -1143,7 +1154,7 @@ size_t bcd_bayes27_record_bytes() { return (size_t)(3 * MSZ + AUX27 + KP) * size
 hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blocks, float *eig, float *V, hipStream_t st);
 
 // Full estimate of items [first_item, first_item + nb_items) of `list`: three launches; `records` holds nb_items records
-// (bcd_bayes27_record_bytes() each), d_work three zeroed ints.
+// (bcd_bayes27_record_bytes() each), d_work BCD_WORK_INTS zeroed ints (the work queues of the three kernels).
 hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int first_item, int nb_items,
                               int *d_work, int num_cus, int W, int H, int b, float min_eig, float *records, float *sum,
                               int32_t *cnt, hipStream_t st)
@@ -1168,16 +1179,16 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         const int w_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / wl1), w_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / wl2);
         hipLaunchKernelGGL(k_bayes27w<1>, dim3(std::min(nb_items, num_cus * w_cu1)), dim3(64), wl1, st, colors, pixcov, mask, list, first_item, nb_items,
                            d_work, g, min_eig, rec, sum, cnt);
-        { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + 1, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
+        { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * w_cu2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
-                           d_work + 2, g, min_eig, rec, sum, cnt);
+                           d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
                        d_work, g, min_eig, rec, sum, cnt);
-    { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + 1, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
+    { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k_bayes27<2>, dim3(std::min(nb_items, num_cus * per_cu2)), dim3(64), lds2, st, colors, pixcov, mask, list, first_item, nb_items,
-                       d_work + 2, g, min_eig, rec, sum, cnt);
+                       d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt);
     return hipGetLastError();
 }
 
