@@ -214,7 +214,11 @@ __global__ __launch_bounds__(64, 3) void k_jacobi27_batch(const float *__restric
             }
             off = half_sum(off);
             dg = half_sum(dg);
-            if (__builtin_amdgcn_ballot_w64(!(off <= 1e-13f * dg)) == 0) break; // both matrices converged
+            // off^2 <= 1e-10 diag^2: the positive part V max(0, lambda) V^T is Lipschitz in the matrix, so what is left off the diagonal moves it
+            // by <= 1e-5 |A| (the frames agree with the oracle to ~1e-6; one more sweep buys nothing the 1e-4 bar can see).  A converged
+            // matrix is frozen -- identity rotations -- while its partner finishes: its result does not depend on who shares the wavefront
+            const bool settled = off <= 1e-10f * dg;
+            if (__builtin_amdgcn_ballot_w64(!settled) == 0) break; // both matrices converged
             // fully unrolled: the Brent-Luk column move of the rows of V~ (a 27-cycle of the register names) costs no instruction
 #pragma unroll
             for (int round = 0; round < KP - 1; ++round) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(64, 3) void k_jacobi27_batch(const float *__restric
                     const float2 d2 = reinterpret_cast<const float2 *>(dv_h)[p >> 1];
                     const float apq_s = Ah[jrow(p) + q], app_s = Ah[jrow(p) + p], aqq_s = Ah[jrow(q) + q];
                     float dp = d2.x, dq = d2.y;
-                    if (apq_s != 0.f) {
+                    if (apq_s != 0.f && !settled) {
                         const float apq = dp * dq * apq_s, app = dp * dp * app_s, aqq = dq * dq * aqq_s;
                         // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working
                         // precision (c^2 + s^2 = 1 +- 1e-7), not the exact minimiser

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
 Integer / discrete results (masks, counts, processed sets) and order-exact float stages must be bit-exact;
 the denoised colours must be within 1e-4 relative L-infinity (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +14,11 @@ TOL = 1e-4  # relative L-inf on in-memory fp32 buffers (north_star)
 
 
 def rel_linf(a, b):
-    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+    v = float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+    if os.environ.get("BCD_TEST_REPORT"):  # (a log of every compared pair: how far below the bar the suite runs)
+        with open(os.environ["BCD_TEST_REPORT"], "a") as f:
+            f.write("%s %.3e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], v))
+    return v
 
 
 def bits_equal(a, b):
