@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64) void k_bayes_weak_w1(const float *__restrict__ 
 // 36-byte segments at 1080p, bound by the L1 tag rate (r3: 0.41 ms at 1080p scale 0, all wave slots of the chip taken meanwhile,
 // which is what the full-estimate kernels started beside it were really waiting for).  The estimates are summed into an 18 x 18
 // LDS window and flushed with one global atomic per touched value.
-// Lane layout as k_bayes_weak_w1: one lane per (fallback pixel, patch row), 21 pixels per wavefront, sums in window order.
+// One lane per (fallback pixel, patch row), sums in window order.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int WT = 16; // tile edge
 __global__ __launch_bounds__(256) void k_bayes_weak_tile(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
@@ -464,21 +464,42 @@ __global__ __launch_bounds__(256) void k_bayes_weak_tile(const float *__restrict
     }
     for (int e = tid; e < (WT + 2) * (WT + 2) * 4; e += 256) accS[e] = 0.f; // (sums and counts are contiguous)
     __syncthreads();
-    // ---- 21 fallback pixels per wavefront and pass, one lane per patch row
-    constexpr int PER_WAVE = 21;
-    const int slot = lane / 3, prow = lane - slot * 3;
+    // ---- one lane per (fallback pixel, patch row).  Wavefront w takes the pairs whose row of the 18 x 18 window, ply + prow, is w mod 4:
+    // no two wavefronts ever touch the same accumulator row, so the sums need no atomics -- ds_add_f32 is served one lane at a time on
+    // gfx950 (193 cycles of the CU's LDS pipe per wavefront instruction against 2.5 for a read and 4.7 for a write, tools/ubench/
+    // lds_rate.hip; with nine of them per pass they were most of this kernel).  Inside a wavefront the LDS instructions are served in
+    // program order; two lanes of ONE instruction must not meet, which they would on the same window row with columns less than 3 apart:
+    // the adds are issued in nine turns, by (plx % 3, prow) -- the same turn and the same window row mean the same pixel row, so two such
+    // pixels are at least 3 columns apart.
+    uint16_t *pairs = wlist + 256 + wave * 192;              // (pixel | prow << 8) of this wavefront: at most 3/4 of 256 pixels
+    int npairs = 0;
+    for (int i0 = 0; i0 < nw; i0 += 64) {
+        const int i = i0 + lane;
+        int code = 0;
+        bool take = false;
+        if (i < nw) {
+            const int lp = wlist[i], t = (wave - (lp >> 4)) & 3;
+            take = t < 3;
+            code = lp | (t << 8);
+        }
+        const unsigned long long bal = __ballot(take);
+        if (take) pairs[npairs + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)code;
+        npairs += __popcll(bal);
+    }
+    __syncthreads();
     const float inv_side = 1.f / (float)g.side;
-    for (int base = wave * PER_WAVE; base < nw; base += 4 * PER_WAVE) {
-        const int item = base + slot;
-        if (slot < PER_WAVE && item < nw) {
-            const int lp = wlist[item], plx = lp & (WT - 1), ply = lp >> 4;
+    for (int base = 0; base < npairs; base += 64) {
+        const bool live = base + lane < npairs;
+        const int code = pairs[live ? base + lane : 0];
+        const int lp = code & 255, prow = code >> 8, plx = lp & (WT - 1), ply = lp >> 4;
+        float a[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) a[e] = 0.f;
+        if (live) {
             const long long p = (long long)(ty0 + ply) * W + tx0 + plx;
             // first float of this lane's patch row for the member at window offset (0, 0), i.e. the pixel itself
             const float *src = win + ((ply + b1 + prow - 1) * TW + plx + b1 - 1) * 3;
             const uint32_t *mw = mask + (size_t)p * g.words;
-            float a[9];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) a[e] = 0.f;
             int n = 0;
             for (int w0 = 0; w0 < g.words; w0 += 6) {
                 uint32_t mreg[6];
@@ -499,10 +520,21 @@ __global__ __launch_bounds__(256) void k_bayes_weak_tile(const float *__restrict
                 }
             }
             const float n_inv = 1.f / (float)n;
-            float *dS = accS + ((ply + prow) * (WT + 2) + plx) * 3;        // patch row prow of the pixel in the 18 x 18 window
-            int *dC = accC + (ply + prow) * (WT + 2) + plx;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) unsafeAtomicAdd(dS + e, n_inv * a[e]);
+            for (int e = 0; e < 9; ++e) a[e] *= n_inv;
+        }
+        float *dS = accS + ((ply + prow) * (WT + 2) + plx) * 3;        // patch row prow of the pixel in the 18 x 18 window
+        int *dC = accC + (ply + prow) * (WT + 2) + plx;
+        const int turn = (plx % 3) * 3 + prow;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (live && turn == t) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) dS[e] += a[e];
+            }
+            asm volatile("" ::: "memory"); // (program order of the LDS accesses: the compiler only reasons about one lane)
+        }
+        if (live) {
 #pragma unroll
             for (int e = 0; e < 3; ++e) atomicAdd(dC + e, 1);
         }
@@ -595,7 +627,7 @@ hipError_t bcd_launch_bayes_weak_tiles(const float *colors, const uint32_t *mask
     BayesGeom g = make_geom(W, H, 1, b);
     if (g.words > 32) return hipErrorInvalidValue;
     const int TW = WT + 2 * (b + 1);
-    const size_t lds = (size_t)((TW * TW * 3 + 3) & ~3) * 4 + (size_t)(WT + 2) * (WT + 2) * 16 + 256 * sizeof(uint16_t);
+    const size_t lds = (size_t)((TW * TW * 3 + 3) & ~3) * 4 + (size_t)(WT + 2) * (WT + 2) * 16 + (256 + 4 * 192) * sizeof(uint16_t);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_bayes_weak_tile, dim3((W + WT - 1) / WT, (H + WT - 1) / WT), dim3(256), lds, st, colors, mask, state, nsim, min_strong, g, sum, cnt);
     return hipGetLastError();

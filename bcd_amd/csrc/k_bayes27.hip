@@ -339,58 +339,62 @@ __device__ void add_noise27(float *M, const float *noise, int lane, float sign)
     __syncthreads();
 }
 
-// in-place inverse of the symmetric positive definite M (LD layout) by the sweep operator, rows held in registers:
-// lane r owns row r; at step k the pivot row is broadcast with v_readlane (k is a compile-time constant), so the 27
-// steps need no LDS traffic and no barrier.  Returns false (wave-uniform) if a pivot is not positive or the bound
-// ||M^-1||_F * min_eig <= 1 fails (then lambda_min >= min_eig is not proven); M is then unspecified.
+// in-place inverse of the symmetric positive definite M (LD layout) by the sweep operator on the matrix core.  Sweeping pivot k,
+//     N_kk = -1 / d,   N_rk = N_kr = m_rk / d,   N_rc = m_rc - m_rk m_kc / d      (d = m_kk; after all 27 pivots N = -M^-1),
+// is ONE rank-1 update N = M - u u^T / d - 2 e_k e_k^T with u = (column k of M) - e_k, i.e. one v_mfma_f32_32x32x2_f32 (exact f32 fma)
+// on a matrix that stays in the accumulator registers for all 27 steps.  In the C/D layout lane (j, h) holds column j, rows
+// (e & 3) + 8 (e >> 2) + 4 h; the matrix is symmetric, so the lanes of half h_k = (k >> 2) & 1 already hold u_j in register e_k: they
+// feed it as the B operand of k-slot h_k and, times -1 / d, as the A operand; the other half's k-slot carries the -2 e_k e_k^T term.  No
+// lane exchange, no LDS, ~12 instructions per pivot (the pivot itself comes through v_readlane; 1 / d = hardware reciprocal + one Newton step: the pivots of
+// a Gauss-Jordan sweep need no correctly rounded quotient).  The previous form -- lane r owns row r, the pivot row broadcast element
+// by element with v_readlane + v_fma -- took 56 instructions per pivot on 27 of the 64 lanes, 3 000 of the ~6 800 vector instructions
+// of a full estimate's finish (r3 counters).
+// Returns false (wave-uniform) if a pivot is not positive or the bound ||M^-1||_F * min_eig <= 1 fails (then lambda_min >= min_eig
+// is not proven); M is then unspecified.
 
 __device__ inline float bcast_lane(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
 __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
 {
     LDS_POINTER(M);
-    const int r = lane < K ? lane : 0;
-    float m[K];
+    const int idx = lane & 31, h = lane >> 5;
+    const float *col = M + (idx < K ? idx : 0) + 4 * h * LD;
+    v16f acc;
 #pragma unroll
-    for (int c = 0; c < K; ++c) m[c] = M[r * LD + c];
+    for (int e = 0; e < 16; ++e) {
+        const int r0 = (e & 3) + 8 * (e >> 2); // row of half 0; half 1: + 4
+        const bool inside = idx < K && r0 + 4 * h < K;
+        acc[e] = inside ? col[r0 * LD] : 0.f;
+    }
+    // (the accumulator is only ever written by the matrix core: patching one of its elements from the vector unit makes the compiler move
+    // all 16 registers out of and back into the accumulator file around every step.  The -2 e_k e_k^T term therefore rides in the k-slot
+    // of the OTHER half, which would feed zeros: A = -2 delta_ik, B = delta_jk.)
+    const float half0 = h == 0 ? 1.f : 0.f, half1 = 1.f - half0;
+    const float sgn0 = h == 0 ? -1.f : 1.f, sgn1 = -sgn0; // feeding half: u = m - e_k; other half: + e_k
     bool ok = true;
-    float scale = 1.f; // pending scale of this lane's row: 1 until the row has been the pivot row, 1 / d afterwards
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float d = bcast_lane(m[k], k); // (row k has not been scaled yet: its scale is still 1)
+        const int hk = (k >> 2) & 1, ek = (k & 3) + 4 * (k >> 3);
+        const float v = acc[ek];
+        const float d = bcast_lane(v, k + 32 * hk);
         ok = ok && (d > 0.f);
-        // 1 / d to an ulp (hardware reciprocal + one Newton step): the pivots of a Gauss-Jordan sweep need no correctly rounded quotient,
-        // and the compiler's IEEE division is a dozen instructions on the critical path of each of the 27 steps
         float inv_d = __builtin_amdgcn_rcpf(d);
         inv_d = fmaf(fmaf(-d, inv_d, 1.f), inv_d, inv_d);
-        const bool pivot_row = (lane == k);
-        // row r != k: a_rc - (a_rk / d) a_kc -- one fma per element.  The pivot row's own step, a_kc / d, is only recorded in its
-        // scale: a row's scale cancels out of every later update of that row (the multiplier a_rk / d' carries it, the pivot row of
-        // that later step is still unscaled), so it is applied once at the end instead of 26 multiplies per step for every lane.
-        // (Sending the pivot row through LDS instead of 27 v_readlane per step was measured: twice as slow, the step then waits
-        // for an LDS round trip.)
-        const float f = pivot_row ? 0.f : m[k] * inv_d;
-#pragma unroll
-        for (int c = 0; c < K; ++c) {
-            if (c == k) continue;
-            const float pkc = bcast_lane(m[c], k); // a_kc (old)
-            m[c] = fmaf(-f, pkc, m[c]);
-        }
-        m[k] = pivot_row ? -1.f : f; // (-1) x scale = -1 / d on the pivot row, a_rk / d elsewhere
-        scale = pivot_row ? inv_d : scale;
+        const float hm = hk ? half1 : half0;
+        const float ek_signed = (idx == k) ? (hk ? sgn1 : sgn0) : 0.f;
+        const float bop = fmaf(v, hm, ek_signed);                  // feeding half: u_j = m_kj - delta_jk; other half: delta_jk
+        const float aop = bop * ((h == hk) ? -inv_d : -2.f);       // feeding half: -u_i / d;               other half: -2 delta_ik
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop, acc, 0, 0, 0);
     }
     float fro = 0.f;
 #pragma unroll
-    for (int c = 0; c < K; ++c) {
-        m[c] = -scale * m[c];
-        fro = fmaf(m[c], m[c], fro);
-    }
-    if (lane >= K) fro = 0.f;
+    for (int e = 0; e < 16; ++e) fro = fmaf(acc[e], acc[e], fro);
     fro = wsum(fro);
-    __syncthreads();
-    if (lane < K) {
+    __syncthreads(); // (every lane has read M)
 #pragma unroll
-        for (int c = 0; c < K; ++c) M[r * LD + c] = m[c];
+    for (int e = 0; e < 16; ++e) {
+        const int r0 = (e & 3) + 8 * (e >> 2);
+        if (idx < K && r0 + 4 * h < K) M[(r0 + 4 * h) * LD + idx] = -acc[e];
     }
     __syncthreads();
     return ok && isfinite(fro) && sqrtf(fro) * min_eig <= 1.f;
@@ -656,7 +660,9 @@ __device__ __attribute__((noinline)) void final_chunk27(const float *Cm, const f
                         const float v = x[r] - y[e];
                         if (in_lds) {
                             const int wq = (dy + b1 + oy) * AW + dx + b1 + ox;
-                            unsafeAtomicAdd(accS + wq * 3 + ch, v);
+                            accS[wq * 3 + ch] += v;
+                            asm volatile("" ::: "memory"); // (not ds_add_f32: see k_bayes27w; the 64 addresses of one instruction are distinct -- members are whole
+                                                    // pixels apart, the two halves' components are of different channels)
                             if (ch == 0) atomicAdd(accC + wq, 1);
                         } else {
                             const int q = q0 + oy * W + ox;
@@ -1084,42 +1090,75 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float
     int *accC = reinterpret_cast<int *>(A + WPIX * 3);
     for (int e = lane; e < WPIX * 4; e += 64) A[e] = 0.f;
     __syncthreads();
-    // ---- output pass, 32 members per matrix-core product: D[r][j] = sum_k F2[r][k] (x_j[k] - m[k]); lane l feeds A = F2[l & 31][k] and
-    // B = x - m of member l & 31, k = 2 s + (l >> 5); it gets back components r = (e & 3) + 8 (e >> 2) + 4 (l >> 5) of member l & 31
+    // ---- output pass, 32 members per matrix-core product: D[r][j] = c[r] + sum_k F2[r][k] x_j[k] with c = m - F2 m (the same affine map).
+    // The sum over k may run in any order as long as both operands agree: the lanes of half h take k = 14 h + s at step s, so that a lane
+    // feeds A = F2[l & 31][14 h .. 14 h + 13] -- 14 registers, loaded once per item -- and B = 14 neighbouring components of the patch of
+    // member l & 31 (read two at a time); it gets back components r = (e & 3) + 8 (e >> 2) + 4 h of that member, on top of c (the product's
+    // initial accumulator: one extra product per item, with B = m for every column).
     {
         const int mj = lane & 31, kh = lane >> 5;
-        const float *frow = Cm + min(mj, K - 1) * LD + kh;      // (rows 27..31 of the A operand only reach rows 27..31 of D: unused)
-        const float *mk_ = mean + kh;
+        float fa[14];
+        {
+            const float *frow = Cm + min(mj, K - 1) * LD + 14 * kh;   // (rows 27..31 of the A operand only reach rows 27..31 of D: unused)
+#pragma unroll
+            for (int s_ = 0; s_ < 14; ++s_) fa[s_] = frow[s_];
+            if (kh) fa[13] = 0.f;                                   // k = 27: padding
+        }
+        v16f c0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c0[e] = 0.f;
+        {
+            const float *mk_ = mean + 14 * kh;
+#pragma unroll
+            for (int s_ = 0; s_ < 14; ++s_) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], mk_[s_ < 13 ? s_ : 12 + (1 - kh)], c0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                c0[e] = mean[min(r, K - 1)] - c0[e];
+            }
+        }
         for (int i0 = 0; i0 < n; i0 += 32) {
             const bool valid = i0 + mj < n;
             const int wp = mem[valid ? i0 + mj : 0];
             const int base = (wp - WAW - 1) * 3;                // top-left pixel of the member's patch in the window, floats
-            const float *xb = cwin + base + kh;
-            v16f y;
+            // component k of a patch vector sits at k + 36 (k / 9) floats from the patch's top-left pixel: k = 14 h + s is at
+            //   s < 4: s + 50 h,    4 <= s < 9: s + 86 h,    9 <= s: s + 36 + 50 h
+            const float *pa = cwin + base + 50 * kh, *pb = cwin + base + 86 * kh;
+            v16f y = c0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) y[e] = 0.f;
-#pragma unroll
-            for (int k0 = 0; k0 < KP; k0 += 2) {
-                // component k = k0 + kh of a patch vector sits at k + 36 (k / 9) floats from the patch's top-left pixel
-                const int j0 = k0 / 9, j1 = (k0 + 1) / 9;
-                float a = frow[k0];
-                float bq = (j0 == j1 ? xb[k0 + 36 * j0] : cwin[base + (kh ? k0 + 1 + 36 * j1 : k0 + 36 * j0)]) - mk_[k0];
-                if (k0 + 1 >= K) { a = kh ? 0.f : a; bq = kh ? 0.f : bq; }   // k = 27: padding
-                y = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, y, 0, 0, 0);
+            for (int s_ = 0; s_ < 14; ++s_) {
+                float bq = s_ < 4 ? pa[s_] : (s_ < 9 ? pb[s_] : pa[s_ + 36]);
+                if (s_ == 13) bq = kh ? 0.f : bq;                  // k = 27: padding (the cell read in its place is a window cell, any content)
+                y = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], bq, y, 0, 0, 0);
             }
             if (valid) {
+                // component r = r0 + 4 h lands r + 36 (r / 9) floats into the patch: r0 + 36 (r0 / 9) plus 4 h -- or 40 h where r0 + 4 is on the
+                // next patch line -- i.e. a compile-time offset from one of two per-lane bases: no address arithmetic per component
+                float *d4 = accS + base + 4 * kh, *d40 = accS + base + 40 * kh;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int r0 = (e & 3) + 8 * (e >> 2);        // r = r0 + 4 kh
-                    const int ja = r0 / 9, jb = (r0 + 4) / 9;
-                    const bool ok = kh ? (r0 + 4 < K) : (r0 < K);
-                    if (ok) {
-                        const float v = mean[r0 + 4 * kh] + y[e];
-                        const int idx = base + (kh ? r0 + 4 + 36 * jb : r0 + 36 * ja);
-                        unsafeAtomicAdd(accS + idx, v);
-                        const bool first_channel = kh ? ((r0 + 4) % 3 == 0) : (r0 % 3 == 0);
-                        if (first_channel) atomicAdd(accC + idx / 3, 1);
-                    }
+                // Plain read-add-write, not ds_add_f32: the LDS float atomic is served one lane at a time on gfx950 (193 cycles of the CU's
+                // LDS pipe per wavefront instruction, measured: tools/ubench/lds_rate.hip; a read is 2.5 and a write 4.7), and there is
+                // nobody to be atomic against -- one wavefront per workgroup, and within one instruction the 64 addresses are distinct:
+                // two members' patches are whole pixels (multiples of 3 floats) apart, the two halves' components 4 or 40 floats.
+                for (int e = 0; e < 12; ++e) {                     // r0 <= 19: both halves inside the 27 components
+                    const int r0 = (e & 3) + 8 * (e >> 2);
+                    float *q = ((r0 + 4) / 9 != r0 / 9 ? d40 : d4) + r0 + 36 * (r0 / 9);
+                    *q = *q + y[e];
+                    // (the NEXT component of another lane may be this address: program order must be kept -- the compiler only reasons about
+                    // one lane, where the addresses differ; the hardware serves a wavefront's LDS instructions in order)
+                    asm volatile("" ::: "memory");
+                }
+                // the 9 pixels of the patch, counted once each: pixel q is (q % 3) + 15 (q / 3) cells from the top-left one; half 0 takes
+                // q = 0..4, half 1 q = 5..8
+                int *c17 = accC + (wp - WAW - 1) + 17 * kh, *c29 = accC + (wp - WAW - 1) + 29 * kh;
+                atomicAdd(c17, 1);
+                atomicAdd(c29 + 1, 1);
+                atomicAdd(c29 + 2, 1);
+                atomicAdd(c17 + 15, 1);
+                if (!kh) {
+#pragma unroll
+                    for (int e = 12; e < 15; ++e) { float *q = d4 + 24 + (e - 12) + 72; *q = *q + y[e]; asm volatile("" ::: "memory"); } // r0 = 24..26 (half 1 would be 28..30)
+                    atomicAdd(c17 + 16, 1);
                 }
             }
         }
