@@ -34,7 +34,7 @@ __host__ __device__ inline float bcd_unit_hash(uint32_t idx, uint32_t seed)
 // work queues of the persistent estimate kernels (k_bayes27.hip): BCD_WORK_QUEUES counters per kernel, one per 128-byte line
 #define BCD_WORK_QUEUES 8
 #define BCD_WORK_STRIDE 32 /* ints */
-#define BCD_WORK_INTS (3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE) /* prepare | solve | finish */
+#define BCD_WORK_INTS (4 * BCD_WORK_QUEUES * BCD_WORK_STRIDE) /* prepare | solve | finish | finish of the redo list */
 
 // ---- displacement tables -----------------------------------------------------------------------------
 // half-plane displacement set used by the pair-distance planes: (dl,dc) with dl in [0,b];

@@ -354,18 +354,9 @@ __device__ void add_noise27(float *M, const float *noise, int lane, float sign)
 
 __device__ inline float bcast_lane(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
-__device__ bool sweep_inverse27(float *M, int lane, float min_eig)
+// the 27 sweeps on a matrix in the accumulator layout; acc <- -(M^-1); returns the wave-uniform verdict (see above)
+__device__ inline bool sweep_regs(v16f &acc, int idx, int h, float min_eig)
 {
-    LDS_POINTER(M);
-    const int idx = lane & 31, h = lane >> 5;
-    const float *col = M + (idx < K ? idx : 0) + 4 * h * LD;
-    v16f acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int r0 = (e & 3) + 8 * (e >> 2); // row of half 0; half 1: + 4
-        const bool inside = idx < K && r0 + 4 * h < K;
-        acc[e] = inside ? col[r0 * LD] : 0.f;
-    }
     // (the accumulator is only ever written by the matrix core: patching one of its elements from the vector unit makes the compiler move
     // all 16 registers out of and back into the accumulator file around every step.  The -2 e_k e_k^T term therefore rides in the k-slot
     // of the OTHER half, which would feed zeros: A = -2 delta_ik, B = delta_jk.)
@@ -390,6 +381,22 @@ __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
 #pragma unroll
     for (int e = 0; e < 16; ++e) fro = fmaf(acc[e], acc[e], fro);
     fro = wsum(fro);
+    return ok && isfinite(fro) && sqrtf(fro) * min_eig <= 1.f;
+}
+
+__device__ bool sweep_inverse27(float *M, int lane, float min_eig)
+{
+    LDS_POINTER(M);
+    const int idx = lane & 31, h = lane >> 5;
+    const float *col = M + (idx < K ? idx : 0) + 4 * h * LD;
+    v16f acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r0 = (e & 3) + 8 * (e >> 2); // row of half 0; half 1: + 4
+        const bool inside = idx < K && r0 + 4 * h < K;
+        acc[e] = inside ? col[r0 * LD] : 0.f;
+    }
+    const bool ok = sweep_regs(acc, idx, h, min_eig);
     __syncthreads(); // (every lane has read M)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -397,7 +404,7 @@ __device__ bool sweep_inverse27(float *M, int lane, float min_eig)
         if (idx < K && r0 + 4 * h < K) M[(r0 + 4 * h) * LD + idx] = -acc[e];
     }
     __syncthreads();
-    return ok && isfinite(fro) && sqrtf(fro) * min_eig <= 1.f;
+    return ok;
 }
 
 // compact in-place two-sided Jacobi on LD-layout matrices (round-robin pairs, everything through LDS): only used by the rare
@@ -1017,10 +1024,11 @@ template <int PHASE>
 __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                  const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
                                                  int first_item, int nb_items, int *work, Geom27 g, float min_eig, Records27 rec, float *sum,
-                                                 int32_t *cnt)
+                                                 int32_t *cnt, const int *redo /* PHASE 2, optional: [0] count, [1..] the items to process */)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
+    if (PHASE == 2 && redo) nb_items = redo[0];
     // PHASE 1: colour window | covariance window | noise | mean | members            (8.8 KB: 18 wavefronts per CU)
     // PHASE 2: Cm | A | V | Bm (matrix scratch, then the colour window) | cs | noise | mean | fl | members   (as the gather kernel)
     float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ;
@@ -1039,8 +1047,9 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float
 
   WorkCursor cursor = work_begin();
   for (;;) {
-    const int slot = work_next(work, nb_items, lane, cursor);
+    int slot = work_next(work, nb_items, lane, cursor);
     if (slot < 0) break;
+    if (PHASE == 2 && redo) slot = __builtin_amdgcn_readfirstlane(redo[1 + slot]);
     const int p = __builtin_amdgcn_readfirstlane(list[first_item + slot]);
     const int pr = p / W, pc = p - pr * W;
     float *recA = rec.A + (size_t)slot * MSZ, *recC = rec.C + (size_t)slot * MSZ, *recX = rec.aux + (size_t)slot * AUX27;
@@ -1182,6 +1191,225 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_finish27w: FINISH of the windowed path with the 27 x 27 algebra in registers.  Every matrix of Steps 1 and 2 after the eigensolver
+// is symmetric or enters a product next to a symmetric one, and a symmetric matrix in the accumulator layout of v_mfma_f32_32x32x2_f32
+// (lane (j, h) holds M[r][j], r = (e & 3) + 8 (e >> 2) + 4 h, e = 0..15) is ALSO a valid A operand and a valid B operand of the next
+// product when the sum over k runs in the order k = r(s, h), s = 0..15: lane (i, h) feeds A[i][k] = M[k][i], lane (j, h) feeds
+// B[k][j] = M[k][j] -- the same register.  A product's result D comes back "by columns" (lane j holds column j), which is what a B
+// operand wants and, read as D^T, what an A operand wants; so the chain is arranged to need only transposes it can have for free:
+//     P    = (V max(0, lambda)) V^T + N         operands straight from the record in HBM (rows of V, 14 consecutive floats per lane)
+//     -C1  = sweep(P)                           27 rank-1 products (sweep_regs)
+//     F^T  = I - C1 N                           A = C1 (symmetric), B = N (block diagonal, per-lane constants of the item)
+//     G^T  = C F^T                              A = C  (symmetric, from the record), B = F^T
+//     H    = F G^T + N  ( = F C F^T + N )       A = F (= F^T read as an A operand), B = G^T
+//     -C2  = sweep(H)
+//     F2^T = I - C2 N                           -> the A operand of the output pass, xhat = (m - F2 m) + F2 x
+// A sweep that fails its checks (a pivot not positive, lambda_min >= min_eig not proven) is the rare spectral branch of
+// inverseSymmetricMatrix: the item is put on a list and left to k_bayes27w<2>, which is launched on that list afterwards.
+// No matrix goes through LDS (the previous form -- k_bayes27<2>'s, kept for the other search radii -- spent 0.2 of its 0.5 ms per 32 768
+// pixels in LDS round trips of these stages), and LDS holds only the windows: 7.4 KB per wavefront instead of 17.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int F2_ACCS = (WPIX * 3 + 3) / 4 * 4, F2_ACCC = 2 * F2_ACCS, F2_NOISE = F2_ACCC + (WPIX + 3) / 4 * 4;
+constexpr int F2_MEAN = F2_NOISE + 56, F2_MEM = F2_MEAN + 32;   // floats; then WMEM member codes
+
+__global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
+                                                     const int32_t *__restrict__ list, int first_item, int nb_items, int *work, Geom27 g,
+                                                     float min_eig, Records27 rec, float *sum, int32_t *cnt, int *redo /* [0] count, [1..] items */)
+{
+    extern __shared__ float lds[];
+    const int lane0 = threadIdx.x;
+    float *cwin = lds, *accS = lds + F2_ACCS;
+    int *accC = reinterpret_cast<int *>(lds + F2_ACCC);
+    float *noise = lds + F2_NOISE, *mean = lds + F2_MEAN;
+    uint16_t *mem = reinterpret_cast<uint16_t *>(lds + F2_MEM);
+    for (int e = lane0; e < WMEM; e += 64) mem[e] = (uint16_t)(WAW + 1); // (entries past |S| are read, never used: keep them inside the window)
+    if (lane0 < 32) mean[lane0] = 0.f;                                   // (components 27..31: zero padding)
+    __syncthreads();
+    const int W = g.W, H = g.H;
+
+    WorkCursor cursor = work_begin();
+    for (;;) {
+        const int slot = work_next(work, nb_items, lane0, cursor);
+        if (slot < 0) break;
+        // per-lane constants of the accumulator layout, derived afresh in every item from a lane number the compiler cannot see through:
+        // hoisted out of the loop, the dozens of lane-dependent offsets and masks of an item stay live across all of it -- they were what
+        // got spilled, and reloaded one by one with a wait each
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int idx = lane & 31, h = lane >> 5;
+        const bool col_ok = idx < K;
+        const int blk = min(idx, K - 1) / 3, jj = min(idx, K - 1) - 3 * blk;
+        const int nz_off0 = blk * 6 + noise_idx(0, jj), nz_off1 = blk * 6 + noise_idx(1, jj), nz_off2 = blk * 6 + noise_idx(2, jj);
+        const int u_blk = col_ok ? 3 * blk - 4 * h : -100;   // row r(e, h) is line t of the column's 3 x 3 noise block  <=>  r0(e) - u_blk == t
+        const int u_eye = col_ok ? idx - 4 * h : -100;       // r(e, h) == idx  <=>  r0(e) == u_eye
+        // ---- the item's reads from HBM are requested ahead of their use: the record's V rows, eigenvalues, noise and mean and the colour
+        // window here; C just before the first sweep, whose 27 dependent products cover its latency.  (The stages below are fenced with
+        // sched_barrier: left alone, the scheduler hoists every load of the item to the top and needs 264 registers -- 64 of them spilled
+        // at three wavefronts per SIMD; in stage order the peak is about 110.)
+        const float *recV = rec.V + (size_t)slot * MSZ, *recC = rec.C + (size_t)slot * MSZ, *recX = rec.aux + (size_t)slot * AUX27;
+        float vA[14], fk[14];
+        {
+            const float2 *rowV = reinterpret_cast<const float2 *>(recV + min(idx, K - 1) * JLD + 14 * h);
+            const float2 *rowE = reinterpret_cast<const float2 *>(rec.eig + (size_t)slot * KP + 14 * h);
+#pragma unroll
+            for (int s_ = 0; s_ < 7; ++s_) {
+                const float2 tv = rowV[s_], te = rowE[s_];
+                vA[2 * s_] = tv.x; vA[2 * s_ + 1] = tv.y;
+                fk[2 * s_] = te.x; fk[2 * s_ + 1] = te.y;
+            }
+        }
+        const float aux_n = recX[min(lane, P * 6 - 1)], aux_m = recX[P * 6 + min(lane, K - 1)];
+        const int p = __builtin_amdgcn_readfirstlane(list[first_item + slot]);
+        const int pr = p / W, pc = p - pr * W;
+        float wv[WIN_SLICE];
+        win_issue<3>(wv, colors, 0, pr, pc, W, H, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane < P * 6) noise[lane] = aux_n;
+        if (lane < K) mean[lane] = aux_m;
+        const int n = decode_members_win(mask, p, g.words, mem, lane);   // (ends with a barrier: noise and mean are visible too)
+
+        // N in the accumulator layout: element (r(e, h), idx) of the block-diagonal noise covariance
+        float Nop[16];
+        {
+            const float nz0 = noise[nz_off0], nz1 = noise[nz_off1], nz2 = noise[nz_off2];   // (columns 27..31: u_blk keeps them out)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int t = (e & 3) + 8 * (e >> 2) - u_blk;
+                Nop[e] = t == 0 ? nz0 : (t == 1 ? nz1 : (t == 2 ? nz2 : 0.f));
+            }
+        }
+        // ---- Step 1 (:421-436), second half
+        v16f acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = Nop[e];
+#pragma unroll
+        for (int s_ = 0; s_ < 14; ++s_) {
+            const float v = col_ok ? vA[s_] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v * fmaxf(0.f, fk[s_]), v, acc, 0, 0, 0);   // V max(0, lambda) V^T + N; clampNegativeEigenValues (:606-630)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float cS[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cS[e] = recC[min((e & 3) + 8 * (e >> 2) + 4 * h, K - 1) * LD + min(idx, K - 1)];   // (clamped addresses: no branches)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!sweep_regs(acc, idx, h, min_eig)) { // rare: the spectral branch of inverseSymmetricMatrix (:578-604) -- the item is left to k_bayes27w<2>
+            if (lane == 0) redo[1 + atomicAdd(redo, 1)] = slot;
+            continue;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        win_commit<3>(cwin, wv, 0, lane);   // (nothing else uses the LDS windows during the algebra)
+        v16f FT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) FT[e] = ((e & 3) + 8 * (e >> 2) == u_eye) ? 1.f : 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) FT = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s_], Nop[s_], FT, 0, 0, 0);         // F^T = I - C1 N  (acc = -C1)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- Step 2 (:438-453)
+        v16f GT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) GT[e] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const bool inside = col_ok && (s_ & 3) + 8 * (s_ >> 2) + 4 * h < K;
+            GT = __builtin_amdgcn_mfma_f32_32x32x2f32(inside ? cS[s_] : 0.f, FT[s_], GT, 0, 0, 0);                       // G^T = C F^T
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = Nop[e];
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], GT[s_], acc, 0, 0, 0);          // F C F^T + N
+        __builtin_amdgcn_sched_barrier(0);
+        if (!sweep_regs(acc, idx, h, min_eig)) {
+            if (lane == 0) redo[1 + atomicAdd(redo, 1)] = slot;
+            continue;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // finalDenoisingMatrixMultiplication (:656-670) as xhat = (m - F2 m) + F2 x, F2 = I - N C2 (the same affine map as x - G2 (x - m))
+#pragma unroll
+        for (int e = 0; e < 16; ++e) FT[e] = ((e & 3) + 8 * (e >> 2) == u_eye) ? 1.f : 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) FT = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s_], Nop[s_], FT, 0, 0, 0);         // F2^T = I - C2 N: lane (i, h) holds F2[i][r(s, h)]
+        __builtin_amdgcn_sched_barrier(0);
+        v16f c0;
+        {
+            float mreg[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { mreg[e] = mean[(e & 3) + 8 * (e >> 2) + 4 * h]; c0[e] = 0.f; }
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], mreg[s_], c0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c0[e] = mreg[e] - c0[e];                                                          // m - F2 m
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the zeroed aggregation window
+        for (int e = lane; e < F2_NOISE - F2_ACCS; e += 64) accS[e] = 0.f;   // (sums and counts are contiguous)
+        __syncthreads();
+        // ---- output pass, 32 members per product: lane (j, h) feeds B = x_j[r(s, h)] and gets back components r(e, h) of member j
+        for (int i0 = 0; i0 < n; i0 += 32) {
+            const bool valid = i0 + idx < n;
+            const int wp = mem[valid ? i0 + idx : 0];
+            const int base = (wp - WAW - 1) * 3;                // top-left pixel of the member's patch in the window, floats
+            // component r = r0 + 4 h is r + 36 (r / 9) floats into the patch: r0 + 36 (r0 / 9) plus 4 h -- or 40 h where r0 + 4 is on the
+            // next patch line -- i.e. a compile-time offset from one of two per-lane bases, for the operand reads and for the sums alike
+            const float *x4 = cwin + base + 4 * h, *x40 = cwin + base + 40 * h;
+            v16f y = c0;
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                const int r0 = (s_ & 3) + 8 * (s_ >> 2);
+                float bq;
+                if (r0 <= 19) bq = ((r0 + 4) / 9 != r0 / 9 ? x40 : x4)[r0 + 36 * (r0 / 9)];
+                else if (r0 < K) bq = (h ? cwin + base : x4 + r0 + 72)[0];   // r0 = 24..26: half 1 is padding (its A operand is zero: any finite cell)
+                else bq = cwin[base];                                       // r0 = 27: padding in both halves
+                y = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], bq, y, 0, 0, 0);
+            }
+            if (valid) {
+                float *d4 = accS + base + 4 * h, *d40 = accS + base + 40 * h;
+                // Plain read-add-write, not ds_add_f32: the LDS float atomic is served one lane at a time on gfx950 (193 cycles of the CU's
+                // LDS pipe per wavefront instruction, measured: tools/ubench/lds_rate.hip; a read is 2.5 and a write 4.7), and there is
+                // nobody to be atomic against -- one wavefront per workgroup, and within one instruction the 64 addresses are distinct:
+                // two members' patches are whole pixels (multiples of 3 floats) apart, the two halves' components 4 or 40 floats.
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {                     // r0 <= 19: both halves inside the 27 components
+                    const int r0 = (e & 3) + 8 * (e >> 2);
+                    float *q = ((r0 + 4) / 9 != r0 / 9 ? d40 : d4) + r0 + 36 * (r0 / 9);
+                    *q = *q + y[e];
+                    // (the NEXT component of another lane may be this address: program order must be kept -- the compiler only reasons about
+                    // one lane, where the addresses differ; the hardware serves a wavefront's LDS instructions in order)
+                    asm volatile("" ::: "memory");
+                }
+                // the 9 pixels of the patch, counted once each: pixel q is (q % 3) + 15 (q / 3) cells from the top-left one; half 0 takes
+                // q = 0..4, half 1 q = 5..8
+                int *c17 = accC + (wp - WAW - 1) + 17 * h, *c29 = accC + (wp - WAW - 1) + 29 * h;
+                atomicAdd(c17, 1);
+                atomicAdd(c29 + 1, 1);
+                atomicAdd(c29 + 2, 1);
+                atomicAdd(c17 + 15, 1);
+                if (!h) {
+#pragma unroll
+                    for (int e = 12; e < 15; ++e) { float *q = d4 + 24 + (e - 12) + 72; *q = *q + y[e]; asm volatile("" ::: "memory"); } // r0 = 24..26
+                    atomicAdd(c17 + 16, 1);
+                }
+            }
+        }
+        __syncthreads();
+        // aggregateOutputPatches (:672-693): one global atomic per touched value of the window, rows contiguous
+        {
+            constexpr int row3 = WAW * 3;
+            const long long base = (long long)p - (long long)(WB + 1) * W - (WB + 1); // window origin; untouched cells may lie outside the image
+            for (int e = lane; e < WAW * row3; e += 64) {
+                int wy = e / row3, r = e - wy * row3, wx = r / 3;
+                if (accC[wy * WAW + wx] != 0) unsafeAtomicAdd(sum + (base + (long long)wy * W) * 3 + r, accS[e]);
+            }
+            for (int e = lane; e < WPIX; e += 64) {
+                int wy = e / WAW, wx = e - wy * WAW, c = accC[e];
+                if (c != 0) atomicAdd(cnt + (base + (long long)wy * W + wx), c);
+            }
+        }
+        __syncthreads(); // the next item reuses the LDS
+    }
+}
+
 } // namespace
 
 // LDS of the widest phase (PHASE 2: four matrix buffers)
@@ -1191,8 +1419,8 @@ size_t bcd_bayes27_lds_bytes(int b)
     return (size_t)(4 * MSZ + 2 * KP + P * 6 + (K + 1) + KP) * sizeof(float) + (((size_t)side * side * sizeof(uint16_t) + 15) & ~(size_t)15);
 }
 
-// bytes of HBM one processed pixel needs between the phases (A, V, C, noise + mean, eigenvalues)
-size_t bcd_bayes27_record_bytes() { return (size_t)(3 * MSZ + AUX27 + KP) * sizeof(float); }
+// bytes of HBM one processed pixel needs between the phases (A, V, C, noise + mean, eigenvalues, its entry of the redo list)
+size_t bcd_bayes27_record_bytes() { return (size_t)(3 * MSZ + AUX27 + KP) * sizeof(float) + 2 * sizeof(int); } // (+ the redo list: 1 + items ints)
 
 hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blocks, float *eig, float *V, hipStream_t st);
 
@@ -1221,10 +1449,22 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         const size_t wl2 = (size_t)W2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
         const int w_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / wl1), w_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / wl2);
         hipLaunchKernelGGL(k_bayes27w<1>, dim3(std::min(nb_items, num_cus * w_cu1)), dim3(64), wl1, st, colors, pixcov, mask, list, first_item, nb_items,
-                           d_work, g, min_eig, rec, sum, cnt);
+                           d_work, g, min_eig, rec, sum, cnt, nullptr);
         { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * w_cu2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
-                           d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt);
+        static const bool lds_algebra = [] { const char *e = getenv("BCD_HIP_FINISH_LDS"); return e && e[0] == '1'; }();
+        if (lds_algebra)
+            hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * w_cu2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
+                               d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, nullptr);
+        else {
+            // the register-resident finish; the items whose sweep inverse fails its checks (rare) come back on a list for the LDS kernel
+            int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP);
+            { hipError_t e = hipMemsetAsync(redo, 0, sizeof(int), st); if (e != hipSuccess) return e; }
+            const size_t wl3 = (size_t)F2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
+            hipLaunchKernelGGL(k_finish27w, dim3(std::min(nb_items, num_cus * 12)), dim3(64), wl3, st, colors, mask, list, first_item, nb_items,
+                               d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo);
+            hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * w_cu2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
+                               d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo);
+        }
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
