@@ -1268,6 +1268,8 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
         if (lane < P * 6) noise[lane] = aux_n;
         if (lane < K) mean[lane] = aux_m;
         const int n = decode_members_win(mask, p, g.words, mem, lane);   // (ends with a barrier: noise and mean are visible too)
+        win_commit<3>(cwin, wv, 0, lane);   // (nothing else uses the LDS windows during the algebra; the loads return with the record's)
+        __builtin_amdgcn_sched_barrier(0);
 
         // N in the accumulator layout: element (r(e, h), idx) of the block-diagonal noise covariance
         float Nop[16];
@@ -1298,7 +1300,6 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
             continue;
         }
         __builtin_amdgcn_sched_barrier(0);
-        win_commit<3>(cwin, wv, 0, lane);   // (nothing else uses the LDS windows during the algebra)
         v16f FT;
 #pragma unroll
         for (int e = 0; e < 16; ++e) FT[e] = ((e & 3) + 8 * (e >> 2) == u_eye) ? 1.f : 0.f;
