@@ -57,7 +57,7 @@ size_t bcd_bayes_lds_bytes(int w, int b);
 size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
 size_t bcd_bayes27_record_bytes();
 hipError_t bcd_launch_bayes27(const float *, const float *, const uint32_t *, const int32_t *, int, int, int *, int, int, int, int, float, float *, float *,
-                              int32_t *, hipStream_t);
+                              int32_t *, int *, hipStream_t);
 hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, const int32_t *, int *, int, int, int, int,
                                    int, float, float *, int32_t *, float *, size_t, hipStream_t);
 hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, const int32_t *, int, int, int, int, int, float *,
@@ -449,9 +449,10 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     RCCHK(ensure(ctx, wk.strong, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.weak, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
-    int32_t *d_c = (int32_t *)wk.counters.p + 16; // [0] strong, [1] weak, [2..3] sum |S|, [4..6] work counters of the estimate kernels
+    int32_t *d_c = (int32_t *)wk.counters.p + 16; // [0] strong, [1] weak, [2..3] sum |S|, [4..6] work counters of the generic estimate kernel, [7] spectral inverses
     static const bool weak_lists = [] { const char *e = getenv("BCD_HIP_WEAK_LISTS"); return e && e[0] == '1'; }();
     const bool weak_tiles = w == 1 && !weak_lists;
+    wk.h_counters[23] = 0;
     // the two paths only meet in the atomic accumulators: the fallback pixels run on a side stream.  The tiled fallback kernel needs no
     // list (it reads states and |S| itself), so it starts at once -- beside the list compaction and the host round trip for the number of
     // full estimates, during which this scale would otherwise leave the chip idle -- and is out of the way when the prepare kernel arrives
@@ -490,8 +491,9 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
             const int n = std::min(chunk_max, n_strong - first);
             HIPCHK(ctx, hipMemsetAsync(wk.work_q.p, 0, BCD_WORK_INTS * sizeof(int32_t), wk.stream)); // the work queues of the three kernels
             HIPCHK(ctx, bcd_launch_bayes27(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, first, n, (int *)wk.work_q.p, cus, W, H, b, min_eig,
-                                           (float *)wk.gscratch.p, d_sum, d_count, wk.stream));
+                                           (float *)wk.gscratch.p, d_sum, d_count, d_c + 7, wk.stream));
         }
+        HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 23, d_c + 7, sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream)); // read after the scale's last synchronisation
     } else {
         const size_t per_block = bcd_bayes_scratch_bytes_per_block(w, b);
         const int strong_blocks = (int)std::min<int64_t>(cap, 1024); // generic kernel: 1024 scratch slices
@@ -566,6 +568,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     st.similarity_path = wk.border_capacity > 0 ? 1 : 0;
     st.borderline_pairs = wk.border_capacity > 0 ? wk.h_counters[43] : 0;
     st.cu_share = ctx->cu_share_pct * (&wk != &ctx->main ? ctx->coarse_share : 100) / 100;
+    st.spectral_inverses = wk.h_counters[23];
     if (prof) {
         st.ms_similarity = stage_ms(wk, 0, 1);
         st.ms_active = stage_ms(wk, 1, 2);

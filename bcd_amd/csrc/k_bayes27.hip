@@ -1215,7 +1215,8 @@ constexpr int F2_MEAN = F2_NOISE + 56, F2_MEM = F2_MEAN + 32;   // floats; then 
 
 __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
                                                      const int32_t *__restrict__ list, int first_item, int nb_items, int *work, Geom27 g,
-                                                     float min_eig, Records27 rec, float *sum, int32_t *cnt, int *redo /* [0] count, [1..] items */)
+                                                     float min_eig, Records27 rec, float *sum, int32_t *cnt, int *redo /* [0] count, [1..] items */,
+                                                     int *redo_total /* statistics: items handed over, all launches of the scale */)
 {
     extern __shared__ float lds[];
     const int lane0 = threadIdx.x;
@@ -1296,7 +1297,7 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
         for (int e = 0; e < 16; ++e) cS[e] = recC[min((e & 3) + 8 * (e >> 2) + 4 * h, K - 1) * LD + min(idx, K - 1)];   // (clamped addresses: no branches)
         __builtin_amdgcn_sched_barrier(0);
         if (!sweep_regs(acc, idx, h, min_eig)) { // rare: the spectral branch of inverseSymmetricMatrix (:578-604) -- the item is left to k_bayes27w<2>
-            if (lane == 0) redo[1 + atomicAdd(redo, 1)] = slot;
+            if (lane == 0) { redo[1 + atomicAdd(redo, 1)] = slot; atomicAdd(redo_total, 1); }
             continue;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1322,7 +1323,7 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
         for (int s_ = 0; s_ < 16; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], GT[s_], acc, 0, 0, 0);          // F C F^T + N
         __builtin_amdgcn_sched_barrier(0);
         if (!sweep_regs(acc, idx, h, min_eig)) {
-            if (lane == 0) redo[1 + atomicAdd(redo, 1)] = slot;
+            if (lane == 0) { redo[1 + atomicAdd(redo, 1)] = slot; atomicAdd(redo_total, 1); }
             continue;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1429,7 +1430,7 @@ hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blo
 // (bcd_bayes27_record_bytes() each), d_work BCD_WORK_INTS zeroed ints (the work queues of the three kernels).
 hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int first_item, int nb_items,
                               int *d_work, int num_cus, int W, int H, int b, float min_eig, float *records, float *sum,
-                              int32_t *cnt, hipStream_t st)
+                              int32_t *cnt, int *d_spectral /* += items whose inverse took the spectral branch (windowed path) */, hipStream_t st)
 {
     if (nb_items <= 0) return hipSuccess;
     Geom27 g;
@@ -1462,8 +1463,10 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
             { hipError_t e = hipMemsetAsync(redo, 0, sizeof(int), st); if (e != hipSuccess) return e; }
             const size_t wl3 = (size_t)F2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
             hipLaunchKernelGGL(k_finish27w, dim3(std::min(nb_items, num_cus * 12)), dim3(64), wl3, st, colors, mask, list, first_item, nb_items,
-                               d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo);
-            hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * w_cu2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
+                               d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo, d_spectral);
+            // (normally an empty list: a small grid, so that its 17 KB workgroups do not queue for LDS behind the kernels of the other scales --
+            // a full-size launch that only reads "0 items" was seen waiting 0.7 ms for room.  A long list is still processed, by fewer wavefronts.)
+            hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * 2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
                                d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo);
         }
         return hipGetLastError();

@@ -33,7 +33,7 @@ class ScaleStats(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("main_pixels", C.c_int64), ("processed", C.c_int64),
                 ("fallback", C.c_int64), ("similar_total", C.c_int64), ("active_rounds", C.c_int32),
                 ("ms_similarity", C.c_float), ("ms_active", C.c_float), ("ms_bayes", C.c_float), ("ms_total", C.c_float),
-                ("similarity_path", C.c_int32), ("borderline_pairs", C.c_int32), ("cu_share", C.c_int32), ("reserved_", C.c_int32)]
+                ("similarity_path", C.c_int32), ("borderline_pairs", C.c_int32), ("cu_share", C.c_int32), ("spectral_inverses", C.c_int32)]
 
 
 # every symbol include/bcd_hip.h declares (checked by tests/test_abi.py)

@@ -106,7 +106,7 @@ def per_scale_stats(ctx, S):
                        "processed_frac": round(st.processed / max(1, st.main_pixels), 4),
                        "fallback_frac": round(st.fallback / max(1, st.processed), 4),
                        "mean_similar": round(st.similar_total / max(1, st.processed), 2), "rounds": st.active_rounds,
-                       "borderline_pairs": st.borderline_pairs if st.similarity_path == 1 else None, "cu_share_pct": st.cu_share})
+                       "borderline_pairs": st.borderline_pairs if st.similarity_path == 1 else None, "cu_share_pct": st.cu_share, "spectral_inverses": st.spectral_inverses})
     return scales
 
 

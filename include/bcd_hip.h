@@ -70,7 +70,8 @@ typedef struct bcd_hip_scale_stats {
     int32_t similarity_path;  /* 1 = approximate planes + exact verification at the threshold, 0 = exact planes */
     int32_t borderline_pairs; /* pairs re-evaluated exactly (similarity_path == 1)  */
     int32_t cu_share;         /* share (%) of the CU slots this scale's persistent estimate kernels took (100: all)  */
-    int32_t reserved_;
+    int32_t spectral_inverses; /* full estimates (3x3 patches, default search radius) whose matrix inverse failed the sweep's checks and took
+                                  the spectral branch of inverseSymmetricMatrix in the LDS kernel (normally 0)        */
 } bcd_hip_scale_stats;
 
 /* ---- context ------------------------------------------------------------------------------ */

@@ -264,6 +264,12 @@ def test_large_min_eigenvalue_takes_the_spectral_path(hipctx):
         got = hipctx.denoise(*dev(col, ns, hist, cov), 1, bh.default_params(m=0.0, min_eig=e)).cpu().numpy()
         want = ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0, min_eig=e))
         assert rel_linf(got, want) < TOL
+        # the register-resident finish kernel hands such items to the LDS kernel (k_bayes27.hip: redo list): the path this test is about
+        st = hipctx.stats(0)
+        assert 0 < st.spectral_inverses <= st.processed - st.fallback
+    # ... and with the reference's default floor no item of this frame needs it
+    hipctx.denoise(*dev(col, ns, hist, cov), 1, bh.default_params(m=0.0))
+    assert hipctx.stats(0).spectral_inverses == 0
 
 
 # ---- BASELINE.json sizes: size-independent properties ----------------------------------------------------------
