@@ -39,6 +39,8 @@
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 constexpr int RW_TW = 64, RW_TH = 4;   // tile
 constexpr int RW_CW = 12;              // widest span of column displacements served by one staged window
 constexpr int RW_NCOLS = RW_TW + RW_CW;
@@ -187,8 +189,9 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                 const float *nb_next = nrow + (lane + min(j + 2, nc - 1)) * D; // (a harmless re-read after the last displacement)
                 float n2 = 1.f, n12 = 1.f;
                 if (!UNI) { n2 = nrow_n[lane + j]; n12 = n1 * n2; }
-                float sum = 0.f;
-                uint32_t cnt = 0;
+                // (sum, number of bins counted) as one packed pair: the bin's term and its count go in with a single v_pk_fma_f32
+                v2f acc2 = { 0.f, 0.f };
+                v2f pd = { 0.f, 1.f }, pr = { 0.f, 1.f };
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                     const float4 v = pf[q % PF];
@@ -215,8 +218,9 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                         for (int e = 0; e < 4; ++e)
                             if (sg[e] > 1.f) {
                                 asm volatile(""); // keep the branch: no if-conversion into selects
-                                sum = fmaf(term(e), __builtin_amdgcn_rcpf(den(sg[e])), sum);
-                                ++cnt;
+                                pd.x = term(e);
+                                pr.x = __builtin_amdgcn_rcpf(den(sg[e]));
+                                acc2 = __builtin_elementwise_fma(pd, pr, acc2);
                             }
                     }
                 }
@@ -230,8 +234,8 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                 const int nc_ = c + dc;
                 if (inside && nc_ >= 0 && nc_ < W && nr < H) {
                     const size_t o = (size_t)bcd_delta_index(dl, dc, b) * plane + pix;
-                    T[o] = __float2half_rn(sum); // binary16 plane (a sum beyond 65504 becomes +inf: far above any admitted tau)
-                    Cn[o] = (uint8_t)cnt;
+                    T[o] = __float2half_rn(acc2.x); // binary16 plane (a sum beyond 65504 becomes +inf: far above any admitted tau)
+                    Cn[o] = (uint8_t)(int)acc2.y;
                 }
             }
             if (dl < b) {
