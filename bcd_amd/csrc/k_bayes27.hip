@@ -319,6 +319,281 @@ __global__ __launch_bounds__(64, 3) void k_jacobi27_batch(const float *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_jacobi27_quads: the same two-sided Jacobi (two matrices per wavefront, rows in registers, scaled rotations, V~ accumulated in
+// registers), with the rows moved through LDS once per THREE rounds instead of once per round.
+// k_jacobi27_batch is bound by the LDS pipe, not by arithmetic: per wavefront and round ~97 cycles for the 7 ds_write_b128 of the rows
+// (a 16-byte store costs 13.9 cycles per wavefront instruction, three times a load: tools/ubench/lds_rate.hip) + 64 for the row and
+// rotation-table loads + ~25 for pivots and scales = ~186 cycles of a pipe that 12 wavefronts share, against ~130 CU-cycles of vector
+// work (r3: removing six of the seven row stores made the kernel 22 % faster).
+// Here a sweep is 9 "super-rounds".  In each the 28 slots form 7 quads of neighbouring lanes and ALL SIX pairs of a quad are rotated --
+// three rounds, partners at lane distance 1, 2, 3 (xor), every exchange a DPP quad_perm, every column pair a compile-time register
+// pair -- before the rows go back to LDS at their next positions.  The nine partitions into quads are the parallel classes of a
+// resolvable 2-(28,4,1) design (tools/jacobi_schedule.py: every pair of slots shares a quad exactly once per sweep; two lane
+// permutations, JSX and JSY, applied x x y x x y x x y, bring every slot home after the ninth).  The rotations of the second and third
+// round depend on the first's results, but only on the 4 x 4 diagonal block of the quad: each lane carries its row of that block along
+// (4 values, in xor-relative order: w[y] = A~[me][me ^ y], so that every index is a compile-time constant in every lane) and the three
+// rounds' angles come out of it before the 28-wide rows are touched.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int JSX[28] = { 1, 6, 12, 8, 10, 24, 0, 17, 19, 11, 20, 14, 23, 5, 9, 26, 15, 25, 22, 3, 4, 18, 21, 2, 13, 7, 16, 27 };
+constexpr int JSY[28] = { 7, 17, 1, 9, 18, 8, 25, 23, 11, 13, 22, 5, 6, 3, 24, 20, 10, 2, 26, 14, 21, 15, 16, 0, 19, 12, 4, 27 };
+// start of row r of a matrix in LDS, floats: no bank conflict in the loads (lane l reads row l) nor in the stores (lane l writes row
+// JSX[l] or JSY[l]) of ds_*_b128 -- found and checked by tools/jacobi_schedule.py
+constexpr int JPLACE[28] = { 196, 252, 308, 28, 364, 564, 392, 84, 112, 168, 280, 708, 596, 140, 748, 336, 476, 652, 0, 508, 624, 776, 536, 56, 224, 420, 448, 680 };
+constexpr int JIDLE_ROW = 15;                       // what the idle lanes 28..31 of a half read
+constexpr int JQ_MAT = 808;                         // floats per matrix (804 used)
+constexpr int JQ_HALF = JQ_MAT + 32 + 3 * 32;       // + scales + the three rounds' rotation tables
+
+// sum over the 32 lanes of a half, without address registers (ds_swizzle, xor mode)
+__device__ inline float half_sum_swz(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (16 << 10) | 0x1f));
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (8 << 10) | 0x1f));
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (4 << 10) | 0x1f));
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (2 << 10) | 0x1f));
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (1 << 10) | 0x1f));
+    return v;
+}
+
+template <int X> __device__ inline float dpp_xor(float v)   // v of lane ^ X inside the quad
+{
+    constexpr int ctrl = X == 1 ? 0xB1 /* [1,0,3,2] */ : (X == 2 ? 0x4E /* [2,3,0,1] */ : 0x1B /* [3,2,1,0] */);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
+}
+
+// x[k] += ms * (x[k] of lane ^ X): rowrot_dpp for the three partners of a quad
+#define BCD_ROWROT(NAME, PERM)                                                                                                              \
+    __device__ inline void NAME(float (&x)[28], float ms)                                                                                   \
+    {                                                                                                                                       \
+        asm volatile("s_nop 1\n\t" BCD_G(0, PERM) BCD_G(1, PERM) BCD_G(2, PERM) BCD_G(3, PERM) BCD_G(4, PERM) BCD_G(5, PERM) BCD_G(6, PERM)  \
+                     BCD_G(7, PERM) BCD_G(8, PERM) BCD_G(9, PERM) BCD_G(10, PERM) BCD_G(11, PERM) BCD_G(12, PERM) BCD_G(13, PERM)            \
+                     BCD_G(14, PERM) BCD_G(15, PERM) BCD_G(16, PERM) BCD_G(17, PERM) BCD_G(18, PERM) BCD_G(19, PERM) BCD_G(20, PERM)         \
+                     BCD_G(21, PERM) BCD_G(22, PERM) BCD_G(23, PERM) BCD_G(24, PERM) BCD_G(25, PERM) BCD_G(26, PERM) BCD_G(27, PERM)         \
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),          \
+                       "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]), "+v"(x[16]), "+v"(x[17]),  \
+                       "+v"(x[18]), "+v"(x[19]), "+v"(x[20]), "+v"(x[21]), "+v"(x[22]), "+v"(x[23]), "+v"(x[24]), "+v"(x[25]), "+v"(x[26]), \
+                       "+v"(x[27])                                                                                                          \
+                     : "v"(ms));                                                                                                            \
+    }
+#define BCD_G(i, PERM) "v_fmac_f32_dpp %" #i ", %" #i ", %28 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+BCD_ROWROT(rowrot_x1, "[1,0,3,2]")
+BCD_ROWROT(rowrot_x2, "[2,3,0,1]")
+BCD_ROWROT(rowrot_x3, "[3,2,1,0]")
+#undef BCD_G
+#undef BCD_ROWROT
+template <int X> __device__ inline void rowrot_quad(float (&x)[28], float ms)
+{
+    if (X == 1) rowrot_x1(x, ms); else if (X == 2) rowrot_x2(x, ms); else rowrot_x3(x, ms);
+}
+
+// one round of a super-round in the quad's 4 x 4 block: my coefficient of the rotation of (me, me ^ X), the block row and scale updated
+template <int X>
+__device__ inline float quad_round(float (&w)[4], float &dme, bool lo, bool frozen)
+{
+    const float pdiag = dpp_xor<X>(w[0]), pd = dpp_xor<X>(dme);
+    // (both lanes of the pair must compute the SAME rotation: the off-diagonal element is taken from the lower lane's row -- the two
+    // copies of a symmetric element agree only to rounding)
+    const float poff = dpp_xor<X>(w[X]);
+    const float app_s = lo ? w[0] : pdiag, aqq_s = lo ? pdiag : w[0], apq_s = lo ? w[X] : poff;
+    const float dp = lo ? dme : pd, dq = lo ? pd : dme;
+    float mbeta = 0.f, alpha = 0.f, c = 1.f;
+    if (apq_s != 0.f && !frozen) {
+        const float apq = dp * dq * apq_s, app = dp * dp * app_s, aqq = dq * dq * aqq_s;
+        // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working precision, not the exact minimiser
+        const float theta = (aqq - app) * __builtin_amdgcn_rcpf(2.f * apq);
+        if (fabsf(theta) < 1e18f) { // (otherwise theta^2 overflows: the rotation is the identity to fp32)
+            float t = __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.f)));
+            t = theta < 0.f ? -t : t;
+            c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
+            const float ratio = dq * __builtin_amdgcn_rcpf(dp);
+            mbeta = -t * ratio;
+            alpha = t * __builtin_amdgcn_rcpf(ratio);
+        }
+    }
+    const float mine = lo ? mbeta : alpha;   // slot p = the lower lane: x' = x - beta y; slot q: y' = y + alpha x
+    dme *= c;
+    // the block row: column rotations (the coefficient of column me ^ y is the one lane me ^ y holds), then the row rotation
+    const float rc1 = dpp_xor<1>(mine), rc2 = dpp_xor<2>(mine), rc3 = dpp_xor<3>(mine);
+    const float rc[4] = { mine, rc1, rc2, rc3 };
+    float nw[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) nw[y] = fmaf(rc[y], w[y ^ X], w[y]);
+#pragma unroll
+    for (int y = 0; y < 4; ++y) w[y] = fmaf(mine, dpp_xor<X>(nw[y ^ X]), nw[y]);
+    return mine;
+}
+
+// one super-round (see k_jacobi27_quads); YSTEP: the rows then move by JSY, otherwise by JSX
+template <bool YSTEP>
+__device__ __forceinline__ void jacobi_super_round(float (&vrow)[JLD], float *src, const float *wsrc, float *dst, float *dv_h, float *rot_h, int r,
+                                                   int me, int snext, bool isRow, bool settled)
+{
+        float row[JLD];
+#pragma unroll
+        for (int q4 = 0; q4 < JLD / 4; ++q4) {
+            float4 v = reinterpret_cast<const float4 *>(src)[q4];
+            row[4 * q4] = v.x; row[4 * q4 + 1] = v.y; row[4 * q4 + 2] = v.z; row[4 * q4 + 3] = v.w;
+        }
+        // my row of the quad's diagonal block, xor-relative, and my scale
+        float w[4] = { wsrc[me], wsrc[me ^ 1], wsrc[me ^ 2], wsrc[me ^ 3] };
+        float dme = dv_h[isRow ? r : 0];
+        const float m1 = quad_round<1>(w, dme, (me & 1) == 0, settled);
+        const float m2 = quad_round<2>(w, dme, (me & 2) == 0, settled);
+        const float m3 = quad_round<3>(w, dme, me == 0 || me == 1, settled);   // pairs (0,3), (1,2): the lower lane is 0 resp. 1
+        if (isRow) {
+            rot_h[r] = m1; rot_h[32 + r] = m2; rot_h[64 + r] = m3;
+            dv_h[snext] = dme; // the scales move with their slots
+        }
+        wave_sync();
+        // the three rounds on the rows of A~ (columns in registers, rows by DPP) and on the rows of V~ (columns)
+#define BCD_ROUND(X, MINE)                                                                                                            \
+        {                                                                                                                      \
+            float rot[JLD];                                                                                                    \
+            _Pragma("unroll") for (int q4 = 0; q4 < JLD / 4; ++q4) {                                                           \
+                float4 w4 = reinterpret_cast<const float4 *>(rot_h + 32 * (X - 1))[q4];                                        \
+                rot[4 * q4] = w4.x; rot[4 * q4 + 1] = w4.y; rot[4 * q4 + 2] = w4.z; rot[4 * q4 + 3] = w4.w;                    \
+            }                                                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < JLD; ++k)                                                                    \
+                if ((k & 3) < ((k ^ X) & 3)) {                                                                                 \
+                    const int q = k ^ X;                                                                                       \
+                    const float xv = vrow[k], yv = vrow[q];                                                                    \
+                    vrow[k] = fmaf(rot[k], yv, xv); vrow[q] = fmaf(rot[q], xv, yv);                                            \
+                }                                                                                                              \
+            /* (pinned here: the optimiser otherwise sinks all of a sweep's updates of V~ to the end of the sweep and keeps the    */ \
+            /* 27 rotation tables in scratch memory until then)                                                                 */ \
+            _Pragma("unroll") for (int k = 0; k < JLD; ++k) asm volatile("" : "+v"(vrow[k]));                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                                 \
+            _Pragma("unroll") for (int k = 0; k < JLD; ++k)                                                                    \
+                if ((k & 3) < ((k ^ X) & 3)) {                                                                                 \
+                    const int q = k ^ X;                                                                                       \
+                    const float xa = row[k], ya = row[q];                                                                      \
+                    row[k] = fmaf(rot[k], ya, xa); row[q] = fmaf(rot[q], xa, ya);                                              \
+                }                                                                                                              \
+            rowrot_quad<X>(row, MINE);                                                                                         \
+        }
+        BCD_ROUND(1, m1)
+        __builtin_amdgcn_sched_barrier(0);
+        BCD_ROUND(2, m2)
+        __builtin_amdgcn_sched_barrier(0);
+        BCD_ROUND(3, m3)
+        __builtin_amdgcn_sched_barrier(0);
+#undef BCD_ROUND
+        // back to LDS at the next positions; the same move of the columns is a renaming of registers
+        {
+            float out[JLD], vout[JLD];
+#pragma unroll
+            for (int k = 0; k < JLD; ++k) { out[YSTEP ? JSY[k] : JSX[k]] = row[k]; vout[YSTEP ? JSY[k] : JSX[k]] = vrow[k]; }
+#pragma unroll
+            for (int k = 0; k < JLD; ++k) vrow[k] = vout[k];
+            if (isRow) {
+#pragma unroll
+                for (int q4 = 0; q4 < JLD / 4; ++q4)
+                    reinterpret_cast<float4 *>(dst)[q4] = make_float4(out[4 * q4], out[4 * q4 + 1], out[4 * q4 + 2], out[4 * q4 + 3]);
+            }
+        }
+        wave_sync(); // the rows of A~ are back in LDS before the next super-round reads them
+        __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(64, 3) void k_jacobi27_quads(const float *__restrict__ Ain, int n, int *work, float *__restrict__ eig,
+                                                          float *__restrict__ Vout)
+{
+    __shared__ float4 lds4[(2 * JQ_HALF + 32) / 4];
+    float *lds = reinterpret_cast<float *>(lds4);
+    int *place_tab = reinterpret_cast<int *>(lds + 2 * JQ_HALF);
+    const int lane = threadIdx.x, h = lane >> 5, r = lane & 31;
+    const bool isRow = r < KP;
+    if (lane < KP) place_tab[lane] = JPLACE[lane];
+    float *Ah = lds + h * JQ_HALF, *dv_h = Ah + JQ_MAT, *rot_h = dv_h + 32;
+    const int rr_ = isRow ? r : JIDLE_ROW;
+    const int sx = isRow ? JSX[rr_] : 0, sy = isRow ? JSY[rr_] : 0;
+    float *src = Ah + JPLACE[rr_];                  // (idle lanes: a row of their own ds_read_b128 bank group)
+    float *dst_x = Ah + JPLACE[sx], *dst_y = Ah + JPLACE[sy];
+    const float *wsrc = src + (isRow ? (r & ~3) : 0);   // the quad's columns of my row
+    const int me = r & 3;
+    wave_sync();
+    WorkCursor cursor = work_begin();
+    for (;;) {
+        const int pair = work_next(work, (n + 1) / 2, lane, cursor);
+        if (pair < 0) break;
+        const int first = 2 * pair;
+        const int item = first + h;
+        const bool live = item < n;
+        // matrix -> LDS (an absent second matrix is the identity: converged from the start)
+        {
+            const float4 *gsrc = reinterpret_cast<const float4 *>(Ain + (size_t)(live ? item : first) * (KP * JLD));
+            for (int e = r; e < KP * JLD / 4; e += 32) {
+                float4 v = gsrc[e];
+                const int e0 = 4 * e, rr = e0 / JLD, c0 = e0 - rr * JLD;
+                if (!live) v = make_float4(rr == c0, rr == c0 + 1, rr == c0 + 2, rr == c0 + 3);
+                *reinterpret_cast<float4 *>(Ah + place_tab[rr] + c0) = v;
+            }
+            if (isRow) dv_h[r] = 1.f;
+        }
+        wave_sync();
+        float vrow[JLD];
+#pragma unroll
+        for (int k = 0; k < JLD; ++k) vrow[k] = (k == r) ? 1.f : 0.f; // V = identity
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            // fold the scales: A~ <- D A~ D, V~ <- V~ D, D <- I; off / diagonal norms of the true matrix on the way (as k_jacobi27_batch)
+            float off = 0.f, dg = 0.f;
+            {
+                float dk[JLD];
+#pragma unroll
+                for (int q4 = 0; q4 < JLD / 4; ++q4) {
+                    float4 w4 = reinterpret_cast<const float4 *>(dv_h)[q4];
+                    dk[4 * q4] = w4.x; dk[4 * q4 + 1] = w4.y; dk[4 * q4 + 2] = w4.z; dk[4 * q4 + 3] = w4.w;
+                }
+                const float dr = dv_h[isRow ? r : 0];
+                float row[JLD];
+#pragma unroll
+                for (int q4 = 0; q4 < JLD / 4; ++q4) {
+                    float4 v = reinterpret_cast<const float4 *>(src)[q4];
+                    row[4 * q4] = v.x; row[4 * q4 + 1] = v.y; row[4 * q4 + 2] = v.z; row[4 * q4 + 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < JLD; ++k) {
+                    row[k] *= dr * dk[k];
+                    vrow[k] *= dk[k];
+                    if (isRow) { if (k == r) dg = fmaf(row[k], row[k], dg); else off = fmaf(row[k], row[k], off); }
+                }
+                wave_sync(); // every lane has read the scales and its row
+                if (isRow) {
+#pragma unroll
+                    for (int q4 = 0; q4 < JLD / 4; ++q4)
+                        reinterpret_cast<float4 *>(src)[q4] = make_float4(row[4 * q4], row[4 * q4 + 1], row[4 * q4 + 2], row[4 * q4 + 3]);
+                    dv_h[r] = 1.f;
+                }
+                wave_sync();
+            }
+            off = half_sum_swz(off);
+            dg = half_sum_swz(dg);
+            // (threshold and freezing of a converged matrix: as k_jacobi27_batch)
+            const bool settled = off <= 1e-10f * dg;
+            if (__builtin_amdgcn_ballot_w64(!settled) == 0) break; // both matrices converged
+            // x x y x x y x x y: one sweep, every slot home again
+            jacobi_super_round<false>(vrow, src, wsrc, dst_x, dv_h, rot_h, r, me, sx, isRow, settled);
+            jacobi_super_round<false>(vrow, src, wsrc, dst_x, dv_h, rot_h, r, me, sx, isRow, settled);
+            jacobi_super_round<true>(vrow, src, wsrc, dst_y, dv_h, rot_h, r, me, sy, isRow, settled);
+            jacobi_super_round<false>(vrow, src, wsrc, dst_x, dv_h, rot_h, r, me, sx, isRow, settled);
+            jacobi_super_round<false>(vrow, src, wsrc, dst_x, dv_h, rot_h, r, me, sx, isRow, settled);
+            jacobi_super_round<true>(vrow, src, wsrc, dst_y, dv_h, rot_h, r, me, sy, isRow, settled);
+            jacobi_super_round<false>(vrow, src, wsrc, dst_x, dv_h, rot_h, r, me, sx, isRow, settled);
+            jacobi_super_round<false>(vrow, src, wsrc, dst_x, dv_h, rot_h, r, me, sx, isRow, settled);
+            jacobi_super_round<true>(vrow, src, wsrc, dst_y, dv_h, rot_h, r, me, sy, isRow, settled);
+        }
+        if (live) {
+            if (isRow) eig[(size_t)item * KP + r] = src[r];
+            if (r < K) {
+                float4 *o = reinterpret_cast<float4 *>(Vout + (size_t)item * (KP * JLD) + r * JLD);
+#pragma unroll
+                for (int q4 = 0; q4 < JLD / 4; ++q4) o[q4] = make_float4(vrow[4 * q4], vrow[4 * q4 + 1], vrow[4 * q4 + 2], vrow[4 * q4 + 3]);
+            }
+        }
+        wave_sync(); // the next pair reuses the LDS
+    }
+}
+
 // JLD-layout copy of the lower triangle of M (LD layout), mirrored, padding row/column zeroed (what Eigen's
 // SelfAdjointEigenSolver reads)
 __device__ void to_jacobi_layout(float *J, const float *M, int lane)
@@ -1486,6 +1761,8 @@ hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blo
     // <padded row placement, DPP-fused row rotation>: measured on 65 536 matrices 31.3 ns per matrix without either, 31.1 with the
     // placement alone (bank conflicts 17 % -> 0.4 % of the LDS cycles), 29.8 with the fused rotation alone (-17 % vector instructions),
     // 29.4 with both
-    hipLaunchKernelGGL((k_jacobi27_batch<true, true>), dim3(blocks), dim3(64), 0, st, A, n, d_work, eig, V);
+    static const bool pairs = [] { const char *e = getenv("BCD_HIP_JACOBI_PAIRS"); return e && e[0] == '1'; }();
+    if (pairs) hipLaunchKernelGGL((k_jacobi27_batch<true, true>), dim3(blocks), dim3(64), 0, st, A, n, d_work, eig, V);
+    else hipLaunchKernelGGL(k_jacobi27_quads, dim3(blocks), dim3(64), 0, st, A, n, d_work, eig, V);
     return hipGetLastError();
 }
