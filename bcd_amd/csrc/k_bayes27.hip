@@ -1576,18 +1576,19 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
             continue;
         }
         __builtin_amdgcn_sched_barrier(0);
+        // (the products below run over s = 0..14: step 15 is k = 27 in half 0 and k = 31 in half 1, zero padding in every operand)
         v16f FT;
 #pragma unroll
         for (int e = 0; e < 16; ++e) FT[e] = ((e & 3) + 8 * (e >> 2) == u_eye) ? 1.f : 0.f;
 #pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) FT = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s_], Nop[s_], FT, 0, 0, 0);         // F^T = I - C1 N  (acc = -C1)
+        for (int s_ = 0; s_ < 15; ++s_) FT = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s_], Nop[s_], FT, 0, 0, 0);         // F^T = I - C1 N  (acc = -C1)
         __builtin_amdgcn_sched_barrier(0);
         // ---- Step 2 (:438-453)
         v16f GT;
 #pragma unroll
         for (int e = 0; e < 16; ++e) GT[e] = 0.f;
 #pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) {
+        for (int s_ = 0; s_ < 15; ++s_) {
             const bool inside = col_ok && (s_ & 3) + 8 * (s_ >> 2) + 4 * h < K;
             GT = __builtin_amdgcn_mfma_f32_32x32x2f32(inside ? cS[s_] : 0.f, FT[s_], GT, 0, 0, 0);                       // G^T = C F^T
         }
@@ -1595,7 +1596,7 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = Nop[e];
 #pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], GT[s_], acc, 0, 0, 0);          // F C F^T + N
+        for (int s_ = 0; s_ < 15; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], GT[s_], acc, 0, 0, 0);          // F C F^T + N
         __builtin_amdgcn_sched_barrier(0);
         if (!sweep_regs(acc, idx, h, min_eig)) {
             if (lane == 0) { redo[1 + atomicAdd(redo, 1)] = slot; atomicAdd(redo_total, 1); }
@@ -1606,7 +1607,7 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
 #pragma unroll
         for (int e = 0; e < 16; ++e) FT[e] = ((e & 3) + 8 * (e >> 2) == u_eye) ? 1.f : 0.f;
 #pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) FT = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s_], Nop[s_], FT, 0, 0, 0);         // F2^T = I - C2 N: lane (i, h) holds F2[i][r(s, h)]
+        for (int s_ = 0; s_ < 15; ++s_) FT = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s_], Nop[s_], FT, 0, 0, 0);         // F2^T = I - C2 N: lane (i, h) holds F2[i][r(s, h)]
         __builtin_amdgcn_sched_barrier(0);
         v16f c0;
         {
@@ -1614,7 +1615,7 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
 #pragma unroll
             for (int e = 0; e < 16; ++e) { mreg[e] = mean[(e & 3) + 8 * (e >> 2) + 4 * h]; c0[e] = 0.f; }
 #pragma unroll
-            for (int s_ = 0; s_ < 16; ++s_) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], mreg[s_], c0, 0, 0, 0);
+            for (int s_ = 0; s_ < 15; ++s_) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], mreg[s_], c0, 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < 16; ++e) c0[e] = mreg[e] - c0[e];                                                          // m - F2 m
         }
@@ -1632,12 +1633,11 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
             const float *x4 = cwin + base + 4 * h, *x40 = cwin + base + 40 * h;
             v16f y = c0;
 #pragma unroll
-            for (int s_ = 0; s_ < 16; ++s_) {
+            for (int s_ = 0; s_ < 15; ++s_) {
                 const int r0 = (s_ & 3) + 8 * (s_ >> 2);
                 float bq;
                 if (r0 <= 19) bq = ((r0 + 4) / 9 != r0 / 9 ? x40 : x4)[r0 + 36 * (r0 / 9)];
-                else if (r0 < K) bq = (h ? cwin + base : x4 + r0 + 72)[0];   // r0 = 24..26: half 1 is padding (its A operand is zero: any finite cell)
-                else bq = cwin[base];                                       // r0 = 27: padding in both halves
+                else bq = (h ? cwin + base : x4 + r0 + 72)[0];   // r0 = 24..26: half 1 is padding (its A operand is zero: any finite cell)
                 y = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], bq, y, 0, 0, 0);
             }
             if (valid) {

@@ -20,7 +20,7 @@ i=1
 for S in "$S1" "$S2" "$S3"; do
   timeout 300 tools/pmc_any.sh final_pd_s$i "$S" pairdist_rw python $R/tools/exp_similarity.py --quick > /dev/null 2>&1
   timeout 300 tools/pmc_any.sh final_eig_s$i "$S" jacobi27 python $R/tools/exp_eig.py 32768 > /dev/null 2>&1
-  BCD_HIP_SERIAL_SCALES=1 timeout 300 tools/pmc_any.sh final_est_s$i "$S" bayes python $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
+  BCD_HIP_SERIAL_SCALES=1 timeout 300 tools/pmc_any.sh final_est_s$i "$S" bayes,finish27 python $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
   i=$((i+1))
 done
 python tools/exp_eig.py 32768 > gpurun_out/final_eig.log 2>&1
