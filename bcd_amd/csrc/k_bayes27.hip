@@ -1,9 +1,12 @@
 // k_bayes27.hip -- full Bayesian estimate of a processed pixel for the default patch radius w = 1 (K = 27): three kernels with a
-// per-pixel record in HBM between them (persistent single-wavefront workgroups, items from a work counter):
+// per-pixel record in HBM between them (persistent single-wavefront workgroups, items from work queues):
 //   k_bayes27w<1> / k_bayes27<1>  PREPARE  members of S(p), noise mean, colour mean, covariance C on the f32 matrix core;
 //                                          record: A = C - N (28 x 28, zero padded), C, N, m
-//   k_jacobi27_batch              SOLVE    eigen-decomposition of every A (clampNegativeEigenValues), two matrices per wavefront
-//   k_bayes27w<2> / k_bayes27<2>  FINISH   clamp, inverses, Step 2, final estimates, aggregation
+//   k_jacobi27_quads              SOLVE    eigen-decomposition of every A (clampNegativeEigenValues), two matrices per wavefront, the
+//                                          rows through LDS once per three rounds (k_jacobi27_batch: once per round, kept for comparison)
+//   k_finish27w                   FINISH   clamp, inverses, Step 2, final estimates, aggregation -- the 27 x 27 algebra in registers on the
+//                                          matrix core (default search radius); items whose inverse needs the spectral branch go to a redo list
+//   k_bayes27w<2> / k_bayes27<2>  FINISH   the same through LDS matrices: the redo list / the other search radii
 // The `w` kernels serve the default search radius b = 6: the 15 x 15 pixel window around p is staged in LDS once and every member
 // access is an LDS read; other radii take the gather kernels (members fetched from global memory).
 //
@@ -19,7 +22,8 @@
 //   * inverseSymmetricMatrix (:578-604) = V diag(1/max(minEig, lambda)) V^T equals the plain inverse
 //     whenever lambda_min >= minEig.  The inverse is computed with the symmetric sweep operator and
 //     accepted only if every pivot is positive and ||M^-1||_F * minEig <= 1 (which proves
-//     lambda_min(M) >= minEig); otherwise the spectral form is evaluated with a compact Jacobi solver.
+//     lambda_min(M) >= minEig); otherwise the spectral form is evaluated with a compact Jacobi solver;
+//   * sums into LDS windows are plain read-add-write, never ds_add_f32 (193 cycles per wavefront instruction on gfx950).
 #include "bcd_common.h"
 #include <cstdio>
 #include <algorithm>
@@ -386,31 +390,30 @@ template <int X> __device__ inline void rowrot_quad(float (&x)[28], float ms)
     if (X == 1) rowrot_x1(x, ms); else if (X == 2) rowrot_x2(x, ms); else rowrot_x3(x, ms);
 }
 
-// one round of a super-round in the quad's 4 x 4 block: my coefficient of the rotation of (me, me ^ X), the block row and scale updated
+// one round of a super-round in the quad's 4 x 4 block: my coefficient of the rotation of (me, me ^ X), the block row and scale updated.
+// Written from the lane's own point of view, the two lanes of a pair run the SAME instructions on mirrored operands: with
+// delta = a_partner - a_me (true values), theta = delta / (2 a_pq), t = sign(theta) / (|theta| + sqrt(theta^2 + 1)), the lower lane's theta is
+// the pair's and the upper lane's its exact negative, so that  mine = -t (d_partner / d_me)  is -beta in the lower lane (x' = x - beta y) and
+// +alpha in the upper one (y' = y + alpha x), and d' = c d in both: no lower / upper selects.  (Both lanes must see the same off-diagonal
+// element: the lower lane's copy -- the two copies of a symmetric element agree only to rounding, and two slightly different angles cost
+// 1.7e-4 of orthogonality.)
 template <int X>
 __device__ inline float quad_round(float (&w)[4], float &dme, bool lo, bool frozen)
 {
-    const float pdiag = dpp_xor<X>(w[0]), pd = dpp_xor<X>(dme);
-    // (both lanes of the pair must compute the SAME rotation: the off-diagonal element is taken from the lower lane's row -- the two
-    // copies of a symmetric element agree only to rounding)
-    const float poff = dpp_xor<X>(w[X]);
-    const float app_s = lo ? w[0] : pdiag, aqq_s = lo ? pdiag : w[0], apq_s = lo ? w[X] : poff;
-    const float dp = lo ? dme : pd, dq = lo ? pd : dme;
-    float mbeta = 0.f, alpha = 0.f, c = 1.f;
+    const float pdiag = dpp_xor<X>(w[0]), pd = dpp_xor<X>(dme), poff = dpp_xor<X>(w[X]);
+    const float apq_s = lo ? w[X] : poff;
+    float mine = 0.f, c = 1.f;
     if (apq_s != 0.f && !frozen) {
-        const float apq = dp * dq * apq_s, app = dp * dp * app_s, aqq = dq * dq * aqq_s;
+        const float apq = (dme * pd) * apq_s, a_me = (dme * dme) * w[0], a_pt = (pd * pd) * pdiag;
         // 1-ulp hardware reciprocal / sqrt / rsqrt: a rotation only has to be orthogonal to working precision, not the exact minimiser
-        const float theta = (aqq - app) * __builtin_amdgcn_rcpf(2.f * apq);
+        const float theta = (a_pt - a_me) * __builtin_amdgcn_rcpf(2.f * apq);
         if (fabsf(theta) < 1e18f) { // (otherwise theta^2 overflows: the rotation is the identity to fp32)
             float t = __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.f)));
-            t = theta < 0.f ? -t : t;
+            t = (lo ? theta < 0.f : !(theta > 0.f)) ? -t : t;   // (theta == 0, equal diagonal elements: the upper lane still takes the opposite sign)
             c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
-            const float ratio = dq * __builtin_amdgcn_rcpf(dp);
-            mbeta = -t * ratio;
-            alpha = t * __builtin_amdgcn_rcpf(ratio);
+            mine = -t * (pd * __builtin_amdgcn_rcpf(dme));
         }
     }
-    const float mine = lo ? mbeta : alpha;   // slot p = the lower lane: x' = x - beta y; slot q: y' = y + alpha x
     dme *= c;
     // the block row: column rotations (the coefficient of column me ^ y is the one lane me ^ y holds), then the row rotation
     const float rc1 = dpp_xor<1>(mine), rc2 = dpp_xor<2>(mine), rc3 = dpp_xor<3>(mine);

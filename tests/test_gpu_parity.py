@@ -746,7 +746,7 @@ def test_fast_similarity_path_is_the_default_and_reports_its_borderline_pairs(hi
 def test_batched_eigensolver_against_lapack(hipctx):
     """bcd_hip_eig27_batch (the Jacobi solver of the Bayesian steps on its own, two matrices per wavefront): V diag(lambda) V^T
     reconstructs the input, V is orthogonal, the eigenvalues are LAPACK's -- for an odd number of matrices (half-empty last pair),
-    an already diagonal matrix and a rank-one matrix"""
+    an already diagonal matrix, a rank-one matrix and matrices with equal diagonal elements"""
     import torch
     rng = np.random.default_rng(4)
     n = 257
@@ -758,6 +758,9 @@ def test_batched_eigensolver_against_lapack(hipctx):
     A[3, :27, :27] = np.diag(np.linspace(-1, 2, 27)).astype(np.float32)
     v = rng.standard_normal(27).astype(np.float32)
     A[5, :27, :27] = np.outer(v, v)
+    # equal diagonal elements (theta = 0: 45-degree rotations, where the two lanes of a pair must still agree on the sign) and exact ties
+    A[7, :27, :27] = 0.25 * np.eye(27) + 0.01 * np.ones((27, 27))
+    A[9, :27, :27] = np.kron(np.eye(9), np.array([[1.0, 0.5, 0.5], [0.5, 1.0, 0.5], [0.5, 0.5, 1.0]]))
     A = (A + A.transpose(0, 2, 1)) / 2
     eig, V, _ = hipctx.eig27_batch(torch.from_numpy(A).cuda())
     eig, V = eig.cpu().numpy().astype(np.float64), V.cpu().numpy().astype(np.float64)
