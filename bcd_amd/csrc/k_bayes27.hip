@@ -1198,14 +1198,15 @@ __device__ __attribute__((noinline)) int win_stage_phase1(float *cwin, float *nw
                                                           int W, int H, int words, int lane)
 {
     LDS_POINTER(cwin); LDS_POINTER(nwin); LDS_POINTER(mem);
-    float wv[WIN_SLICE];
+    // all 33 loads of the lane are in flight at once (one exposed round trip to memory per item instead of three)
+    float wv[WIN_SLICE], wn0[WIN_SLICE], wn1[WIN_SLICE];
     win_issue<3>(wv, colors, 0, pr, pc, W, H, lane);
+    win_issue<6>(wn0, pixcov, 0, pr, pc, W, H, lane);
+    win_issue<6>(wn1, pixcov, WIN_SLICE, pr, pc, W, H, lane);
     const int n = decode_members_win(mask, p, words, mem, lane);
     win_commit<3>(cwin, wv, 0, lane);
-    win_issue<6>(wv, pixcov, 0, pr, pc, W, H, lane);
-    win_commit<6>(nwin, wv, 0, lane);
-    win_issue<6>(wv, pixcov, WIN_SLICE, pr, pc, W, H, lane);
-    win_commit<6>(nwin, wv, WIN_SLICE, lane);
+    win_commit<6>(nwin, wn0, 0, lane);
+    win_commit<6>(nwin, wn1, WIN_SLICE, lane);
     __syncthreads();
     return n;
 }
