@@ -96,6 +96,7 @@ struct Work {
     hipEvent_t ev_built = nullptr; // this scale's pyramid level is complete
     hipStream_t aux = nullptr;     // side stream: the fallback-pixel kernel runs beside the (latency-bound) full estimate kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_pixcov = nullptr; // the per-pixel covariances (side stream, beside the distance kernel) are complete
     // approximate distance planes computed ahead of similarity() by a caller that streams the frame in (bcd_hip_denoise_host_ex): valid for
     // exactly this problem; similarity() consumes the note
     struct { bool ready = false; const float *hist = nullptr, *ns = nullptr; int W = 0, H = 0, D = 0, b = 0; float tau = 0.f, uni_n = 0.f; } planes;
@@ -540,7 +541,14 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     // the fast division back), and one at the end for the counters.  The estimate kernels take their list lengths from device
     // memory, the finalisation is enqueued before the last synchronisation.
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[0], wk.stream));
-    HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, wk.stream));
+    // The per-pixel covariances (only the estimate stage reads them) and the clearing of the accumulators go to the side stream: the scale's
+    // own stream starts with the distance kernel, they run beside it instead of ahead of it / between marking and estimate
+    HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream)); // (the inputs are ready at this point of the scale's stream)
+    HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
+    HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, wk.aux));
+    HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.aux));
+    HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), wk.aux));
+    HIPCHK(ctx, hipEventRecord(wk.ev_pixcov, wk.aux));
     for (int attempt = 0, mode = 2; attempt < 3; ++attempt) { // production kernels; if they complain: general formula, then exact kernels
         RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, mode));
         if (prof && attempt == 0) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
@@ -554,8 +562,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     }
     progress_add(ctx, 0.5 * (double)npix); // similar patches selected, processed set known
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
-    HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.stream));
-    HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), wk.stream));
+    HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_pixcov, 0)); // covariances computed, accumulators cleared (long done)
     RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p,
                 (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count));
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[3], wk.stream));
@@ -626,6 +633,7 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
     HIPCHK(ctx, hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_pixcov, hipEventDisableTiming));
     w.initialised = true;
     return BCD_HIP_OK;
 }
@@ -641,6 +649,7 @@ void work_destroy(Work &w)
     if (w.ev_built) (void)hipEventDestroy(w.ev_built);
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
     if (w.ev_join) (void)hipEventDestroy(w.ev_join);
+    if (w.ev_pixcov) (void)hipEventDestroy(w.ev_pixcov);
     if (w.aux) (void)hipStreamDestroy(w.aux);
     if (w.owns_stream && w.stream) (void)hipStreamDestroy(w.stream);
 }

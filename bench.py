@@ -368,6 +368,19 @@ def main():
         except Exception:
             pass
 
+    # what actually bounds the kernel: the vector pipe, from the committed SQ counter table of the same kernel (rocprofv3 --pmc; offline)
+    try:
+        import glob
+        import re
+        tabs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.txt")))
+        txt = open(tabs[-1]).read()
+        m = re.search(r"k_pairdist_rw.*?VALU pipe busy ([0-9.]+) %", txt, re.S)
+        if m:
+            roofline["vector_pipe_busy_profiled"] = {"frac": round(float(m.group(1)) / 100.0, 3), "source": "profiles/" + os.path.basename(tabs[-1]) +
+                                                     " (SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES) per shader engine, 1280x720 scale 0 alone)"}
+    except Exception:
+        pass
+
     if rank == 0:
         res = {
             "metric": "Mpixels/sec denoised (3-scale, b=6, w=1)", "value": round(W * H / 1e6 / (ms_step * 1e-3), 3), "unit": "Mpix/s",
