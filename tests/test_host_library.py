@@ -80,3 +80,20 @@ def test_samples_accumulator_thread_safe_variant():
         assert np.allclose(x, y, rtol=2e-5, atol=1e-6)
     one = core.accumulate_threadsafe(samples, 9, 7, threads=1)
     assert all(same(x, y) for x, y in zip(a, one))                               # one thread: the very same sequence
+
+
+def test_jacobi_quad_schedule_matches_the_kernel_constants():
+    """tools/jacobi_schedule.py builds and CHECKS the resolvable 2-(28,4,1) design behind k_jacobi27_quads (every pair of slots in one quad per
+    sweep, every slot home after nine super-rounds, conflict-free LDS placement); the tables it prints must be the ones compiled into
+    bcd_amd/csrc/k_bayes27.hip"""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "jacobi_schedule.py")], capture_output=True, text=True, check=True).stdout
+    src = open(os.path.join(root, "bcd_amd", "csrc", "k_bayes27.hip")).read()
+    for name in ("JSX", "JSY", "JPLACE"):
+        want = re.search(r"constexpr int %s\[28\] = \{([^}]*)\}" % name, out).group(1).split(",")
+        got = re.search(r"constexpr int %s\[28\] = \{([^}]*)\}" % name, src).group(1).split(",")
+        assert [int(v) for v in want] == [int(v) for v in got], name
+    assert re.search(r"constexpr int JIDLE_ROW = (\d+);", out).group(1) == re.search(r"constexpr int JIDLE_ROW = (\d+);", src).group(1)
