@@ -774,6 +774,29 @@ def test_batched_eigensolver_against_lapack(hipctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["BCD_HIP_JACOBI_PAIRS", "BCD_HIP_FINISH_LDS"])
+def test_comparison_kernels_stay_correct(switch):
+    """the kernels kept for A/B comparisons behind environment switches (read once per process: run in a child) -- the round-per-LDS-trip
+    eigensolver and the finish kernel through LDS matrices -- still reproduce the oracle"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch, oracle_lib as ol, bcd_amd.core as core, bcd_amd.hip as bh\n"
+            "col, ns, hist, cov = core.synthetic_scene(72, 56, 32, 5, 0.08, 0.0)\n"
+            "ctx = bh.Context(0)\n"
+            "got = ctx.denoise(*[torch.from_numpy(a).cuda() for a in (col, ns, hist, cov)], 1, bh.default_params(m=0.0)).cpu().numpy()\n"
+            "want = ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0))\n"
+            "print('ERR %%.3e' %% (np.max(np.abs(got - want)) / np.max(np.abs(want))))\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                          os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env[switch] = "1"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    err = float([l for l in out.stdout.splitlines() if l.startswith("ERR")][-1].split()[1])
+    assert err < TOL, err
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("W,H,S,ranks,m,random_order,b", [(256, 288, 3, 2, 1.0, 1, 6), (256, 288, 3, 4, 1.0, 1, 6), (256, 288, 3, 4, 0.0, 0, 6),
                                                           (96, 80, 3, 2, 1.0, 0, 3), (70, 66, 2, 3, 0.5, 1, 6), (64, 48, 1, 1, 1.0, 1, 6)])
 def test_native_multi_rank_driver_equals_single_gpu(hipctx, W, H, S, ranks, m, random_order, b):
