@@ -601,6 +601,25 @@ def test_720p_three_scale_frame_against_the_oracle(hipctx):
 
 
 @pytest.mark.gpu
+def test_1080p_headline_frame_against_the_oracle(hipctx):
+    """BASELINE config[2] at its FULL size on the bench's own frame (1920 x 1080, 32 spp, sigma 0.35, spikes, 3 scales, b = 6, w = 1): -m 0
+    (order-free: every main pixel estimated, 1.6 M of them through the full Bayesian estimate -- the run the 1e-4 bar is defined on) against
+    the oracle on the host cores of the box (about half a minute on 128 threads)"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H = 1920, 1080
+    col, ns, hist, cov = core.synthetic_scene(W, H, 32, 1234, 0.35, 0.01)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), 3, bh.default_params(m=0.0)).cpu().numpy()
+    st = hipctx.stats(0)
+    assert st.processed == st.main_pixels and st.processed - st.fallback > 1000000 and st.spectral_inverses == 0
+    threads = min(128, _os.cpu_count() or 1)
+    want = ol.denoise_multiscale(col, ns, hist, cov, 3, ol.params(m=0.0, threads=threads))
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+
+
+@pytest.mark.gpu
 def test_quarter_hd_three_scale_marking_run_against_the_oracle(hipctx):
     """the bench workload (noisy frame, 3 scales, b = 6, -m 1 -r 1) at 480 x 270 against the oracle visiting the pixels in the SAME
     explicit order (one thread, ~15 s): marking decisions, fallback and full estimates, pyramid and merges in one comparison"""
