@@ -632,11 +632,16 @@ int bcdo_denoise_mono(const float *colors, const float *nsamp, const float *hist
     int Wm = W - 2 * w, Hm = H - 2 * w;
     int64_t nmain = (int64_t)Wm * Hm;
     int serial = (prm->skip_probability != 0.f) || order != NULL;
+    /* An ordered visit with nb_threads > 1 asked for explicitly: the SAME visit in three phases (below) -- what is decided one pixel
+     * after the other stays sequential, the similar sets and the estimates are computed on all threads.  For frames too large for the
+     * one-thread loop (the 1080p bench frame with its marking order). */
+    int phased = serial && prm->nb_threads > 1;
     int nthreads = 1;
 #ifdef _OPENMP
     if (!serial) {
         nthreads = prm->nb_threads > 0 ? prm->nb_threads : omp_get_max_threads();
     }
+    if (phased) nthreads = prm->nb_threads;
 #endif
     float **sums = (float **)malloc(sizeof(float *) * nthreads);
     int32_t **cnts = (int32_t **)malloc(sizeof(int32_t *) * nthreads);
@@ -644,7 +649,53 @@ int bcdo_denoise_mono(const float *colors, const float *nsamp, const float *hist
         sums[t] = (float *)calloc(npix * 3, sizeof(float));
         cnts[t] = (int32_t *)calloc(npix, sizeof(int32_t));
     }
-    if (serial) {
+    if (phased) {
+        /* phase 1 (parallel): S(p) of every main pixel, as bit masks -- selectSimilarPatches (:196-219) does not depend on the visit */
+        int b = prm->search_radius, side = 2 * b + 1, words = (side * side + 31) / 32, K = 3 * (2 * w + 1) * (2 * w + 1);
+        uint32_t *mask = (uint32_t *)malloc(sizeof(uint32_t) * npix * words);
+        int32_t *count = (int32_t *)malloc(sizeof(int32_t) * npix);
+        bcdo_similarity_masks(hist, nsamp, W, H, D, w, b, prm->hist_dist_threshold, mask, count, nthreads);
+        /* phase 2 (sequential): the visit of denoisePatchAndSimilarPatches (:157-194) reduced to its decisions -- a pixel is processed unless
+         * it was marked (and the skip draw says so); a pixel processed through the full estimate (|S| >= 3P + 1) marks its similar set (:690),
+         * one processed through denoiseOnlyMainPatch marks nobody */
+        int64_t n = order ? n_order : nmain, nt = 0;
+        int32_t *todo = (int32_t *)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+        for (int64_t i = 0; i < n; ++i) {
+            int pl, pc;
+            if (order) { pl = order[i] / W; pc = order[i] % W; }
+            else { pl = w + (int)(i / Wm); pc = w + (int)(i % Wm); }
+            size_t pi = (size_t)pl * W + pc;
+            if (prm->skip_probability != 0.f && marked[pi])
+                if (prm->skip_probability == 1.f || unit_hash((uint32_t)pi, prm->skip_seed) < prm->skip_probability) continue;
+            todo[nt++] = (int32_t)pi;
+            if (count[pi] >= K + 1) {
+                const uint32_t *m = mask + pi * words;
+                for (int k = 0; k < side * side; ++k)
+                    if (m[k >> 5] >> (k & 31) & 1u) marked[(size_t)(pl + k / side - b) * W + (pc + k % side - b)] = 1;
+            }
+        }
+        free(mask); free(count);
+        /* phase 3 (parallel): the processed pixels' estimates with the per-pixel code of the serial visit (marks no longer matter: skip
+         * probability 0), per-thread accumulators like Denoiser.cpp:149-159 */
+#pragma omp parallel num_threads(nthreads)
+        {
+            int t = 0;
+#ifdef _OPENMP
+            t = omp_get_thread_num();
+#endif
+            Unit u;
+            unit_init(&u, W, H, D, prm, colors, nsamp, hist, pixcov, sums[t], cnts[t], marked);
+#pragma omp for schedule(dynamic, 16)
+            for (int64_t i = 0; i < nt; ++i)
+                denoise_patch_and_similar(&u, todo[i] / W, todo[i] % W, 0.f, diag);
+            unit_free(&u);
+        }
+        free(todo);
+        for (int t = 1; t < nthreads; ++t) {
+            for (size_t k = 0; k < npix * 3; ++k) sums[0][k] += sums[t][k];
+            for (size_t k = 0; k < npix; ++k) cnts[0][k] += cnts[t][k];
+        }
+    } else if (serial) {
         Unit u;
         g_skip_seed = prm->skip_seed;
         unit_init(&u, W, H, D, prm, colors, nsamp, hist, pixcov, sums[0], cnts[0], marked);

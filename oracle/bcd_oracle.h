@@ -73,7 +73,11 @@ void bcdo_sym_eig(int n, const float *A, float *evals, float *evecs /* column j 
 
 /* ---- a9..a16: monoscale denoiser (src/core/Denoiser.cpp:84-212, DenoisingUnit.cpp:157-693)
  * order: visiting order of main pixels as linear indices line*W+col (NULL = scanline,
- * the reference's 1-thread -r 0 order, Denoiser.cpp:136-146).  Returns 0 on success. ---- */
+ * the reference's 1-thread -r 0 order, Denoiser.cpp:136-146).  Returns 0 on success.
+ * An ordered / marking visit is a one-thread loop; with prm->nb_threads > 1 the SAME visit runs in three phases -- the similar sets of
+ * all pixels in parallel (selectSimilarPatches does not depend on the visit), the decisions of denoisePatchAndSimilarPatches one pixel
+ * after the other (processed unless marked; a full estimate marks its similar set), the processed pixels' estimates in parallel with the
+ * loop's per-pixel code -- equal to the loop up to the summation order of the per-thread accumulators (full-size frames). ---- */
 int bcdo_denoise_mono(const float *colors, const float *nsamp, const float *hist, const float *cov,
                       int W, int H, int D, const BcdoParams *prm,
                       const int32_t *order, int64_t n_order,

@@ -620,6 +620,26 @@ def test_1080p_headline_frame_against_the_oracle(hipctx):
 
 
 @pytest.mark.gpu
+def test_1080p_bench_workload_against_the_oracle(hipctx):
+    """the bench's headline workload ITSELF -- 1920 x 1080, 3 scales, b = 6, -m 1 -r 1 with the bench's seed, on the bench's frame -- against the oracle
+    visiting the pixels in the same explicit orders (its three-phase ordered visit on the host cores of the box: the decisions of the visit stay
+    sequential): marking decisions, fallback and full estimates, pyramid and merges of the measured configuration in one comparison"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H, S = 1920, 1080, 3
+    col, ns, hist, cov = core.synthetic_scene(W, H, 32, 1234, 0.35, 0.01)
+    prm = bh.default_params(m=1.0, random_order=1, seed=1234)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), S, prm).cpu().numpy()
+    st = hipctx.stats(0)
+    assert (st.processed, st.fallback, st.similar_total) == (513339, 481684, 7370779)   # (what bench.py prints for this frame)
+    threads = min(128, _os.cpu_count() or 1)
+    want = ol.denoise_multiscale(col, ns, hist, cov, S, ol.params(m=1.0, skip_seed=1234, threads=threads), orders=_orders(W, H, 1, 1, 1234, S))
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+
+
+@pytest.mark.gpu
 def test_quarter_hd_three_scale_marking_run_against_the_oracle(hipctx):
     """the bench workload (noisy frame, 3 scales, b = 6, -m 1 -r 1) at 480 x 270 against the oracle visiting the pixels in the SAME
     explicit order (one thread, ~15 s): marking decisions, fallback and full estimates, pyramid and merges in one comparison"""

@@ -280,3 +280,24 @@ def test_one_patch_trace_fixture_and_stagewise_float64_cross_check():
     # contributions here: the final image test above covers the sum)
     l, c = [int(v) for v in t["pts"][0]]
     assert np.allclose(t["p0_step2"][list(t["p0_members"]).index(l * W + c)][12:15], f["out_m0"][l, c], atol=0.2)
+
+
+def test_phased_ordered_visit_equals_the_serial_one():
+    """bcdo_denoise_mono with an order / a skip probability and nb_threads > 1 runs the same visit in three phases (similar sets in parallel, the
+    decisions of the visit sequentially, the estimates in parallel): same processed set, same marks, results equal to the one-thread loop up to the
+    summation order of the per-thread accumulators -- this is what lets the GPU tests compare the 1080p bench frame with its marking order"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H, S = 96, 72, 2
+    col, ns, hist, cov = core.synthetic_scene(W, H, 32, 1234, 0.35, 0.01)
+    orders, w_, h_ = [], W, H
+    for s_ in range(S):
+        orders.append(bh.visit_order(w_, h_, 1, 1, bh.scale_seed(5, s_)))
+        w_, h_ = w_ // 2, h_ // 2
+    for m in (1.0, 0.5):
+        serial = ol.denoise_multiscale(col, ns, hist, cov, S, ol.params(m=m, skip_seed=7), orders=orders)
+        phased = ol.denoise_multiscale(col, ns, hist, cov, S, ol.params(m=m, skip_seed=7, threads=4), orders=orders)
+        assert np.max(np.abs(serial - phased)) / np.max(np.abs(serial)) < 5e-6
+    serial = ol.denoise_mono(col, ns, hist, cov, ol.params(m=1.0))          # scanline order
+    phased = ol.denoise_mono(col, ns, hist, cov, ol.params(m=1.0, threads=4))
+    assert np.max(np.abs(serial - phased)) / np.max(np.abs(serial)) < 5e-6
