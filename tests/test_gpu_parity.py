@@ -640,6 +640,25 @@ def test_1080p_bench_workload_against_the_oracle(hipctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not _os.environ.get("BCD_TEST_SLOW"), reason="two minutes of oracle time on 128 host threads: run with BCD_TEST_SLOW=1")
+def test_4k_config3_frame_against_the_oracle(hipctx):
+    """BASELINE configs[3]'s frame at its FULL size (3840 x 2160, 3 scales, b = 6, -m 1 -r 1) on one GPU against the oracle's ordered visit on the
+    host cores (opt-in: the oracle needs about two minutes); the 8-row-band form of the same frame is compared with this single-GPU result by
+    test_4k_config3_properties_and_eight_row_bands"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H, S = 3840, 2160, 3
+    col, ns, hist, cov = core.synthetic_scene(W, H, 8, 3, 0.15, 0.0)
+    prm = bh.default_params(seed=17)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), S, prm).cpu().numpy()
+    threads = min(128, _os.cpu_count() or 1)
+    want = ol.denoise_multiscale(col, ns, hist, cov, S, ol.params(m=1.0, skip_seed=17, threads=threads), orders=_orders(W, H, 1, 1, 17, S))
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+
+
+@pytest.mark.gpu
 def test_quarter_hd_three_scale_marking_run_against_the_oracle(hipctx):
     """the bench workload (noisy frame, 3 scales, b = 6, -m 1 -r 1) at 480 x 270 against the oracle visiting the pixels in the SAME
     explicit order (one thread, ~15 s): marking decisions, fallback and full estimates, pyramid and merges in one comparison"""
