@@ -659,6 +659,25 @@ def test_4k_config3_frame_against_the_oracle(hipctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not _os.environ.get("BCD_TEST_SLOW"), reason="several minutes of oracle time on 128 host threads: run with BCD_TEST_SLOW=1")
+def test_4k_config4_frame_against_the_oracle(hipctx):
+    """BASELINE configs[4]'s chain at its FULL size (3840 x 2160, b = 12, -p 1 --p-factor 2, -r 1 -m 1, 3 scales) on one GPU against the oracle
+    (its spike filter -- pinned to the reference's compiled unit -- then its ordered visit on the host cores; opt-in)"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H, S, b = 3840, 2160, 3, 12
+    col, ns, hist, cov = core.synthetic_scene(W, H, 8, 3, 0.25, 0.01)
+    prm = bh.default_params(seed=23, b=b, random_order=1)
+    got = hipctx.denoise_host(col, ns, hist, cov, S, prm, spike_factor=2.0)
+    fc, fn, fh, fv = ol.oracle_ops()["spike"](col, ns, hist, cov, 2.0)
+    threads = min(128, _os.cpu_count() or 1)
+    want = ol.denoise_multiscale(fc, fn, fh, fv, S, ol.params(b=b, m=1.0, skip_seed=23, threads=threads), orders=_orders(W, H, 1, 1, 23, S))
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+
+
+@pytest.mark.gpu
 def test_quarter_hd_three_scale_marking_run_against_the_oracle(hipctx):
     """the bench workload (noisy frame, 3 scales, b = 6, -m 1 -r 1) at 480 x 270 against the oracle visiting the pixels in the SAME
     explicit order (one thread, ~15 s): marking decisions, fallback and full estimates, pyramid and merges in one comparison"""
