@@ -223,6 +223,9 @@ int check_params(bcd_hip_ctx *ctx, int W, int H, int D, const bcd_hip_params *pr
         return BCD_HIP_EUNSUPPORTED;
     }
     if ((int64_t)W * H >= (1ll << 31) / (D > 6 ? D : 6)) return bad(ctx, "image too large for 32-bit DeepImage indices");
+    if (prm->use_random_pixel_order < 0 || prm->use_random_pixel_order > 2) return bad(ctx, "pixel order must be 0 (scanline), 1 (seeded random) or 2 (strips)");
+    if (prm->use_random_pixel_order == 2 && (W > 8191 || H > 8191 || prm->patch_radius > 3 || prm->search_radius < 1))
+        return bad(ctx, "the strip order supports frames up to 8191 x 8191, patch radius <= 3, search radius >= 1");
     return BCD_HIP_OK;
 }
 
@@ -382,7 +385,7 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
         const int side = 2 * b + 1, words = (side * side + 31) / 32;
         const int iters = 8; // in-tile iterations per launch
         int i = 0;
-        batch = random_order ? 3 : ROUND_BATCH;
+        batch = random_order == 1 ? 3 : ROUND_BATCH;
         if (wk.dep_ready && (wk.dep_mask != (const void *)d_mask || wk.dep_state != (const void *)d_state)) wk.dep_ready = false;
         if (!wk.dep_ready) {
             RCCHK(ensure(ctx, wk.dep, (size_t)W * H * words * sizeof(uint32_t)));
@@ -393,7 +396,7 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
             wk.dep_state = d_state;
             // first batch: what the previous marking problem of this workspace needed, plus one (frames of a sequence and
             // the bands of a frame behave alike), so that the usual case costs a single host round trip
-            if (random_order) batch = std::min(ROUND_BATCH, std::max(5, wk.rounds_hint + 1));
+            if (random_order == 1) batch = std::min(ROUND_BATCH, std::max(5, wk.rounds_hint + 1));
         }
         for (; i < batch; ++i)
             HIPCHK(ctx, bcd_launch_mark_round((const uint32_t *)wk.dep.p, d_state, W, H, b, row_begin, row_end, iters, d_lines + LINE_INTS * i, wk.stream));
@@ -425,7 +428,9 @@ int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t
         int undecided = 1, before = INT_MAX;
         while (undecided != 0) {
             int n = 0;
-            RCCHK(active_step(ctx, wk, d_mask, d_nsim, W, H, w, b, row_begin, row_end, random_order, seed, 0, rounds == 0 && skip_prob >= 1.f,
+            // (strip order: the key needs the frame's geometry, which travels in the seed argument; the skip draws keep the caller's seed)
+            const uint32_t key_seed = random_order == 2 ? bcd_strip_order_seed(W, H, w, b) : seed;
+            RCCHK(active_step(ctx, wk, d_mask, d_nsim, W, H, w, b, row_begin, row_end, random_order, key_seed, 0, rounds == 0 && skip_prob >= 1.f,
                               d_state, &undecided, &n));
             rounds += n;
             if (undecided != 0 && undecided >= before) { set_err(ctx, "marking fixed point made no progress"); return BCD_HIP_EDEVICE; }
@@ -1422,6 +1427,8 @@ int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, 
 
 // ---- host utilities -------------------------------------------------------------------------------------
 uint32_t bcd_hip_scale_seed(uint32_t seed0, int scale) { return seed0 + (uint32_t)scale; }
+
+uint32_t bcd_hip_strip_order_seed(int W, int H, int patch_radius, int search_radius) { return bcd_strip_order_seed(W, H, patch_radius, search_radius); }
 
 int bcd_hip_visit_order(int W, int H, int w, int random_order, uint32_t seed, int32_t *h_order)
 {

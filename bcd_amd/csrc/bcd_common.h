@@ -7,18 +7,37 @@
 enum : uint8_t { BCD_ST_NONE = 0, BCD_ST_IN = 1, BCD_ST_OUT = 2, BCD_ST_UNDECIDED = 3 };
 
 // ---- visiting order ---------------------------------------------------------------------------------
-// The reference visits main pixels in scanline order (-r 0, 1 thread; src/core/Denoiser.cpp:136-146) or
-// in a wall-clock-seeded shuffle (-r 1; :416-420).  Here the order is the ascending order of a 64-bit
-// key: scanline -> key = linear index; random -> (hash32(index, seed) << 32) | index.  Any permutation
-// is an admissible outcome of the reference's shuffle; a seeded one is reproducible.
+// The reference visits main pixels in scanline order (-r 0, 1 thread; src/core/Denoiser.cpp:136-146), in a
+// wall-clock-seeded shuffle (-r 1; :416-420), or -- -r 0 with several threads -- strip by strip, the even strips of 2b
+// lines first and then the odd ones (reorderPixelSetJumpNextStrip, :381-414; a trailing partial strip stays last).
+// Here the order is the ascending order of a 64-bit key:
+//   mode 0 scanline -> key = linear index;   mode 1 random -> (hash32(index, seed) << 32) | index  (any permutation is an
+//   admissible outcome of the reference's shuffle; a seeded one is reproducible);   mode 2 strips -> (position in the
+//   reordered list << 32) | index, with the frame geometry packed into the `seed` argument (bcd_strip_order_seed).
 __host__ __device__ inline uint32_t bcd_mix32(uint32_t x)
 {
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
     return x;
 }
-__host__ __device__ inline uint64_t bcd_order_key(uint32_t idx, int random_order, uint32_t seed)
+// geometry of the strip order: width and number of main lines (13 bits each), patch radius (2 bits), search radius (4 bits)
+__host__ __device__ inline uint32_t bcd_strip_order_seed(int W, int H, int w, int b)
 {
-    uint32_t hi = random_order ? bcd_mix32(idx ^ bcd_mix32(seed + 0x9E3779B9u)) : 0u;
+    return (uint32_t)W | ((uint32_t)(H - 2 * w) << 13) | ((uint32_t)w << 26) | ((uint32_t)b << 28);
+}
+__host__ __device__ inline uint64_t bcd_order_key(uint32_t idx, int order_mode, uint32_t seed)
+{
+    if (order_mode == 2) {
+        const int W = (int)(seed & 8191u), Hm = (int)((seed >> 13) & 8191u), w = (int)((seed >> 26) & 3u), b = (int)(seed >> 28);
+        const int Wm = W - 2 * w, row = (int)(idx / (uint32_t)W) - w, col = (int)(idx % (uint32_t)W) - w;
+        uint32_t pos = idx; // (not a main pixel: never compared)
+        if (row >= 0 && row < Hm && col >= 0 && col < Wm && b > 0) {
+            const int lines = 2 * b, strip = row / lines, nfull = Hm / lines; // a chunk is Wm * 2b pixels = one strip of 2b lines
+            const int first = strip >= nfull ? strip : ((strip & 1) ? (nfull + 1) / 2 + strip / 2 : strip / 2); // even strips, then the odd ones
+            pos = (uint32_t)((first * lines + (row - strip * lines)) * Wm + col);
+        }
+        return ((uint64_t)pos << 32) | idx;
+    }
+    uint32_t hi = order_mode ? bcd_mix32(idx ^ bcd_mix32(seed + 0x9E3779B9u)) : 0u;
     return ((uint64_t)hi << 32) | idx;
 }
 // uniform in [0,1) per pixel, for skip probabilities strictly between 0 and 1

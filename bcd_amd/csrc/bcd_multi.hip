@@ -665,6 +665,7 @@ int make_job(bcd_hip_multi *m, Job &job, int W, int H, int D, int nb_scales, con
 {
     if (!prm) { fail(m, "null parameters"); return BCD_HIP_EINVAL; }
     if (W <= 0 || H <= 0 || D <= 0 || nb_scales < 1 || nb_scales > MAX_S) { fail(m, "bad image size or number of scales"); return BCD_HIP_EINVAL; }
+    if (prm->use_random_pixel_order == 2) { fail(m, "the strip visiting order (pixel order 2) is not available on row bands"); return BCD_HIP_EINVAL; }
     job.m = m; job.h_col = job.h_ns = job.h_hist = job.h_cov = nullptr; job.h_out = nullptr;
     job.W = W; job.H = H; job.D = D; job.S = nb_scales; job.prm = *prm;
     std::string err;

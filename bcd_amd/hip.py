@@ -47,7 +47,7 @@ SYMBOLS = [
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_similarity_masks_deferred", "bcd_hip_similarity_masks_verdict", "bcd_hip_similarity_masks_exact", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
-    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels", "bcd_hip_selftest_approx_distance", "bcd_hip_eig27_batch",
+    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_strip_order_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels", "bcd_hip_selftest_approx_distance", "bcd_hip_eig27_batch",
 ]
 
 _lib = None
@@ -63,6 +63,7 @@ def lib():
         _lib.bcd_hip_last_error.restype = C.c_char_p
         _lib.bcd_hip_last_error.argtypes = [_VP]
         _lib.bcd_hip_scale_seed.restype = C.c_uint32
+        _lib.bcd_hip_strip_order_seed.restype = C.c_uint32
         _lib.bcd_hip_ctx_create.argtypes = [C.POINTER(_VP), C.c_int, _VP]
         _lib.bcd_hip_ctx_destroy.argtypes = [_VP]
         _lib.bcd_hip_ctx_destroy.restype = None
@@ -471,3 +472,9 @@ def visit_order(W, H, w, random_order, seed):
 
 def scale_seed(seed0, scale):
     return int(lib().bcd_hip_scale_seed(C.c_uint32(seed0), int(scale)))
+
+
+def strip_order_seed(W, H, w, b):
+    """the `seed` argument of visit_order / the marking entry points for pixel order 2 (the reference's multi-thread -r 0 list: even
+    strips of 2b lines, then the odd ones): it carries the frame geometry"""
+    return int(lib().bcd_hip_strip_order_seed(int(W), int(H), int(w), int(b)))

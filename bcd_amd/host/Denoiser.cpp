@@ -131,6 +131,7 @@ namespace bcd
 		}
 		// Denoiser.cpp:121 writes the actual OpenMP thread count back.  The loop runs on the device; what the host contributes is one
 		// driver thread per scale and device
+		const int requestedNbOfCores = m_parameters.m_nbOfCores;
 		m_parameters.m_nbOfCores = i_nbOfScales * int(m_devices.size());
 
 		bcd_hip_params prm;
@@ -139,7 +140,9 @@ namespace bcd
 		prm.patch_radius = m_parameters.m_patchRadius;
 		prm.search_radius = m_parameters.m_searchWindowRadius;
 		prm.min_eigen_value = m_parameters.m_minEigenValue;
-		prm.use_random_pixel_order = m_parameters.m_useRandomPixelOrder ? 1 : 0;
+		// Denoiser.cpp:375-380: a shuffle (-r 1), else -- several cores asked for -- the strip list (reorderPixelSetJumpNextStrip), else scanline.
+		// The marking follows that list exactly (the reference's threads race through it); row bands over several devices keep the scanline order
+		prm.use_random_pixel_order = m_parameters.m_useRandomPixelOrder ? 1 : ((requestedNbOfCores > 1 && m_devices.size() == 1) ? 2 : 0);
 		prm.marked_skip_probability = m_parameters.m_markedPixelsSkippingProbability;
 		prm.order_seed = m_orderSeed;
 

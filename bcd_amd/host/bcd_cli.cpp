@@ -2,7 +2,7 @@
 // (src/cli/main.cpp:122-504 of the reference): -o -i -h -c -d -b -w -r -p --p-factor -m -s --ncores --use-cuda -e.
 // Real defaults are -r 1 and -p 1 (main.cpp:52-53) although the reference's README says 0.  Missing -h / -c are
 // inferred as <input>_hist.exr / <input>_cov.exr (:344-370).  Extra flags of this build: --seed <n> (visiting
-// order), --device <n>.  --ncores is accepted and ignored (the loop runs on the HIP device); --use-cuda 0 (a request for the CPU path this
+// order), --device <n>.  --ncores only selects the visiting order (n > 1 with -r 0: the reference's strip list; the loop runs on the HIP device); --use-cuda 0 (a request for the CPU path this
 // build does not have) is refused with an error, never answered by silently running something else.
 // -a <file.bcd.json> (advertised but never parsed by the reference, main.cpp:107) loads a preset; later flags override it.
 #include "Chronometer.h"
@@ -70,7 +70,7 @@ namespace
 		cout << "    --p-factor <float>   Standard deviation factor of the spike threshold (default: " << d.m_prefilterThresholdStDevFactor << ")" << endl;
 		cout << "    -m <float in [0,1]>  Probability of skipping marked centers of denoised patches (default: " << d.m_markedPixelsSkippingProbability << ")" << endl;
 		cout << "    -s <int>             Number of Scales for Multi-Scaling (default: " << d.m_nbOfScales << ")" << endl;
-		cout << "    --ncores <n>         accepted for compatibility, ignored" << endl;
+		cout << "    --ncores <n>         the loop runs on the HIP device; n > 1 with -r 0 selects the reference's strip visiting order" << endl;
 		cout << "    --use-cuda <0/1>     1 (default): run on the HIP device; 0 asks for the CPU path, which this build does not have: the run is refused" << endl;
 		cout << "    -e <float>           Minimum eigen value for matrix inversion (default: " << d.m_minEigenValue << ")" << endl;
 		cout << "    --seed <int>         Seed of the random pixel order (default: " << d.m_orderSeed << ")" << endl;

@@ -48,7 +48,8 @@ typedef struct bcd_hip_params {
     int32_t  patch_radius;            /* m_patchRadius                         default 1     */
     int32_t  search_radius;           /* m_searchWindowRadius                  default 6     */
     float    min_eigen_value;         /* m_minEigenValue                       default 1e-8  */
-    int32_t  use_random_pixel_order;  /* m_useRandomPixelOrder                 default 1     */
+    int32_t  use_random_pixel_order;  /* m_useRandomPixelOrder                 default 1     (0 scanline, 1 seeded shuffle, 2 the reference's
+                                         multi-thread -r 0 list: even strips of 2b lines, then the odd ones, Denoiser.cpp:381-414; single GPU only) */
     float    marked_skip_probability; /* m_markedPixelsSkippingProbability     default 1     */
     uint32_t order_seed;              /* seed of the visiting order; the reference seeds its
                                          shuffle from the wall clock (Denoiser.cpp:418)      */
@@ -294,6 +295,8 @@ int bcd_hip_eig27_batch(bcd_hip_ctx *ctx, const float *d_A, int n, float *d_eig,
  * visiting order, written to h_order[(W-2w)*(H-2w)].  random_order == 0 is the reference's
  * single-thread scanline order (Denoiser.cpp:136-146). */
 int bcd_hip_visit_order(int W, int H, int patch_radius, int random_order, uint32_t seed, int32_t *h_order);
+/* order 2 (strips): the `seed` argument of bcd_hip_visit_order / bcd_hip_active_set carries the frame geometry instead of a seed */
+uint32_t bcd_hip_strip_order_seed(int W, int H, int patch_radius, int search_radius);
 /* seed used for scale s of a multiscale run started with seed0 */
 uint32_t bcd_hip_scale_seed(uint32_t seed0, int scale);
 

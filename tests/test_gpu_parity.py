@@ -117,6 +117,31 @@ def test_mono_parity(hipctx, m, random_order, sigma, spp):
     assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
 
 
+@pytest.mark.parametrize("W,H,S", [(72, 66, 1), (90, 131, 2)])
+def test_strip_visiting_order_against_the_oracle(hipctx, W, H, S):
+    """pixel order 2 = the list the reference builds for -r 0 with several threads (reorderPixelSetJumpNextStrip, Denoiser.cpp:381-414: the
+    even strips of 2b lines, then the odd ones): the marking fixed point follows it, per scale with that scale's geometry"""
+    import bcd_amd.hip as bh
+    col, ns, hist, cov, _ = inputs(W, H, 16, 0.15)
+    prm = bh.default_params(m=1.0, random_order=2, seed=5)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), S, prm).cpu().numpy()
+    orders, w_, h_ = [], W, H
+    for _s in range(S):
+        orders.append(bh.visit_order(w_, h_, 1, 2, bh.strip_order_seed(w_, h_, 1, 6)))
+        w_, h_ = w_ // 2, h_ // 2
+    assert not np.array_equal(orders[0], bh.visit_order(W, H, 1, 0, 0))      # (not the scanline order)
+    want = ol.denoise_multiscale(col, ns, hist, cov, S, ol.params(m=1.0), orders=orders) if S > 1 else ol.denoise_mono(col, ns, hist, cov, ol.params(m=1.0), order=orders[0])
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+    md = bh.MultiDenoiser([0, 0])
+    try:
+        with pytest.raises(bh.BcdHipError, match="strip"):                    # (row bands: refused, not silently reordered)
+            md.denoise_host(col, ns, hist, cov, S, prm)
+    finally:
+        md.close()
+
+
 @pytest.mark.parametrize("m,random_order,W,H", [(1.0, 1, 96, 64), (0.0, 0, 61, 45), (1.0, 0, 97, 65)])
 def test_multiscale_parity(hipctx, m, random_order, W, H):
     import bcd_amd.hip as bh
@@ -1158,6 +1183,16 @@ def test_bcd_cli_baseline_config0_plumbing(hipctx, tmp_path):
     want = ol.denoise_mono(col_h, ns, hist, cov, ol.params(b=6, m=1.0, threads=1))   # 1 thread, -r 0: plain scanline order
     want = np.where(np.isfinite(want) & (want >= 0), want, 0.0).astype(np.float32)
     assert np.max(np.abs(got - want.astype(np.float16).astype(np.float32))) <= 2e-3 * np.max(want)
+    # --ncores 4 -r 0: the reference reorders the pixel list strip-wise (Denoiser.cpp:375-414); so does the engine, and the marking follows it
+    import bcd_amd.hip as bh
+    r = subprocess.run(flags[:-1] + ["4", "--use-cuda", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got4 = core.read_exr(out_path, False)
+    strips = bh.visit_order(W, H, 1, 2, bh.strip_order_seed(W, H, 1, 6))
+    want4 = ol.denoise_mono(col_h, ns, hist, cov, ol.params(b=6, m=1.0, threads=1), order=strips)
+    want4 = np.where(np.isfinite(want4) & (want4 >= 0), want4, 0.0).astype(np.float32)
+    assert np.max(np.abs(got4 - want4.astype(np.float16).astype(np.float32))) <= 2e-3 * np.max(want4)
+    assert np.max(np.abs(want4 - want)) > 1e-3 * np.max(want)             # (the two orders do give different images)
 
 
 # ---- BASELINE configs[3] and configs[4]: against the ORACLE at reduced size, by properties at full size ------------------------------

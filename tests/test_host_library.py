@@ -97,3 +97,25 @@ def test_jacobi_quad_schedule_matches_the_kernel_constants():
         got = re.search(r"constexpr int %s\[28\] = \{([^}]*)\}" % name, src).group(1).split(",")
         assert [int(v) for v in want] == [int(v) for v in got], name
     assert re.search(r"constexpr int JIDLE_ROW = (\d+);", out).group(1) == re.search(r"constexpr int JIDLE_ROW = (\d+);", src).group(1)
+
+
+def test_strip_visiting_order_is_the_reference_list():
+    """bcd_hip_visit_order mode 2 against a restatement of reorderPixelSetJumpNextChunk (src/core/Denoiser.cpp:393-414): chunks of
+    (W - 2w) * 2b pixels, the even ones first, then the odd ones; what is left of a partial chunk stays where it was"""
+    import bcd_amd.hip as bh
+
+    def reference_list(W, H, w, b):
+        Wm, Hm = W - 2 * w, H - 2 * w
+        lst = [(w + i // Wm) * W + w + i % Wm for i in range(Wm * Hm)]
+        chunk, out, o = Wm * 2 * b, None, 0
+        nfull = len(lst) // chunk
+        out = list(lst)
+        for start in range(2):
+            for ch in range(start, nfull, 2):
+                out[o:o + chunk] = lst[ch * chunk:(ch + 1) * chunk]
+                o += chunk
+        return np.array(out, np.int32)
+
+    for W, H, w, b in [(40, 61, 1, 6), (33, 50, 1, 3), (64, 24, 1, 6), (30, 100, 2, 4), (20, 13, 1, 6), (25, 26, 1, 12)]:
+        got = bh.visit_order(W, H, w, 2, bh.strip_order_seed(W, H, w, b))
+        assert np.array_equal(got, reference_list(W, H, w, b)), (W, H, w, b)
