@@ -65,6 +65,15 @@ def denoise(col, ns, hist, cov, nscales=1, tau=1.0, w=1, b=6, min_eig=1e-8, rand
     return rc != 0, out, rc == 1
 
 
+def denoise_reuse(col, ns, hist, cov, nscales=3, b=6, nb_of_cores=0):
+    """one IDenoiser object, denoise() twice with -r 0: (ok, first output, second output, (m_nbOfCores after call 1, after call 2))"""
+    H, W, D = hist.shape
+    o1, o2 = np.zeros((H, W, 3), np.float32), np.zeros((H, W, 3), np.float32)
+    after = (C.c_int * 2)()
+    rc = lib().bcdcore_denoise_reuse(_fp(col), _fp(ns), _fp(hist), _fp(cov), W, H, D, nscales, b, nb_of_cores, _fp(o1), _fp(o2), after)
+    return rc != 0, o1, o2, (after[0], after[1])
+
+
 def last_nb_of_cores():
     """DenoiserParameters::m_nbOfCores after the last denoise() (the reference writes the actual thread count back)"""
     return lib().bcdcore_last_nb_of_cores()

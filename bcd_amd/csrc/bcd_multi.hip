@@ -37,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -56,7 +57,7 @@ struct ScaleBand {
 struct Geometry {
     int W, H, S, b, w, world, halo, align;
     std::vector<int> bounds;
-    bool init(int W_, int H_, int S_, int b_, int w_, int world_, std::string &err)
+    bool init(int W_, int H_, int S_, int b_, int w_, int world_, std::string &err, bool loopback_ = false)
     {
         W = W_; H = H_; S = S_; b = b_; w = w_; world = world_;
         halo = b + w;
@@ -69,7 +70,7 @@ struct Geometry {
         for (int r = 0; r < world; ++r) {
             int o0, o1;
             owned(r, S - 1, o0, o1);
-            if (world > 1 && o1 - o0 < std::max(halo, 2)) { err = "a band owns fewer lines than the halo at the coarsest scale: use fewer devices"; return false; }
+            if ((world > 1 || loopback_) && o1 - o0 < std::max(halo, 2)) { err = "a band owns fewer lines than the halo at the coarsest scale: use fewer devices"; return false; }
         }
         return true;
     }
@@ -206,7 +207,15 @@ struct bcd_hip_multi {
     // thread per frame turns "no progress for frame_timeout_s" into such a failure, which is what ends a frame whose PEER (another
     // process or device) has died.
     std::mutex comm_mutex;
+    // rank threads hold comm_rw shared while they ENQUEUE on a communicator (group start .. group end, the all-reduce call); an abort takes it
+    // exclusively, so ncclCommAbort -- which frees the communicator -- never runs while a thread is inside an RCCL call on it
+    std::shared_mutex comm_rw;
     bool comm_aborted = false;
+    // loopback (bcd_hip_multi_set_loopback; one rank, tests on a one-GPU box): the rank is its own neighbour on both sides -- every exchange and
+    // all-reduce of a frame is enqueued on real RCCL communicators (ncclCommInitRank with n = 1, grouped self send / recv), in the order and with
+    // the sizes a band inside a larger world would use; what is received goes to scratch, so the frame is still the single-GPU frame
+    bool loopback = false;
+    DBuf loop_rx[MAX_S + 1][2];
     Watchdog *watchdog = nullptr;             // created with the first RCCL frame, joined by bcd_hip_multi_destroy
     int frame_timeout_ms = 600 * 1000;        // BCD_HIP_MULTI_TIMEOUT_S / bcd_hip_multi_set_frame_timeout
     // progress reporting (IDenoiser::setProgressCallback): every (rank, scale) adds its owned pixels twice, like bcd_hip_denoise
@@ -222,6 +231,7 @@ namespace {
 void abort_comms(bcd_hip_multi *m)
 {
     if (!m->use_rccl) return;
+    std::unique_lock<std::shared_mutex> excl(m->comm_rw); // no rank thread is inside an RCCL call on these communicators
     std::lock_guard<std::mutex> lk(m->comm_mutex);
     for (int c = 0; c <= MAX_S; ++c) {
         if (!m->comm_ready[c]) continue;
@@ -259,6 +269,7 @@ struct Watchdog {
     std::condition_variable cv;
     std::thread th;
     bool armed = false, quit = false;
+    bool firing = false;          // fail() of a timed-out frame is running: that frame's guard waits for it, so it can never hit the NEXT frame
     unsigned long long epoch = 0; // frames armed so far: a wait that times out only fires if its own frame is still the armed one
     void run(bcd_hip_multi *m)
     {
@@ -270,10 +281,15 @@ struct Watchdog {
             const bool released = cv.wait_for(lk, std::chrono::milliseconds(m->frame_timeout_ms), [this, mine]() { return quit || !armed || epoch != mine; });
             if (quit) return;
             if (!released) {
+                // (the predicate was evaluated under the lock: this frame is still the armed one.)  The frame's guard cannot disarm and
+                // return while `firing` is set, so the failure lands in the frame that timed out and nowhere else
                 armed = false;
+                firing = true;
                 lk.unlock();
                 fail(m, "frame timed out (a peer rank has stopped?): the frame is abandoned, RCCL communicators aborted");
                 lk.lock();
+                firing = false;
+                cv.notify_all();
             }
         }
     }
@@ -285,14 +301,18 @@ struct FrameWatchdog { // scope guard of one frame
     ~FrameWatchdog()
     {
         if (!w) return;
-        { std::lock_guard<std::mutex> lk(w->mu); w->armed = false; }
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->armed = false;
+            w->cv.wait(lk, [this]() { return !w->firing; });
+        }
         w->cv.notify_all();
     }
 };
 
 FrameWatchdog::FrameWatchdog(bcd_hip_multi *m)
 {
-    if (m->n < 2 || m->frame_timeout_ms <= 0) return; // (both transports: a rank that stops also stalls the in-process barriers)
+    if ((m->n < 2 && !m->loopback) || m->frame_timeout_ms <= 0) return; // (both transports: a rank that stops also stalls the in-process barriers)
     if (!m->watchdog) {
         m->watchdog = new Watchdog();
         Watchdog *wd = m->watchdog;
@@ -327,13 +347,25 @@ bool exchange(bcd_hip_multi *m, int rank, int ch, const void *send_up, void *rec
               size_t bytes_down)
 {
     hipStream_t st = m->stream[rank][ch];
-    const bool up = rank > 0, down = rank < m->n - 1;
+    const bool lb = m->loopback;
+    const bool up = rank > 0 || lb, down = rank < m->n - 1 || lb;
+    const int peer_up = lb ? rank : rank - 1, peer_down = lb ? rank : rank + 1;
     trace_op(m, rank, ch, 0, up ? bytes_up : 0, down ? bytes_down : 0);
+    if (lb) { // the rank is its own neighbour: what it "receives" is its own data and goes to scratch unless the caller (the self-test) wants it
+        if (!recv_up) { if (!m->loop_rx[ch][0].ensure(bytes_up)) { fail(m, "out of device memory"); return false; } recv_up = m->loop_rx[ch][0].p; }
+        if (!recv_down) { if (!m->loop_rx[ch][1].ensure(bytes_down)) { fail(m, "out of device memory"); return false; } recv_down = m->loop_rx[ch][1].p; }
+    }
     if (m->use_rccl) {
-        ncclResult_t r = ncclGroupStart();
-        if (r == ncclSuccess && up) { r = ncclSend(send_up, bytes_up, ncclChar, rank - 1, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(recv_up, bytes_up, ncclChar, rank - 1, m->comm[ch][rank], st); }
-        if (r == ncclSuccess && down) { r = ncclSend(send_down, bytes_down, ncclChar, rank + 1, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(recv_down, bytes_down, ncclChar, rank + 1, m->comm[ch][rank], st); }
-        const ncclResult_t e = ncclGroupEnd();
+        ncclResult_t r = ncclSuccess, e = ncclSuccess;
+        {
+            std::shared_lock<std::shared_mutex> enq(m->comm_rw); // (an abort waits for this section to end before it frees the communicator)
+            if (!m->comm_ready[ch] || m->abort_flag.load()) return false; // aborted meanwhile: fail() has recorded why
+            r = ncclGroupStart();
+            // operations to the same peer are matched in issue order: in loopback the first send pairs with the first receive
+            if (r == ncclSuccess && up) { r = ncclSend(send_up, bytes_up, ncclChar, peer_up, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(recv_up, bytes_up, ncclChar, peer_up, m->comm[ch][rank], st); }
+            if (r == ncclSuccess && down) { r = ncclSend(send_down, bytes_down, ncclChar, peer_down, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(recv_down, bytes_down, ncclChar, peer_down, m->comm[ch][rank], st); }
+            e = ncclGroupEnd();
+        }
         if (r != ncclSuccess || e != ncclSuccess) { fail(m, std::string("RCCL exchange failed: ") + ncclGetErrorString(r != ncclSuccess ? r : e)); return false; }
         return true;
     }
@@ -355,7 +387,12 @@ bool allreduce(bcd_hip_multi *m, int rank, int ch, long long *value)
     if (m->use_rccl) {
         hipStream_t st = m->stream[rank][ch];
         MCHK(m, rank, hipMemcpyAsync(m->d_red[rank][ch], value, sizeof(long long), hipMemcpyHostToDevice, st));
-        const ncclResult_t r = ncclAllReduce(m->d_red[rank][ch], m->d_red[rank][ch], 1, ncclInt64, ncclSum, m->comm[ch][rank], st);
+        ncclResult_t r;
+        {
+            std::shared_lock<std::shared_mutex> enq(m->comm_rw);
+            if (!m->comm_ready[ch] || m->abort_flag.load()) return false;
+            r = ncclAllReduce(m->d_red[rank][ch], m->d_red[rank][ch], 1, ncclInt64, ncclSum, m->comm[ch][rank], st);
+        }
         if (r != ncclSuccess) { fail(m, std::string("RCCL all-reduce failed: ") + ncclGetErrorString(r)); return false; }
         MCHK(m, rank, hipMemcpyAsync(value, m->d_red[rank][ch], sizeof(long long), hipMemcpyDeviceToHost, st));
         MCHK(m, rank, hipStreamSynchronize(st));
@@ -443,11 +480,12 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
         if (redo) ECHK(m, rank, c, bcd_hip_similarity_masks_exact(c, hist, ns, W, rows, D, w, b, tau, mask, nsim));
         verdict_known = true;
     }
-    if (m->ordered && g.world > 1 && !m->gate[rank].wait_coarser(s, g.S)) return false;
+    const bool talk = g.world > 1 || m->loopback; // (loopback: one rank that exchanges with itself, see bcd_hip_multi::loopback)
+    if (m->ordered && talk && !m->gate[rank].wait_coarser(s, g.S)) return false;
     int rounds = 0;
     const long long REDO = 1ll << 40; // added to the all-reduced count of undecided pixels by a rank whose masks are not valid
     for (;;) { // the marking problem; once more from the start if some rank has to recompute its masks
-        if (marking && g.world > 1) {
+        if (marking && talk) {
             // |S| of the b boundary lines comes from their owner (locally their windows are cut by the band edge)
             if (!exchange(m, rank, s, nsim + (size_t)r0 * W, up ? nsim + (size_t)(r0 - b) * W : nullptr, (size_t)b * W * 4,
                           nsim + (size_t)(r1 - b) * W, down ? nsim + (size_t)r1 * W : nullptr, (size_t)b * W * 4)) return false;
@@ -458,7 +496,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
         if (marking) {
             long long before = -1;
             for (;;) {
-                if (g.world > 1 && !exchange(m, rank, s, state + (size_t)r0 * W, up ? state + (size_t)(r0 - b) * W : nullptr, (size_t)b * W,
+                if (talk && !exchange(m, rank, s, state + (size_t)r0 * W, up ? state + (size_t)(r0 - b) * W : nullptr, (size_t)b * W,
                                              state + (size_t)(r1 - b) * W, down ? state + (size_t)r1 * W : nullptr, (size_t)b * W)) return false;
                 int32_t undecided = 0;
                 ECHK(m, rank, c, bcd_hip_active_step(c, mask, nsim, W, rows, w, b, r0, r1, job.prm.use_random_pixel_order, seed, row_offset,
@@ -471,7 +509,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
                     my_redo = redo != 0;
                     if (my_redo) total += REDO;
                 }
-                if (g.world > 1 && !allreduce(m, rank, s, &total)) return false;
+                if (talk && !allreduce(m, rank, s, &total)) return false;
                 if (!verdict_known) {
                     verdict_known = true;
                     if (total >= REDO) { restart = true; break; }
@@ -494,7 +532,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
     // accumulator halos: the (b + w) lines written outside the owned band belong to the neighbours
     float *rx_us = (float *)B(bcd_hip_multi::RX_UP_S).p, *rx_ds = (float *)B(bcd_hip_multi::RX_DN_S).p;
     int32_t *rx_uc = (int32_t *)B(bcd_hip_multi::RX_UP_C).p, *rx_dc = (int32_t *)B(bcd_hip_multi::RX_DN_C).p;
-    if (g.world > 1) {
+    if (talk) {
         if (!exchange(m, rank, s, sum, rx_us, (size_t)halo * W * 12, sum + (size_t)(rows - halo) * W * 3, rx_ds, (size_t)halo * W * 12)) return false;
         if (!exchange(m, rank, s, cnt, rx_uc, (size_t)halo * W * 4, cnt + (size_t)(rows - halo) * W, rx_dc, (size_t)halo * W * 4)) return false;
     }
@@ -574,7 +612,8 @@ bool rank_compute(const Job &job, int rank)
     }
     // ---- two lines of every unmerged finer output (hi - up(down(hi)) at the band edge), one line of the coarsest (up(lo))
     auto out_rows = [&](int s, int local_line) { return (float *)B(s, bcd_hip_multi::OUT).p + (size_t)local_line * bands[s].W * 3; };
-    if (S > 1 && g.world > 1) {
+    const bool talk = g.world > 1 || m->loopback;
+    if (S > 1 && talk) {
         for (int s = 0; s < S; ++s) {
             const int n = s < S - 1 ? 2 : 1, o0 = bands[s].own0 - bands[s].loc0, o1 = bands[s].own1 - bands[s].loc0;
             const size_t bytes = (size_t)n * bands[s].W * 12;
@@ -588,7 +627,7 @@ bool rank_compute(const Job &job, int rank)
         const int m0 = up ? o0 - 2 : o0, m1 = down ? o1 + 2 : o1;
         const int lo0 = (sb.loc0 + m0) / 2 - nb.loc0;
         ECHK(m, rank, cm, bcd_hip_merge(cm, out_rows(s, m0), sb.W, m1 - m0, out_rows(s + 1, lo0), 3));
-        if (s > 0 && g.world > 1) {
+        if (s > 0 && talk) {
             const size_t bytes = (size_t)sb.W * 12;
             if (!exchange(m, rank, S, out_rows(s, o0), up ? out_rows(s, o0 - 1) : nullptr, bytes, out_rows(s, o1 - 1), down ? out_rows(s, o1) : nullptr, bytes)) return false;
         }
@@ -640,7 +679,7 @@ int prepare(bcd_hip_multi *m, int S)
             if (m->use_rccl && hipMalloc((void **)&m->d_red[r][c], 64) != hipSuccess) { fail(m, "hipMalloc failed"); return BCD_HIP_ENOMEM; }
         }
     }
-    if (m->use_rccl && m->n > 1)
+    if (m->use_rccl && (m->n > 1 || m->loopback))
         for (int c = 0; c <= S; ++c) {
             if (m->comm_ready[c]) continue;
             ncclResult_t r;
@@ -669,7 +708,7 @@ int make_job(bcd_hip_multi *m, Job &job, int W, int H, int D, int nb_scales, con
     job.m = m; job.h_col = job.h_ns = job.h_hist = job.h_cov = nullptr; job.h_out = nullptr;
     job.W = W; job.H = H; job.D = D; job.S = nb_scales; job.prm = *prm;
     std::string err;
-    if (!job.geom.init(W, H, nb_scales, prm->search_radius, prm->patch_radius, m->n, err)) { fail(m, err); return BCD_HIP_EINVAL; }
+    if (!job.geom.init(W, H, nb_scales, prm->search_radius, prm->patch_radius, m->n, err, m->loopback)) { fail(m, err); return BCD_HIP_EINVAL; }
     if ((W >> (nb_scales - 1)) < 2 * prm->patch_radius + 1) { fail(m, "too many scales for this image size"); return BCD_HIP_EINVAL; }
     return BCD_HIP_OK;
 }
@@ -848,11 +887,100 @@ int bcd_hip_multi_create_rank(bcd_hip_multi **out, int rank, int n_ranks, int de
     m->use_rccl = true; // ranks of other processes are only reachable through RCCL
     m->ordered = true;
     m->stats.transport = 1;
-    for (int i = 0; i < n_ids && n_ranks > 1; ++i) {
+    for (int i = 0; i < n_ids && ids; ++i) { // (a world of one only needs them in loopback mode)
         ncclUniqueId id;
         memcpy(&id, ids + (size_t)i * sizeof(id), sizeof(id));
         m->ids.push_back(id);
     }
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_multi_set_loopback(bcd_hip_multi *m, int enabled)
+{
+    if (!m) return BCD_HIP_EINVAL;
+    if (enabled && (m->n != 1 || m->local_rank != 0)) { fail(m, "loopback needs a one-rank handle made by bcd_hip_multi_create_rank(rank 0 of 1)"); return BCD_HIP_EINVAL; }
+    if (enabled && m->ids.empty()) { fail(m, "loopback needs RCCL unique ids (one per scale + 1)"); return BCD_HIP_EINVAL; }
+    m->loopback = enabled != 0;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_multi_rank_renew_ids(bcd_hip_multi *m, const char *ids, int n_ids)
+{
+    if (!m || !ids || n_ids < 1) return BCD_HIP_EINVAL;
+    if (m->local_rank < 0) { fail(m, "not a one-rank handle"); return BCD_HIP_EINVAL; }
+    // communicators that are still up belong to the old ids: a renewal replaces all of them (every process does the same)
+    abort_comms(m);
+    m->ids.clear();
+    for (int i = 0; i < n_ids; ++i) {
+        ncclUniqueId id;
+        memcpy(&id, ids + (size_t)i * sizeof(id), sizeof(id));
+        m->ids.push_back(id);
+    }
+    std::lock_guard<std::mutex> lk(m->comm_mutex);
+    m->comm_aborted = false;
+    return BCD_HIP_OK;
+}
+
+// One device, real RCCL: everything the band driver does with the library, through the driver's own exchange() / allreduce() / fail() / prepare().
+int bcd_hip_multi_selftest_transport(int device, long long halo_bytes, char *report, int report_capacity)
+{
+    auto say = [&](const std::string &t) { if (report && report_capacity > 0) { strncpy(report, t.c_str(), (size_t)report_capacity - 1); report[report_capacity - 1] = 0; } };
+    if (halo_bytes < 16 || halo_bytes > (1ll << 30)) { say("halo_bytes out of range"); return BCD_HIP_EINVAL; }
+    const int S = 1, n_ids = S + 1;
+    auto fresh_ids = [&](std::vector<char> &v) {
+        v.resize((size_t)n_ids * BCD_HIP_MULTI_ID_BYTES);
+        for (int i = 0; i < n_ids; ++i)
+            if (bcd_hip_multi_unique_id(v.data() + (size_t)i * BCD_HIP_MULTI_ID_BYTES) != BCD_HIP_OK) return false;
+        return true;
+    };
+    std::vector<char> ids;
+    if (!fresh_ids(ids)) { say("ncclGetUniqueId failed"); return BCD_HIP_EDEVICE; }
+    bcd_hip_multi *m = nullptr;
+    int rc = bcd_hip_multi_create_rank(&m, 0, 1, device, ids.data(), n_ids);
+    if (rc != BCD_HIP_OK) { say("bcd_hip_multi_create_rank failed"); return rc; }
+    struct Guard { bcd_hip_multi *m; void *p[4] = { nullptr, nullptr, nullptr, nullptr }; ~Guard() { for (void *q : p) if (q) (void)hipFree(q); bcd_hip_multi_destroy(m); } } guard{ m };
+    auto bail = [&](const char *where, int code) { say(std::string(where) + ": " + bcd_hip_multi_last_error(m)); return code; };
+    if ((rc = bcd_hip_multi_set_loopback(m, 1)) != BCD_HIP_OK) return bail("set_loopback", rc);
+    reset_error(m);
+    if ((rc = prepare(m, S)) != BCD_HIP_OK) return bail("prepare (ncclCommInitRank, n = 1)", rc);
+    if (hipSetDevice(device) != hipSuccess) { say("hipSetDevice failed"); return BCD_HIP_EDEVICE; }
+    const size_t nb = (size_t)halo_bytes;
+    for (int i = 0; i < 4; ++i)
+        if (hipMalloc(&guard.p[i], nb) != hipSuccess) { say("out of device memory"); return BCD_HIP_ENOMEM; }
+    std::vector<unsigned char> h_up(nb), h_down(nb), back(nb);
+    auto round = [&](int ch, unsigned salt, const char *what) -> int {
+        hipStream_t st = m->stream[0][ch];
+        for (size_t i = 0; i < nb; ++i) { h_up[i] = (unsigned char)(i * 7u + salt); h_down[i] = (unsigned char)(i * 13u + 3u * salt + 1u); }
+        if (hipMemcpyAsync(guard.p[0], h_up.data(), nb, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(guard.p[1], h_down.data(), nb, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemsetAsync(guard.p[2], 0, nb, st) != hipSuccess || hipMemsetAsync(guard.p[3], 0, nb, st) != hipSuccess) { say("copy failed"); return BCD_HIP_EDEVICE; }
+        if (!exchange(m, 0, ch, guard.p[0], guard.p[2], nb, guard.p[1], guard.p[3], nb)) return bail(what, BCD_HIP_EDEVICE);
+        if (hipStreamSynchronize(st) != hipSuccess) { say(std::string(what) + ": stream synchronisation failed"); return BCD_HIP_EDEVICE; }
+        // the grouped self send / recv pairs in issue order: what went "up" comes back as the data from "up", likewise down
+        if (hipMemcpy(back.data(), guard.p[2], nb, hipMemcpyDeviceToHost) != hipSuccess || back != h_up) { say(std::string(what) + ": data of the first send / recv pair differs"); return BCD_HIP_EDEVICE; }
+        if (hipMemcpy(back.data(), guard.p[3], nb, hipMemcpyDeviceToHost) != hipSuccess || back != h_down) { say(std::string(what) + ": data of the second send / recv pair differs"); return BCD_HIP_EDEVICE; }
+        long long v = 123456789012ll + salt;
+        if (!allreduce(m, 0, ch, &v)) return bail(what, BCD_HIP_EDEVICE);
+        if (v != 123456789012ll + salt) { say(std::string(what) + ": all-reduce of one rank changed the value"); return BCD_HIP_EDEVICE; }
+        return BCD_HIP_OK;
+    };
+    for (int ch = 0; ch <= S; ++ch)
+        if ((rc = round(ch, 17u + (unsigned)ch, "first exchange")) != BCD_HIP_OK) return rc;
+    // failure path: ncclCommAbort on every communicator; the consumed ids cannot make new ones; fresh ids can
+    fail(m, "self-test: simulated failure");
+    if (m->comm_ready[0] || !m->comm_aborted) { say("abort did not take the communicators down"); return BCD_HIP_EDEVICE; }
+    {
+        long long v = 1;
+        if (exchange(m, 0, 0, guard.p[0], guard.p[2], nb, guard.p[1], guard.p[3], nb) || allreduce(m, 0, 0, &v)) { say("an aborted communicator was used"); return BCD_HIP_EDEVICE; }
+    }
+    reset_error(m);
+    if (prepare(m, S) == BCD_HIP_OK) { say("prepare() rebuilt communicators from consumed ids"); return BCD_HIP_EDEVICE; }
+    if (!fresh_ids(ids)) { say("ncclGetUniqueId failed"); return BCD_HIP_EDEVICE; }
+    if ((rc = bcd_hip_multi_rank_renew_ids(m, ids.data(), n_ids)) != BCD_HIP_OK) return bail("renew_ids", rc);
+    reset_error(m);
+    if ((rc = prepare(m, S)) != BCD_HIP_OK) return bail("prepare after the abort", rc);
+    for (int ch = 0; ch <= S; ++ch)
+        if ((rc = round(ch, 91u + (unsigned)ch, "exchange after abort + rebuild")) != BCD_HIP_OK) return rc;
+    say("ok: ncclCommInitRank(n=1) x2, grouped self send/recv + int64 all-reduce on 2 channels, ncclCommAbort, rebuild from fresh ids, second exchange");
     return BCD_HIP_OK;
 }
 

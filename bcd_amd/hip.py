@@ -43,7 +43,7 @@ SYMBOLS = [
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_set_progress_callback",
     "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_set_progress_callback", "bcd_hip_multi_set_frame_timeout", "bcd_hip_multi_set_comm_trace", "bcd_hip_multi_get_comm_trace", "bcd_hip_multi_denoise_host",
     "bcd_hip_multi_unique_id", "bcd_hip_multi_create_rank", "bcd_hip_multi_rank_configure", "bcd_hip_multi_rank_upload", "bcd_hip_multi_rank_step",
-    "bcd_hip_multi_rank_download",
+    "bcd_hip_multi_rank_download", "bcd_hip_multi_rank_renew_ids", "bcd_hip_multi_set_loopback", "bcd_hip_multi_selftest_transport",
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_similarity_masks_deferred", "bcd_hip_similarity_masks_verdict", "bcd_hip_similarity_masks_exact", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
@@ -449,6 +449,28 @@ class RankDenoiser:
     def step(self):
         self._chk(lib().bcd_hip_multi_rank_step(self.h))
 
+    def set_loopback(self, on=True):
+        """one rank of one, exchanging with itself over real RCCL communicators (one-GPU test of the transport code)"""
+        self._chk(lib().bcd_hip_multi_set_loopback(self.h, 1 if on else 0))
+
+    def renew_ids(self, ids):
+        self._chk(lib().bcd_hip_multi_rank_renew_ids(self.h, ids, len(ids) // MULTI_ID_BYTES))
+
+    def stats(self):
+        s = MultiStats()
+        lib().bcd_hip_multi_get_stats(self.h, C.byref(s))
+        return s
+
+    def set_comm_trace(self, on):
+        lib().bcd_hip_multi_set_comm_trace(self.h, 1 if on else 0)
+
+    def comm_trace(self):
+        n = lib().bcd_hip_multi_get_comm_trace(self.h, self.rank, None, 0)
+        buf = (C.c_int64 * max(1, n))()
+        n = lib().bcd_hip_multi_get_comm_trace(self.h, self.rank, buf, n)
+        v = list(buf[:n])
+        return [tuple(v[i:i + 4]) for i in range(0, n, 4)]
+
     def download(self):
         import numpy as np
         out = np.empty((self.owned[1], self.W, 3), np.float32)
@@ -459,6 +481,13 @@ class RankDenoiser:
         if self.h:
             lib().bcd_hip_multi_destroy(self.h)
             self.h = None
+
+
+def selftest_transport(device=0, halo_bytes=7 * 3840 * 16):
+    """bcd_hip_multi_selftest_transport: (rc, report line)"""
+    buf = C.create_string_buffer(512)
+    rc = lib().bcd_hip_multi_selftest_transport(int(device), C.c_longlong(int(halo_bytes)), buf, 512)
+    return rc, buf.value.decode()
 
 
 def visit_order(W, H, w, random_order, seed):

@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <omp.h>
 #include <vector>
 
 using namespace std;
@@ -129,20 +130,32 @@ namespace bcd
 					"set m_useCuda = true (the default) to run on the HIP device" << endl;
 			return false;
 		}
-		// Denoiser.cpp:121 writes the actual OpenMP thread count back.  The loop runs on the device; what the host contributes is one
-		// driver thread per scale and device
-		const int requestedNbOfCores = m_parameters.m_nbOfCores;
-		m_parameters.m_nbOfCores = i_nbOfScales * int(m_devices.size());
-
+		// Denoiser.cpp:113-121: m_nbOfCores <= 0 means "OpenMP's default", and the ACTUAL thread count is written back -- the same number that
+		// then decides the -r 0 visiting order (:375-380).  The loop runs on the device; the field keeps exactly that meaning here: the thread
+		// count the reference would have run with.  Written back, it reproduces itself on the next denoise() of a reused object (a value
+		// derived from scales x devices did not: frame 2 of a reused MultiscaleDenoiser visited in another order than frame 1)
+		const int effectiveNbOfCores = m_parameters.m_nbOfCores > 0 ? m_parameters.m_nbOfCores : std::max(1, omp_get_max_threads());
+		m_parameters.m_nbOfCores = effectiveNbOfCores;
 		bcd_hip_params prm;
 		bcd_hip_default_params(&prm);
 		prm.hist_dist_threshold = m_parameters.m_histogramDistanceThreshold;
 		prm.patch_radius = m_parameters.m_patchRadius;
 		prm.search_radius = m_parameters.m_searchWindowRadius;
 		prm.min_eigen_value = m_parameters.m_minEigenValue;
-		// Denoiser.cpp:375-380: a shuffle (-r 1), else -- several cores asked for -- the strip list (reorderPixelSetJumpNextStrip), else scanline.
-		// The marking follows that list exactly (the reference's threads race through it); row bands over several devices keep the scanline order
-		prm.use_random_pixel_order = m_parameters.m_useRandomPixelOrder ? 1 : ((requestedNbOfCores > 1 && m_devices.size() == 1) ? 2 : 0);
+		// Denoiser.cpp:375-380: a shuffle (-r 1), else -- more than one thread -- the strip list (reorderPixelSetJumpNextStrip), else scanline.
+		// The marking follows that list exactly (the reference's threads race through it).  The strip key packs the frame geometry into 32 bits
+		// (bcd_common.h) and row bands over several devices mark in scanline order: outside those limits -r 0 falls back to the scanline
+		// order -- the reference's own one-thread order -- with a note
+		prm.use_random_pixel_order = m_parameters.m_useRandomPixelOrder ? 1 : 0;
+		if(!m_parameters.m_useRandomPixelOrder && effectiveNbOfCores > 1)
+		{
+			const bool fits = m_width <= 8191 && m_height <= 8191 && m_parameters.m_patchRadius <= 3 && m_parameters.m_searchWindowRadius >= 1;
+			if(m_devices.size() == 1 && fits)
+				prm.use_random_pixel_order = 2;
+			else
+				cout << "Note: -r 0 with " << effectiveNbOfCores << " cores asks for the strip visiting order, which is not available "
+						<< (fits ? "on several devices" : "for this frame geometry") << ": visiting in scanline order (the reference's one-core order)" << endl;
+		}
 		prm.marked_skip_probability = m_parameters.m_markedPixelsSkippingProbability;
 		prm.order_seed = m_orderSeed;
 

@@ -228,6 +228,15 @@ namespace
 
 	int launchBayesianCollaborativeDenoising(int argc, const char** argv)
 	{
+		// --use-cuda 0 asks for the reference's CPU/OpenMP loop, which this build does not have (one product path: the HIP device).  Said
+		// before the input files are read, not after minutes of EXR decoding (the library refuses the same request with `false`)
+		for(int i = 1; i + 1 < argc; ++i)
+			if(string(argv[i]) == "--use-cuda" && atoi(argv[i + 1]) != 1)
+			{
+				cerr << "bcd_cli: --use-cuda 0 requests the CPU/OpenMP path, which this build does not have; nothing was read or written. "
+						"Run without the flag (or --use-cuda 1) to denoise on the HIP device" << endl;
+				return 2;
+			}
 		ProgramArguments args;
 		if(!parseProgramArguments(argc, argv, args))
 			return 1;

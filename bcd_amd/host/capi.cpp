@@ -140,6 +140,39 @@ int bcdcore_denoise_ex(const float* col, const float* ns, const float* hist, con
 	return ok ? (monotone ? 1 : 2) : 0;
 }
 
+/// ONE MultiscaleDenoiser (or Denoiser), denoise() called twice with -r 0 and the given m_nbOfCores: the written-back core count must not
+/// change what the second call does (returns 0 on failure, else 1; nbOfCoresAfter[2] = the field after each call)
+int bcdcore_denoise_reuse(const float* col, const float* ns, const float* hist, const float* cov, int W, int H, int D, int nscales, int b,
+		int nbOfCores, float* out1, float* out2, int* nbOfCoresAfter)
+{
+	Deepimf cImg(W, H, 3), nImg(W, H, 1), hImg(W, H, D), vImg(W, H, 6), oImg(W, H, 3);
+	cImg.copyDataFrom(col); nImg.copyDataFrom(ns); hImg.copyDataFrom(hist); vImg.copyDataFrom(cov);
+	DenoiserInputs in;
+	in.m_pColors = &cImg; in.m_pNbOfSamples = &nImg; in.m_pHistograms = &hImg; in.m_pSampleCovariances = &vImg;
+	DenoiserOutputs o;
+	o.m_pDenoisedColors = &oImg;
+	DenoiserParameters p;
+	p.m_searchWindowRadius = b;
+	p.m_useRandomPixelOrder = false;
+	p.m_nbOfCores = nbOfCores;
+	std::unique_ptr<IDenoiser> d;
+	if(nscales > 1) d.reset(new MultiscaleDenoiser(nscales));
+	else d.reset(new Denoiser());
+	d->setInputs(in);
+	d->setOutputs(o);
+	d->setParameters(p);
+	float* outs[2] = { out1, out2 };
+	for(int i = 0; i < 2; ++i)
+	{
+		oImg = cImg; // (the multiscale path wants the output pre-sized like the input)
+		if(!d->denoise())
+			return 0;
+		oImg.copyDataTo(outs[i]);
+		nbOfCoresAfter[i] = d->getParameters().m_nbOfCores;
+	}
+	return 1;
+}
+
 int bcdcore_spike_filter(float* col, float* ns, float* hist, float* cov, int W, int H, int D, float factor)
 {
 	Deepimf c(W, H, 3), n(W, H, 1), h(W, H, D), v(W, H, 6);

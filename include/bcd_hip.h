@@ -158,7 +158,7 @@ int  bcd_hip_multi_set_frame_timeout(bcd_hip_multi *m, int milliseconds);
  * in a send / receive / all-reduce are released instead of waiting for ever), and a frame that has not finished after
  * BCD_HIP_MULTI_TIMEOUT_S seconds (default 600; 0 = never; bcd_hip_multi_set_frame_timeout sets it in milliseconds) is failed the
  * same way by the handle's watchdog thread, which is what ends a frame whose peer process died.  bcd_hip_multi_create handles rebuild their communicators on the next call; a bcd_hip_multi_create_rank handle (one process
- * per GPU) must be destroyed and created again from fresh unique ids by all processes. */
+ * per GPU) needs fresh unique ids from all processes: bcd_hip_multi_rank_renew_ids, or destroy and create it again. */
 /* Communication trace of the last frame (debugging / tests): per rank, in the order the rank ENQUEUED them, four values per
  * operation: channel (scale, or nb_scales for the merges), kind (0 = neighbour exchange, 1 = all-reduce), bytes exchanged with the
  * rank above, bytes exchanged with the rank below.  All ranks must show the same (channel, kind) sequence and neighbours the same
@@ -180,6 +180,20 @@ int  bcd_hip_multi_rank_configure(bcd_hip_multi *m, int W, int H, int D, int nb_
 int  bcd_hip_multi_rank_upload(bcd_hip_multi *m, const float *h_colors, const float *h_nsamples, const float *h_histograms, const float *h_covariances);
 int  bcd_hip_multi_rank_step(bcd_hip_multi *m);
 int  bcd_hip_multi_rank_download(bcd_hip_multi *m, float *h_out_owned);
+/* After a failure (or a timeout) the communicators of a one-rank handle are gone and their unique ids are consumed: instead of
+ * destroying the handle, every process may hand in nb_scales + 1 FRESH ids (shared like the first set) and go on with the next frame;
+ * contexts, streams and the resident band stay. */
+int  bcd_hip_multi_rank_renew_ids(bcd_hip_multi *m, const char *ids, int n_ids);
+/* Loopback (tests on a one-GPU box; a handle made by bcd_hip_multi_create_rank(rank 0 of 1) with ids): the rank is its own neighbour on
+ * both sides, so that a frame enqueues every exchange and all-reduce of the band protocol on real RCCL communicators (ncclCommInitRank
+ * with n = 1, grouped self send / recv) in the order and with the sizes a band inside a larger world would use; received data goes to
+ * scratch and the result is the single-GPU frame. */
+int  bcd_hip_multi_set_loopback(bcd_hip_multi *m, int enabled);
+/* One device, real RCCL, through the driver's own transport code: communicators of a world of one from real unique ids, a grouped
+ * self send / recv of two halo_bytes buffers and the int64 all-reduce on two channels (data checked), a simulated failure
+ * (ncclCommAbort; the aborted communicators refuse further use; consumed ids cannot rebuild them), renewal from fresh ids, a second
+ * exchange.  0 = all of it worked; `report` gets one line either way. */
+int  bcd_hip_multi_selftest_transport(int device, long long halo_bytes, char *report, int report_capacity);
 
 /* ---- whole path, host buffers (what bcd::Denoiser / bcd_cli call): H2D + denoise + D2H -------- */
 int bcd_hip_denoise_host(bcd_hip_ctx *ctx, const float *h_colors, const float *h_nsamples,

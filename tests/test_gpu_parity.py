@@ -665,7 +665,7 @@ def test_1080p_bench_workload_against_the_oracle(hipctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not _os.environ.get("BCD_TEST_SLOW"), reason="two minutes of oracle time on 128 host threads: run with BCD_TEST_SLOW=1")
+@pytest.mark.skipif((_os.cpu_count() or 1) < 64 and not _os.environ.get("BCD_TEST_SLOW"), reason="the 4K oracle run needs >= 64 host cores (80 s on 128 threads of the GPU box); BCD_TEST_SLOW=1 forces it")
 def test_4k_config3_frame_against_the_oracle(hipctx):
     """BASELINE configs[3]'s frame at its FULL size (3840 x 2160, 3 scales, b = 6, -m 1 -r 1) on one GPU against the oracle's ordered visit on the
     host cores (opt-in: the oracle needs about two minutes); the 8-row-band form of the same frame is compared with this single-GPU result by
@@ -684,7 +684,7 @@ def test_4k_config3_frame_against_the_oracle(hipctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not _os.environ.get("BCD_TEST_SLOW"), reason="several minutes of oracle time on 128 host threads: run with BCD_TEST_SLOW=1")
+@pytest.mark.skipif((_os.cpu_count() or 1) < 64 and not _os.environ.get("BCD_TEST_SLOW"), reason="the 4K b = 12 oracle run needs >= 64 host cores (220 s on 128 threads of the GPU box); BCD_TEST_SLOW=1 forces it")
 def test_4k_config4_frame_against_the_oracle(hipctx):
     """BASELINE configs[4]'s chain at its FULL size (3840 x 2160, b = 12, -p 1 --p-factor 2, -r 1 -m 1, 3 scales) on one GPU against the oracle
     (its spike filter -- pinned to the reference's compiled unit -- then its ordered visit on the host cores; opt-in)"""
@@ -776,7 +776,7 @@ def test_similarity_masks_bitexact_on_a_large_scale(hipctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["bench_noisy", "bench_clean", "mixed_counts", "b12", "ragged"])
 def test_fast_similarity_path_equals_exact_kernels(hipctx, kind):
-    """approximate distance planes + exact re-evaluation of the pairs within tau (1 +- 2^-14) (k_similarity_fast.hip) give the
+    """approximate distance planes + exact re-evaluation of the pairs within tau (1 +- 2^-10) (k_similarity_fast.hip) give the
     masks of the exact kernels bit for bit; the approximate patch distances stay far inside that band; bin counts are exact"""
     import bcd_amd.core as core
     b, tau = 6, 1.0
@@ -1195,6 +1195,28 @@ def test_bcd_cli_baseline_config0_plumbing(hipctx, tmp_path):
     assert np.max(np.abs(want4 - want)) > 1e-3 * np.max(want)             # (the two orders do give different images)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb_of_cores,expect_strips", [(0, True), (1, False), (4, True)])
+def test_reused_multiscale_denoiser_visits_in_the_same_order_twice(hipctx, nb_of_cores, expect_strips):
+    """ONE bcd::MultiscaleDenoiser, denoise() twice with -r 0: the core count written back after the first call (Denoiser.cpp:121) is the one
+    that decided its visiting order (:375-380), so the second call gives the same frame (to the round-off of the accumulators' atomics) -- and m_nbOfCores = 0 means all cores (strips on a
+    multi-core host, as in the reference), 1 the scanline order"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H, S = 96, 80, 3
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 21, 0.12, 0.0)
+    ok, o1, o2, after = core.denoise_reuse(col, ns, hist, cov, nscales=S, b=6, nb_of_cores=nb_of_cores)
+    assert ok and after[0] == after[1] and (after[0] == nb_of_cores or nb_of_cores == 0)
+    assert rel_linf(o1, o2) < 2e-6                                   # (the accumulators' float atomics: ~1e-7; another ORDER is > 1e-4, below)
+    if (_os.cpu_count() or 1) > 1:
+        prm = bh.default_params(m=1.0, random_order=2 if expect_strips else 0, seed=bh.strip_order_seed(W, H, 1, 6) if expect_strips else 0)
+        # (per-scale strip seeds are derived inside the engine; compare against the engine called with that order directly)
+        other = bh.default_params(m=1.0, random_order=0 if expect_strips else 2)
+        a = hipctx.denoise_host(col, ns, hist, cov, S, prm)
+        b_ = hipctx.denoise_host(col, ns, hist, cov, S, other)
+        assert rel_linf(o1, a) < 1e-6 and rel_linf(o1, b_) > 1e-4     # the order asked for, not the other one
+
+
 # ---- BASELINE configs[3] and configs[4]: against the ORACLE at reduced size, by properties at full size ------------------------------
 @pytest.mark.gpu
 def test_config4_chain_single_gpu_against_the_oracle(hipctx):
@@ -1238,7 +1260,9 @@ def test_config4_chain_row_bands_against_the_oracle(hipctx, ranks):
     # through bcd::MultiscaleDenoiser::setDevices + setSpikePrefilter (what bcd_cli --devices a,b -p 1 does)
     ok, out, monotone = core.denoise(col, ns, hist, cov, nscales=S, b=b, m=1.0, seed=77, devices=[0] * ranks, prefilter_factor=2.0)
     assert ok and monotone and rel_linf(out, want) < TOL
-    assert core.last_nb_of_cores() == S * ranks                           # host driver threads: one per scale and device
+    # m_nbOfCores = 0 in, the thread count the reference would have run with out (Denoiser.cpp:113-121: OpenMP's default) -- the number that
+    # also decides the -r 0 visiting order, so that it reproduces itself on a reused object
+    assert core.last_nb_of_cores() >= 1 and core.last_nb_of_cores() == (_os.cpu_count() if not _os.environ.get("OMP_NUM_THREADS") else int(_os.environ["OMP_NUM_THREADS"]))
     assert core.lib().bcdcore_last_progress_values() > 4                  # the multi-device path reports progress inside the loop
 
 
@@ -1343,6 +1367,84 @@ def test_two_gpu_bench_exercises_the_rccl_transport():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["parallelism"] == "rowband2-exactmark-native"
     assert line["band_check"]["rel_linf_vs_single_gpu"] < 1e-5 and line["n_gpus"] == 2
+
+
+_RCCL_CANARY = {}
+
+
+def _rccl_canary():
+    """the transport self-test once in a child process with a time limit: a communication kernel that never returns must cost this test,
+    not the session (the in-process calls below only run after the child came back)"""
+    if "rc" not in _RCCL_CANARY:
+        import subprocess
+        import sys
+        root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+        env = dict(_os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        code = "import bcd_amd.hip as bh; rc, msg = bh.selftest_transport(0); print(msg); raise SystemExit(rc)"
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+            _RCCL_CANARY["rc"], _RCCL_CANARY["msg"] = r.returncode, (r.stdout + r.stderr)[-1500:]
+        except subprocess.TimeoutExpired:
+            _RCCL_CANARY["rc"], _RCCL_CANARY["msg"] = -9, "the transport self-test did not return within 300 s"
+    return _RCCL_CANARY["rc"], _RCCL_CANARY["msg"]
+
+
+@pytest.mark.gpu
+def test_rccl_transport_selftest_on_one_gpu():
+    """the band driver's RCCL usage on ONE device, through its own exchange() / allreduce() / fail() / prepare(): ncclCommInitRank with n = 1 from
+    real unique ids on two channels, a grouped self send / recv of two halo-sized buffers (7 lines of a 4K frame's accumulators) with the data
+    checked, the int64 all-reduce, a simulated failure (ncclCommAbort; the aborted communicators refuse further use, consumed ids cannot rebuild
+    them), bcd_hip_multi_rank_renew_ids with fresh ids, and a second exchange on the rebuilt communicators"""
+    import bcd_amd.hip as bh
+    rc, msg = _rccl_canary()
+    assert rc == 0, msg
+    rc, msg = bh.selftest_transport(0, 13 * 3840 * 16)          # in this process too (b = 12 halo size): librccl is mapped and used here
+    assert rc == 0 and msg.startswith("ok"), msg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [1.0, 0.0])
+def test_whole_frame_through_the_rccl_transport_in_loopback(hipctx, m):
+    """bcd_hip_multi_create_rank(0 of 1) with real ids in loopback mode: every exchange and all-reduce of the band protocol of a 3-scale frame
+    is enqueued on real RCCL communicators (one per scale + the merges'), on the scales' streams between the compute kernels and under the
+    issue-order gate -- with the sizes a band inside a larger world would use -- and the frame is still the single-GPU frame"""
+    import bcd_amd.hip as bh
+    import bcd_amd.core as core
+    rc, msg = _rccl_canary()
+    assert rc == 0, msg
+    W, H, S, b = 256, 288, 3, 6
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 21, 0.12, 0.005)
+    prm = bh.default_params(m=m, random_order=1, seed=9, b=b)
+    want = hipctx.denoise_host(col, ns, hist, cov, S, prm)
+    rd = bh.RankDenoiser(0, 1, 0, bh.multi_unique_ids(S + 1))
+    try:
+        rd.set_loopback(True)
+        rd.set_comm_trace(True)
+        first, lines, own0, owned = rd.configure(W, H, hist.shape[2], S, prm)
+        assert (first, lines, own0, owned) == (0, H, 0, H)
+        rd.upload(col, ns, hist, cov)
+        rd.step()
+        got = rd.download()
+        trace = rd.comm_trace()
+        rd.step()                                               # steady state: same communicators, second frame
+        again = rd.download()
+        st = rd.stats()
+    finally:
+        rd.close()
+    assert st.transport == 1 and st.frames == 2
+    assert rel_linf(got, want) < 1e-5 and rel_linf(again, want) < 1e-5
+    chans = [ch for ch, _, _, _ in trace]
+    assert set(chans) == set(range(S + 1))                      # every scale's communicator and the merges' one carried traffic
+    halo = b + 1
+    for s in range(S):
+        sizes = [(up, dn) for ch, k, up, dn in trace if ch == s and k == 0]
+        assert ((halo * (W >> s) * 12,) * 2 in sizes) and ((halo * (W >> s) * 4,) * 2 in sizes)     # accumulator halos of the scale, both neighbours
+    assert any(k == 1 for _, k, _, _ in trace) == (m > 0)       # the marking all-reduce
+    first_of = {c: chans.index(c) for c in set(chans)}
+    last_of = {c: len(chans) - 1 - chans[::-1].index(c) for c in set(chans)}
+    for c in range(S - 1):
+        assert last_of[c + 1] < first_of[c]                     # issue order: coarser scales first
+    assert first_of[S] > max(last_of[c] for c in range(S))      # the merges' exchanges last
 
 
 @pytest.mark.gpu
