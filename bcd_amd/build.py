@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the reference CPU path is built without FMA contraction and the similarity test is a
 # hard threshold; kernels call fmaf() explicitly where fusing is wanted.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
-             "-Wno-unused-result", "-Wno-unused-value", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+             "-Wno-unused-result", "-Wno-unused-value", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt"] + os.environ.get("HIPCC_EXTRA", "").split()
 CXX_FLAGS = ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-fopenmp"]
 
 

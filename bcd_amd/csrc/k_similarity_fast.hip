@@ -41,6 +41,9 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// sixteen zero bytes in global memory: the source of LDS-DMA lanes whose pixel lies outside the image
+__device__ const float4 g_rw_zero16 = { 0.f, 0.f, 0.f, 0.f };
+
 constexpr int RW_TW = 64, RW_TH = 4;   // tile
 constexpr int RW_CW = 12;              // widest span of column displacements served by one staged window
 constexpr int RW_NCOLS = RW_TW + RW_CW;
@@ -102,6 +105,39 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
         const bool pow2 = (__float_as_uint(un) & 0x7fffffu) == 0u && un >= 1.f && un <= 65536.f;
         if (!pow2) { if (threadIdx.x == 0) range_flag[2] = 1; return; } // (the same for every workgroup: nothing of this launch is used)
     }
+    // (round 4) The four lines that open a pass over the displacement lines go straight from global memory into their ring slots
+    // (global_load_lds_dwordx4: lane l of a wavefront lands at base + 16 l, which IS the ring's layout; no staging registers), all four
+    // at once -- and for the first pass before anything else, so that the own histogram, the range check and the sample-count check run
+    // in the shadow of that fetch.  Before: own histogram, checks, then four fetch -> store round trips one after the other, during which
+    // the workgroup's eight wavefronts did no arithmetic.  Lanes outside the image copy sixteen zero bytes.
+    auto pass_geometry = [&](int cbeg, int &cend, int &nc, int &wcols, int &dl0) __attribute__((always_inline)) {
+        cend = min(b, cbeg + RW_CW); nc = cend - cbeg + 1; wcols = RW_TW + (cend - cbeg);
+        dl0 = cend >= 0 ? 0 : 1; // displacement line 0 only holds dc >= 0
+    };
+    auto open_pass = [&](int cbeg, int wcols, int dl0) __attribute__((always_inline)) {
+        for (int g = row0 + dl0; g < row0 + dl0 + 4; ++g) {
+            float *slot = ring + (g & 3) * L::ROW;
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) {
+                const int i = threadIdx.x + u * RW_THREADS;
+                const int lc = i / Q, q = i - lc * Q, gc = col0 + cbeg + lc;
+                const bool in_image = g < H && gc >= 0 && gc < W;
+                const float4 *src = in_image ? reinterpret_cast<const float4 *>(hist) + ((size_t)g * W + gc) * Q + q : &g_rw_zero16;
+                if (i < wcols * Q) // (whole wavefronts beyond the line's end issue nothing)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(slot + 4 * (wave * 64 + u * RW_THREADS)), 16, 0, 0);
+            }
+            if (!UNI) {
+                const int lc = threadIdx.x, gc = col0 + cbeg + lc;
+                if (lc < wcols) ring_n[(g & 3) * RW_NCOLS + lc] = (g < H && gc >= 0 && gc < W) ? ns[(size_t)g * W + gc] : 1.f;
+            }
+        }
+    };
+    {
+        int cend, nc, wcols, dl0;
+        pass_geometry(-b, cend, nc, wcols, dl0);
+        open_pass(-b, wcols, dl0);
+    }
     float h1[D];
     float n1 = UNI ? un : 1.f;
     {
@@ -155,15 +191,15 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
     };
 
     for (int cbeg = -b; cbeg <= b; cbeg += RW_ND) {
-        const int cend = min(b, cbeg + RW_CW), nc = cend - cbeg + 1, wcols = RW_TW + (cend - cbeg);
-        const int dl0 = cend >= 0 ? 0 : 1; // displacement line 0 only holds dc >= 0
+        int cend, nc, wcols, dl0;
+        pass_geometry(cbeg, cend, nc, wcols, dl0);
         float4 pre[NPRE];
         float pre_n = 1.f;
-        __syncthreads(); // the previous pass is done with the ring
-        for (int g = row0 + dl0; g < row0 + dl0 + 4; ++g) {
-            fetch_line(pre, pre_n, g, cbeg, wcols);
-            store_line(pre, pre_n, g, wcols);
+        if (cbeg != -b) { // (the first pass's lines are on their way since the top of the kernel)
+            __syncthreads(); // the previous pass is done with the ring
+            open_pass(cbeg, wcols, dl0);
         }
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the LDS-DMA of this wavefront has landed (hipcc does not count it: counted here)
         __syncthreads();
         for (int dl = dl0; dl <= b; ++dl) {
             // the line that enters the ring for dl + 1 travels while dl is evaluated

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbcd_hip.so")
+LIB_PATH = os.environ.get("BCD_HIP_LIB") or os.path.join(_HERE, "lib", "libbcd_hip.so")   # (BCD_HIP_LIB: tools load instrumented builds)
 
 _F = C.POINTER(C.c_float)
 _VP = C.c_void_p
