@@ -31,11 +31,14 @@ int bcd_pairdist_rw_supported(int D);
 hipError_t bcd_launch_pairdist_rw(const float *, const float *, int, int, int, int, void * /* binary16 T planes */, uint8_t *, int *, float, hipStream_t);
 hipError_t bcd_launch_pairdist_rw_rows(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, int, int, hipStream_t);
 int bcd_pairdist_rw_tile_lines();
+hipError_t bcd_launch_pairdist_rw_counting(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_spike_rows(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *, float *, float *, int, int,
                                  hipStream_t);
 hipError_t bcd_launch_max_rel_dev(const float *, const float *, const uint8_t *, const uint8_t *, int, int, int, unsigned int *, hipStream_t);
 hipError_t bcd_launch_window_distances(const float *, const uint8_t *, int, int, int, int, int, int, float *, hipStream_t);
 hipError_t bcd_launch_pixel_cov(const float *, const float *, int64_t, float *, hipStream_t);
+hipError_t bcd_launch_pixel_cov_clear(const float *, const float *, int64_t, float *, float *, int32_t *, hipStream_t);
+hipError_t bcd_launch_scale_begin(int *, int, int, int, int *, int, int *, int, hipStream_t);
 hipError_t bcd_launch_finalize_band(const float *, const int32_t *, int, int, int, const float *, const int32_t *, const float *, const int32_t *, float *,
                                     hipStream_t);
 hipError_t bcd_launch_finalize(const float *, const int32_t *, int64_t, float *, hipStream_t);
@@ -57,7 +60,9 @@ size_t bcd_bayes_lds_bytes(int w, int b);
 size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
 size_t bcd_bayes27_record_bytes();
 hipError_t bcd_launch_bayes27(const float *, const float *, const uint32_t *, const int32_t *, int, int, int *, int, int, int, int, float, float *, float *,
-                              int32_t *, int *, hipStream_t);
+                              int32_t *, int *, hipStream_t, int);
+hipError_t bcd_launch_bayes27_redo(const float *, const float *, const uint32_t *, const int32_t *, int, int, int *, int, int, int, int, float, float *, float *,
+                                   int32_t *, hipStream_t);
 hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, const int32_t *, int *, int, int, int, int,
                                    int, float, float *, int32_t *, float *, size_t, hipStream_t);
 hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, const int32_t *, int, int, int, int, int, float *,
@@ -104,6 +109,12 @@ struct Work {
     bool nonuniform = false;
     unsigned uni_probe = 0;
     bool speculated = false;       // the current pass launched the uniform kernel on the first pixel's count, unchecked by the host
+    // (round 4) k_scale_begin cleared these at the head of the scale's stream: the first user takes them as they are, a repeated use (second
+    // similarity attempt, second marking batch, second chunk of a long list) clears its own as before
+    bool clean_flags = false, clean_lines = false, clean_dc = false, clean_wq = false;
+    // the redo kernel of the register-resident finish (k_bayes27w<2> over the -- normally empty -- list of items whose sweep inverse failed its
+    // checks) is only launched when the list's counter, read with the scale's last synchronisation, says so
+    struct { bool pending = false; int first = 0, n = 0, cus = 0; } redo;
 };
 
 struct bcd_hip_ctx {
@@ -287,7 +298,8 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     const bool pre = wk.planes.ready && exact_mode != 1 && wk.planes.hist == d_hist && wk.planes.ns == d_ns && wk.planes.W == W && wk.planes.H == H &&
                      wk.planes.D == D && wk.planes.b == b && wk.planes.tau == tau && w == 1;
     wk.planes.ready = false;
-    if (pre) { // (flags [0] and [2] belong to the launches that made the planes)
+    if (wk.clean_flags) wk.clean_flags = false; // (cleared by k_scale_begin, which kept the words of planes computed ahead)
+    else if (pre) { // (flags [0] and [2] belong to the launches that made the planes)
         HIPCHK(ctx, hipMemsetAsync(d_flag + 1, 0, sizeof(int), wk.stream));
         HIPCHK(ctx, hipMemsetAsync(d_flag + 3, 0, sizeof(int), wk.stream));
     } else HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream));
@@ -374,13 +386,16 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
     constexpr size_t LINE_INTS = (size_t)BCD_CNT_LINES * BCD_CNT_STRIDE;
     RCCHK(ensure(ctx, wk.cnt_lines, ROUND_BATCH * LINE_INTS * sizeof(int)));
     int *d_lines = (int *)wk.cnt_lines.p;
-    HIPCHK(ctx, hipMemsetAsync(d_lines, 0, ROUND_BATCH * LINE_INTS * sizeof(int), wk.stream));
+    if (wk.clean_lines) wk.clean_lines = false; // (k_scale_begin)
+    else {
+        HIPCHK(ctx, hipMemsetAsync(d_lines, 0, ROUND_BATCH * LINE_INTS * sizeof(int), wk.stream));
+        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), wk.stream));
+    }
     // b = 6 / 12: dependency lists extracted once per marking problem, then cheap tile rounds (in-tile chains are resolved
     // inside a launch: few launches for a random order, more for the long chains of the scanline order);
     // other radii: the generic one-level-per-launch kernel
     const bool listed = (b == 6 || b == 12);
     int batch = 4;
-    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ROUND_BATCH * sizeof(int), wk.stream));
     if (listed) {
         const int side = 2 * b + 1, words = (side * side + 31) / 32;
         const int iters = 8; // in-tile iterations per launch
@@ -448,10 +463,11 @@ int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t
 // number of full-estimate pixels (one short round trip, the fallback kernel is already running on its side stream) to size the
 // record buffer and to cut very long lists (-m 0) into chunks.  Other patch radii: one persistent kernel, no round trip.
 int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask, const int32_t *d_nsim,
-          const uint8_t *d_state, int W, int H, int w, int b, float min_eig, float *d_sum, int32_t *d_count)
+          const uint8_t *d_state, int W, int H, int w, int b, float min_eig, float *d_sum, int32_t *d_count, bool defer_redo = false)
 {
     const int64_t npix = (int64_t)W * H;
     const int K = 3 * (2 * w + 1) * (2 * w + 1);
+    wk.redo.pending = false;
     RCCHK(ensure(ctx, wk.strong, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.weak, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
@@ -468,7 +484,8 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
         HIPCHK(ctx, bcd_launch_bayes_weak_tiles(d_colors, d_mask, d_state, d_nsim, K + 1, W, H, b, d_sum, d_count, wk.aux));
         HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
     }
-    HIPCHK(ctx, hipMemsetAsync(d_c, 0, 8 * sizeof(int32_t), wk.stream));
+    if (wk.clean_dc) wk.clean_dc = false; // (k_scale_begin)
+    else HIPCHK(ctx, hipMemsetAsync(d_c, 0, 8 * sizeof(int32_t), wk.stream));
     HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)wk.strong.p, (int32_t *)wk.weak.p, d_c, wk.stream));
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream));
     const int64_t cap = std::max<int64_t>(1, npix);
@@ -495,9 +512,13 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
         RCCHK(ensure(ctx, wk.work_q, BCD_WORK_INTS * sizeof(int32_t)));
         for (int first = 0; first < n_strong; first += chunk_max) {
             const int n = std::min(chunk_max, n_strong - first);
-            HIPCHK(ctx, hipMemsetAsync(wk.work_q.p, 0, BCD_WORK_INTS * sizeof(int32_t), wk.stream)); // the work queues of the three kernels
+            if (wk.clean_wq) wk.clean_wq = false; // (k_scale_begin)
+            else HIPCHK(ctx, hipMemsetAsync(wk.work_q.p, 0, BCD_WORK_INTS * sizeof(int32_t), wk.stream)); // the work queues of the three kernels
+            // one chunk (the usual case) and a caller that looks at the redo counter after its last synchronisation: the redo kernel waits for that
+            const bool defer = defer_redo && n_strong <= chunk_max;
             HIPCHK(ctx, bcd_launch_bayes27(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, first, n, (int *)wk.work_q.p, cus, W, H, b, min_eig,
-                                           (float *)wk.gscratch.p, d_sum, d_count, d_c + 7, wk.stream));
+                                           (float *)wk.gscratch.p, d_sum, d_count, d_c + 7, wk.stream, defer ? 1 : 0));
+            if (defer) { wk.redo.pending = true; wk.redo.first = first; wk.redo.n = n; wk.redo.cus = cus; } // (the counter is h_counters[23], below)
         }
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 23, d_c + 7, sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream)); // read after the scale's last synchronisation
     } else {
@@ -550,10 +571,20 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     // own stream starts with the distance kernel, they run beside it instead of ahead of it / between marking and estimate
     HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream)); // (the inputs are ready at this point of the scale's stream)
     HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
-    HIPCHK(ctx, bcd_launch_pixel_cov(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, wk.aux));
-    HIPCHK(ctx, hipMemsetAsync(d_sum, 0, npix * 3 * sizeof(float), wk.aux));
-    HIPCHK(ctx, hipMemsetAsync(d_count, 0, npix * sizeof(int32_t), wk.aux));
+    HIPCHK(ctx, bcd_launch_pixel_cov_clear(d_cov, d_ns, (int64_t)npix, (float *)wk.pixcov.p, d_sum, d_count, wk.aux)); // (+ the accumulators cleared: one launch)
     HIPCHK(ctx, hipEventRecord(wk.ev_pixcov, wk.aux));
+    // every counter, flag and work queue of the chain in one launch at the head of the scale's stream (round 4: they were ~7 fills between
+    // the kernels of the critical path); flags raised by distance planes computed ahead of this call are kept
+    {
+        constexpr size_t LINE_INTS = (size_t)BCD_CNT_LINES * BCD_CNT_STRIDE;
+        RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+        RCCHK(ensure(ctx, wk.cnt_lines, ROUND_BATCH * LINE_INTS * sizeof(int)));
+        RCCHK(ensure(ctx, wk.work_q, BCD_WORK_INTS * sizeof(int32_t)));
+        const bool ahead = wk.planes.ready;
+        HIPCHK(ctx, bcd_launch_scale_begin((int *)wk.counters.p, 64, ahead ? 40 : -1, ahead ? 42 : -1, (int *)wk.cnt_lines.p, (int)(ROUND_BATCH * LINE_INTS),
+                                           (int *)wk.work_q.p, BCD_WORK_INTS, wk.stream));
+        wk.clean_flags = wk.clean_lines = wk.clean_dc = wk.clean_wq = true;
+    }
     for (int attempt = 0, mode = 2; attempt < 3; ++attempt) { // production kernels; if they complain: general formula, then exact kernels
         RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, mode));
         if (prof && attempt == 0) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
@@ -568,11 +599,22 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     progress_add(ctx, 0.5 * (double)npix); // similar patches selected, processed set known
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
     HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_pixcov, 0)); // covariances computed, accumulators cleared (long done)
+    wk.clean_flags = wk.clean_lines = false; // (consumed, or never used by this configuration)
     RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p,
-                (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count));
+                (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count, true));
+    wk.clean_dc = wk.clean_wq = false;
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[3], wk.stream));
     if (d_out) HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, (int64_t)npix, d_out, wk.stream));
     HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    if (wk.redo.pending && wk.h_counters[23] > 0) {
+        // items whose sweep inverse failed its checks (large -e, ill-conditioned frames): their list goes through the LDS kernel now
+        // (spectral inverse), and the finalisation is repeated on the completed accumulators
+        HIPCHK(ctx, bcd_launch_bayes27_redo(d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.strong.p, wk.redo.first, wk.redo.n,
+                                            (int *)wk.work_q.p, wk.redo.cus, W, H, b, prm->min_eigen_value, (float *)wk.gscratch.p, d_sum, d_count, wk.stream));
+        if (d_out) HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, (int64_t)npix, d_out, wk.stream));
+        HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    }
+    wk.redo.pending = false;
     progress_add(ctx, 0.5 * (double)npix);
     int64_t ns = 0, nw = 0, tot = 0;
     bayes_counts(wk, &ns, &nw, &tot);
@@ -1336,6 +1378,60 @@ int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, con
     (void)hipFree(C2);
     if (rc != BCD_HIP_OK) set_err(ctx, "distance kernel self-test failed to run");
     return rc;
+}
+
+// Measurement (bench.py `roofline.valu`): what the production distance kernel computes on this frame -- the (pixel pair, bin) terms it
+// evaluates (exactly the reference's count of bins with b1 + b2 > 1 over the half plane), the bins a wavefront issues because one of its 64
+// pairs needs them, the groups of four bins it enters -- from a counting instantiation of the kernel, and the duration of the PRODUCTION
+// instantiation on the same input (HIP events, best of `reps`).
+int bcd_hip_selftest_bin_work(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int search_radius, int reps,
+                              int64_t *lane_bins, int64_t *wave_bins, int64_t *wave_groups, float *kernel_ms)
+{
+    if (!ctx || !d_hist || !d_ns || !lane_bins || !wave_bins || !wave_groups || !kernel_ms || W <= 0 || H <= 0 || search_radius < 1 || reps < 1) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
+    if (!bcd_pairdist_rw_supported(D)) { set_err(ctx, "no approximate kernel for this histogram depth"); return BCD_HIP_EUNSUPPORTED; }
+    Work &wk = ctx->main;
+    const size_t npix = (size_t)W * H;
+    const int nd = bcd_delta_count(search_radius);
+    RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
+    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+    int *d_flag = (int *)wk.counters.p + 40;
+    unsigned long long *d_work = reinterpret_cast<unsigned long long *>((int32_t *)wk.counters.p + 48); // (8-byte aligned: words 48..53)
+    HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream));
+    HIPCHK(ctx, hipMemsetAsync(d_work, 0, 3 * sizeof(unsigned long long), wk.stream));
+    // the uniform kernel on the first pixel's count if every pixel carries it (the kernel checks), else the general formula -- like similarity()
+    float uni_n = -1.f;
+    HIPCHK(ctx, bcd_launch_pairdist_rw_counting(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, d_work, wk.stream));
+    int flags[4] = { 0, 0, 0, 0 };
+    HIPCHK(ctx, hipMemcpyAsync(flags, d_flag, sizeof(flags), hipMemcpyDeviceToHost, wk.stream));
+    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    if (flags[2] != 0) { // not one power-of-two count: count again with the general formula
+        uni_n = 0.f;
+        HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream));
+        HIPCHK(ctx, hipMemsetAsync(d_work, 0, 3 * sizeof(unsigned long long), wk.stream));
+        HIPCHK(ctx, bcd_launch_pairdist_rw_counting(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, d_work, wk.stream));
+    }
+    unsigned long long h[3] = { 0, 0, 0 };
+    HIPCHK(ctx, hipMemcpyAsync(h, d_work, sizeof(h), hipMemcpyDeviceToHost, wk.stream));
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_err(ctx, "hipEventCreate"); return BCD_HIP_EDEVICE; }
+    float best = -1.f;
+    int rc = BCD_HIP_OK;
+    for (int r = 0; r < reps + 1 && rc == BCD_HIP_OK; ++r) { // (the first one warms up)
+        if (hipEventRecord(e0, wk.stream) != hipSuccess ||
+            bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream) != hipSuccess ||
+            hipEventRecord(e1, wk.stream) != hipSuccess || hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && (best < 0.f || ms < best)) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != BCD_HIP_OK) { set_err(ctx, "bin-work self-test failed to run"); return rc; }
+    *lane_bins = (int64_t)h[0]; *wave_bins = (int64_t)h[1]; *wave_groups = (int64_t)h[2]; *kernel_ms = best;
+    return BCD_HIP_OK;
 }
 
 int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int search_radius,

@@ -21,10 +21,10 @@
 // operation runs, and HIP multiplexes the streams of a process onto a few hardware queues, so two ranks that enqueue the
 // operations of two communicators in opposite orders can block each other for good (each queue's head waits for a kernel stuck
 // behind the other queue's head).  The scales run on concurrent host threads, so their relative order is a matter of timing;
-// the gate makes it a rule instead: within a rank, scale s enqueues its first exchange only after every coarser scale has
-// enqueued its last one, and the merges' exchanges come after all of them.  Every rank then enqueues the same global sequence,
-// and operation k only ever waits for operations < k and for compute kernels.  The coarse scales finish early (a quarter of
-// the pixels each), so the finest scale reaches the gate about when they are done.
+// the gate makes it a rule instead: a phase-major sequence -- the marking operations of scale S-1, ..., of scale 0, then the
+// accumulator exchanges of scale S-1, ..., of scale 0, then the merges' exchanges (struct CommGate).  Every rank then enqueues the
+// same global sequence, and operation k only ever waits for operations < k and for compute kernels.  A scale waits for the coarser
+// scales' marking, never for their estimates, so the three chains of a band overlap as on a single GPU.
 #include "../../include/bcd_hip.h"
 #include "bcd_common.h"
 
@@ -126,23 +126,49 @@ struct HostBarrier {
     }
 };
 
-// ---- CommGate: scale s of a rank may start communicating once the scales s + 1 .. S - 1 of that rank are through -------------
+// ---- CommGate: the order in which the scale threads of a rank enqueue their communication operations -------------------------
+// Every rank must enqueue the same global sequence (header).  The sequence is PHASE-major (round 4): phase 1 = everything the marking
+// needs (|S| of the boundary lines, the states and the all-reduced count of every batch; a data-dependent number of operations, but
+// the same number on every rank -- the all-reduce decides it), phase 2 = the accumulator halos:
+//     P1(scale S-1) ... P1(scale 1)  P1(scale 0)   P2(scale S-1) ... P2(scale 0)   merges
+// so a scale waits for the COARSER scales' marking before its own, never for their estimates.  Until round 4 the sequence was
+// scale-major (scale s first talked when every coarser scale was through its whole chain): the tails of the three scales of a band ran
+// one after the other, 3.5 ms for a band whose kernels take 2.7 ms (profiles/r04_band_timeline_*.txt).  The coarse scales wait with their
+// accumulator exchange until the finest scale's marking is enqueued -- they have slack.
 struct CommGate {
     std::mutex m;
     std::condition_variable cv;
-    unsigned done = 0; // bit s: scale s has enqueued its last exchange of this frame
+    unsigned done1 = 0, done2 = 0; // bit s: scale s has enqueued its last operation of phase 1 / phase 2 of this frame
     std::atomic<bool> *abort_flag = nullptr;
-    void reset() { std::lock_guard<std::mutex> lk(m); done = 0; }
-    void finish(int s)
+    void reset() { std::lock_guard<std::mutex> lk(m); done1 = done2 = 0; }
+    void finish1(int s)
     {
-        { std::lock_guard<std::mutex> lk(m); done |= 1u << s; }
+        { std::lock_guard<std::mutex> lk(m); done1 |= 1u << s; }
         cv.notify_all();
     }
-    bool wait_coarser(int s, int S)
+    void finish2(int s)
     {
-        const unsigned need = ((1u << S) - 1u) & ~((2u << s) - 1u);
+        { std::lock_guard<std::mutex> lk(m); done2 |= 1u << s; }
+        cv.notify_all();
+    }
+    void finish(int s) // the scale leaves (normally or not): nobody waits for it any longer
+    {
+        { std::lock_guard<std::mutex> lk(m); done1 |= 1u << s; done2 |= 1u << s; }
+        cv.notify_all();
+    }
+    static unsigned coarser(int s, int S) { return ((1u << S) - 1u) & ~((2u << s) - 1u); }
+    bool wait1(int s, int S) // before the first phase-1 operation of scale s
+    {
+        const unsigned need = coarser(s, S);
         std::unique_lock<std::mutex> lk(m);
-        while ((done & need) != need && !abort_flag->load()) cv.wait_for(lk, std::chrono::milliseconds(50));
+        while ((done1 & need) != need && !abort_flag->load()) cv.wait_for(lk, std::chrono::milliseconds(50));
+        return !abort_flag->load();
+    }
+    bool wait2(int s, int S) // before the phase-2 operations of scale s
+    {
+        const unsigned all = (1u << S) - 1u, need = coarser(s, S);
+        std::unique_lock<std::mutex> lk(m);
+        while (((done1 & all) != all || (done2 & need) != need) && !abort_flag->load()) cv.wait_for(lk, std::chrono::milliseconds(50));
         return !abort_flag->load();
     }
 };
@@ -481,7 +507,8 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
         verdict_known = true;
     }
     const bool talk = g.world > 1 || m->loopback; // (loopback: one rank that exchanges with itself, see bcd_hip_multi::loopback)
-    if (m->ordered && talk && !m->gate[rank].wait_coarser(s, g.S)) return false;
+    const bool gated = m->ordered && talk;
+    if (gated && !m->gate[rank].wait1(s, g.S)) return false; // phase 1 of this scale: after the coarser scales' marking
     int rounds = 0;
     const long long REDO = 1ll << 40; // added to the all-reduced count of undecided pixels by a rank whose masks are not valid
     for (;;) { // the marking problem; once more from the start if some rank has to recompute its masks
@@ -522,6 +549,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
         if (!restart) break;
         if (my_redo) ECHK(m, rank, c, bcd_hip_similarity_masks_exact(c, hist, ns, W, rows, D, w, b, tau, mask, nsim));
     }
+    m->gate[rank].finish1(s); // the finer scales may mark; nothing of this scale is enqueued on a communicator until phase 2
     progress_add(m, 0.5 * (double)(r1 - r0) * W); // similar patches selected, processed set known
     // halo lines are processed by their owner
     if (r0 > 0) MCHK(m, rank, hipMemsetAsync(state, 0, (size_t)r0 * W, st));
@@ -532,10 +560,12 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
     // accumulator halos: the (b + w) lines written outside the owned band belong to the neighbours
     float *rx_us = (float *)B(bcd_hip_multi::RX_UP_S).p, *rx_ds = (float *)B(bcd_hip_multi::RX_DN_S).p;
     int32_t *rx_uc = (int32_t *)B(bcd_hip_multi::RX_UP_C).p, *rx_dc = (int32_t *)B(bcd_hip_multi::RX_DN_C).p;
+    if (gated && !m->gate[rank].wait2(s, g.S)) return false; // phase 2: after every scale's marking and the coarser scales' accumulators
     if (talk) {
         if (!exchange(m, rank, s, sum, rx_us, (size_t)halo * W * 12, sum + (size_t)(rows - halo) * W * 3, rx_ds, (size_t)halo * W * 12)) return false;
         if (!exchange(m, rank, s, cnt, rx_uc, (size_t)halo * W * 4, cnt + (size_t)(rows - halo) * W, rx_dc, (size_t)halo * W * 4)) return false;
     }
+    m->gate[rank].finish2(s);
     float *out = (float *)B(bcd_hip_multi::OUT).p;
     ECHK(m, rank, c, bcd_hip_finalize_band(c, sum + (size_t)r0 * W * 3, cnt + (size_t)r0 * W, W, r1 - r0, halo, up ? rx_us : nullptr, up ? rx_uc : nullptr,
                                            down ? rx_ds : nullptr, down ? rx_dc : nullptr, out + (size_t)o0 * W * 3));

@@ -1309,6 +1309,8 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
     if (PHASE == 2 && redo) nb_items = redo[0];
+    // (PHASE 1 opens the chunk: it clears the redo list's counter for the finish kernel two launches later -- this was a fill between the kernels)
+    if (PHASE == 1 && redo && blockIdx.x == 0 && lane == 0) const_cast<int *>(redo)[0] = 0;
     // PHASE 1: colour window | covariance window | noise | mean | members            (8.8 KB: 18 wavefronts per CU)
     // PHASE 2: Cm | A | V | Bm (matrix scratch, then the colour window) | cs | noise | mean | fl | members   (as the gather kernel)
     float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ;
@@ -1710,7 +1712,8 @@ hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blo
 // (bcd_bayes27_record_bytes() each), d_work BCD_WORK_INTS zeroed ints (the work queues of the three kernels).
 hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int first_item, int nb_items,
                               int *d_work, int num_cus, int W, int H, int b, float min_eig, float *records, float *sum,
-                              int32_t *cnt, int *d_spectral /* += items whose inverse took the spectral branch (windowed path) */, hipStream_t st)
+                              int32_t *cnt, int *d_spectral /* += items whose inverse took the spectral branch (windowed path) */, hipStream_t st,
+                              int defer_redo /* != 0: the caller reads *d_spectral after its next synchronisation and calls bcd_launch_bayes27_redo if it is > 0 */)
 {
     if (nb_items <= 0) return hipSuccess;
     Geom27 g;
@@ -1730,24 +1733,26 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         const size_t wl1 = (size_t)W1_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
         const size_t wl2 = (size_t)W2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
         const int w_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / wl1), w_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / wl2);
-        hipLaunchKernelGGL(k_bayes27w<1>, dim3(std::min(nb_items, num_cus * w_cu1)), dim3(64), wl1, st, colors, pixcov, mask, list, first_item, nb_items,
-                           d_work, g, min_eig, rec, sum, cnt, nullptr);
-        { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
         static const bool lds_algebra = [] { const char *e = getenv("BCD_HIP_FINISH_LDS"); return e && e[0] == '1'; }();
+        int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP); // (the register-resident finish; cleared by the prepare kernel)
+        hipLaunchKernelGGL(k_bayes27w<1>, dim3(std::min(nb_items, num_cus * w_cu1)), dim3(64), wl1, st, colors, pixcov, mask, list, first_item, nb_items,
+                           d_work, g, min_eig, rec, sum, cnt, lds_algebra ? nullptr : redo);
+        { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
         if (lds_algebra)
             hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * w_cu2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
                                d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, nullptr);
         else {
             // the register-resident finish; the items whose sweep inverse fails its checks (rare) come back on a list for the LDS kernel
-            int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP);
-            { hipError_t e = hipMemsetAsync(redo, 0, sizeof(int), st); if (e != hipSuccess) return e; }
             const size_t wl3 = (size_t)F2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
             hipLaunchKernelGGL(k_finish27w, dim3(std::min(nb_items, num_cus * 12)), dim3(64), wl3, st, colors, mask, list, first_item, nb_items,
                                d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo, d_spectral);
             // (normally an empty list: a small grid, so that its 17 KB workgroups do not queue for LDS behind the kernels of the other scales --
             // a full-size launch that only reads "0 items" was seen waiting 0.7 ms for room.  A long list is still processed, by fewer wavefronts.)
-            hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * 2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
-                               d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo);
+            // Round 4: a caller that looks at the counter anyway does not launch it at all on an empty list -- beside the persistent kernels of the other
+            // scales even the small launch sat 170-470 us on a coarse scale's stream waiting for LDS, with nothing to do.
+            if (!defer_redo)
+                hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * 2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
+                                   d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo);
         }
         return hipGetLastError();
     }
@@ -1756,6 +1761,26 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k_bayes27<2>, dim3(std::min(nb_items, num_cus * per_cu2)), dim3(64), lds2, st, colors, pixcov, mask, list, first_item, nb_items,
                        d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt);
+    return hipGetLastError();
+}
+
+// the deferred redo pass of bcd_launch_bayes27(..., defer_redo = 1): same arguments (the records still hold the chunk)
+hipError_t bcd_launch_bayes27_redo(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int first_item, int nb_items,
+                                   int *d_work, int num_cus, int W, int H, int b, float min_eig, float *records, float *sum, int32_t *cnt, hipStream_t st)
+{
+    if (nb_items <= 0 || b != WB) return hipSuccess;
+    Geom27 g;
+    g.W = W; g.H = H; g.b = b; g.side = 2 * b + 1; g.words = (g.side * g.side + 31) / 32; g.maxS = g.side * g.side;
+    Records27 rec;
+    rec.A = records;
+    rec.V = rec.A + (size_t)nb_items * MSZ;
+    rec.C = rec.V + (size_t)nb_items * MSZ;
+    rec.aux = rec.C + (size_t)nb_items * MSZ;
+    rec.eig = rec.aux + (size_t)nb_items * AUX27;
+    int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP);
+    const size_t wl2 = (size_t)W2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
+    hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * 2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
+                       d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo);
     return hipGetLastError();
 }
 

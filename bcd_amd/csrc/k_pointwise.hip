@@ -14,6 +14,30 @@ __global__ void k_pixel_cov(const float *__restrict__ cov, const float *__restri
     out[i] = cov[i] * inv;
 }
 
+// the same, and the accumulators of the scale cleared in the same pass (sum: 3 floats per pixel, count: 1 int): one launch on the scale's side
+// stream instead of the kernel and two fills (round 4)
+__global__ void k_pixel_cov_clear(const float *__restrict__ cov, const float *__restrict__ ns, int64_t npix, float *__restrict__ out,
+                                  float *__restrict__ sum, int32_t *__restrict__ cnt)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 6) return;
+    float inv = 1.f / ns[i / 6];
+    out[i] = cov[i] * inv;
+    if (i < npix * 3) sum[i] = 0.f;
+    else if (i < npix * 4) cnt[i - npix * 3] = 0;
+}
+
+// every counter, flag and work queue a scale's chain starts from, in one launch (round 4; before: one fill per buffer, on the critical stream):
+// a: the 64 control words (keep0 / keep1: words that belong to launches already made -- the flags of distance planes computed ahead),
+// b: the sub-counter lines of the marking launches, c: the work queues of the estimate kernels
+__global__ void k_scale_begin(int *__restrict__ a, int na, int keep0, int keep1, int *__restrict__ b, int nb, int *__restrict__ c, int nc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) { if (i != keep0 && i != keep1) a[i] = 0; }
+    else if (i < na + nb) b[i - na] = 0;
+    else if (i < na + nb + nc) c[i - na - nb] = 0;
+}
+
 // Denoiser::finalAggregation tail (src/core/Denoiser.cpp:458-469): (1.f / count) * sum
 __global__ void k_finalize(const float *__restrict__ sum, const int32_t *__restrict__ cnt, int64_t npix, float *__restrict__ out)
 {
@@ -231,6 +255,16 @@ inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); 
 hipError_t bcd_launch_pixel_cov(const float *cov, const float *ns, int64_t npix, float *out, hipStream_t st)
 {
     hipLaunchKernelGGL(k_pixel_cov, dim3(nblk(npix * 6, 256)), dim3(256), 0, st, cov, ns, npix, out);
+    return hipGetLastError();
+}
+hipError_t bcd_launch_pixel_cov_clear(const float *cov, const float *ns, int64_t npix, float *out, float *sum, int32_t *cnt, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pixel_cov_clear, dim3(nblk(npix * 6, 256)), dim3(256), 0, st, cov, ns, npix, out, sum, cnt);
+    return hipGetLastError();
+}
+hipError_t bcd_launch_scale_begin(int *a, int na, int keep0, int keep1, int *b, int nb, int *c, int nc, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_scale_begin, dim3(nblk((int64_t)na + nb + nc, 256)), dim3(256), 0, st, a, na, keep0, keep1, b, nb, c, nc);
     return hipGetLastError();
 }
 hipError_t bcd_launch_finalize(const float *sum, const int32_t *cnt, int64_t npix, float *out, hipStream_t st)

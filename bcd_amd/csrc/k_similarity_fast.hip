@@ -72,10 +72,14 @@ template <int D> struct RwLayout {
     static constexpr int NPRE = (RW_NCOLS * (D / 4) + RW_THREADS - 1) / RW_THREADS; // float4 per thread of one prefetched line
 };
 
-template <int D, bool UNI>
+// COUNT (measurement only, bcd_hip_selftest_bin_work): the same kernel also counts the bins it evaluates -- per lane (b1 + b2 > 1: the
+// reference's own count, DenoisingUnit.cpp:379-381) and per wavefront instruction stream (a bin is issued when ANY of the 64 pairs needs it)
+// -- into work_count[0..1]; the production instantiation carries no trace of it.
+template <int D, bool UNI, bool COUNT = false>
 __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H,
                                                               int b, __half *__restrict__ T, uint8_t *__restrict__ Cn, int *range_flag,
-                                                              float uni_n, int tile_row0 /* first tile row of this launch */)
+                                                              float uni_n, int tile_row0 /* first tile row of this launch */,
+                                                              unsigned long long *work_count = nullptr)
 {
     using L = RwLayout<D>;
     constexpr int Q = D / 4, NPRE = L::NPRE;
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
     float *ring_n = ring + 4 * L::ROW;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (wave-uniform: loop control on the scalar unit)
+    unsigned int cnt_lane_bins = 0, cnt_wave_bins = 0, cnt_wave_groups = 0; // (COUNT only; wave-uniform)
     const int ty = wave & 3, hv = wave >> 2; // the two halves of a tile line land on the same SIMD
     int tile;
     {
@@ -248,8 +253,14 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                     float sg[4];
                     uint64_t live = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { sg[e] = h1[4 * q + e] + b2[e]; live |= __builtin_amdgcn_ballot_w64(sg[e] > 1.f); }
+                    for (int e = 0; e < 4; ++e) {
+                        sg[e] = h1[4 * q + e] + b2[e];
+                        const uint64_t lm = __builtin_amdgcn_ballot_w64(sg[e] > 1.f);
+                        live |= lm;
+                        if (COUNT) { cnt_lane_bins += (unsigned int)__builtin_popcountll(lm); cnt_wave_bins += lm != 0 ? 1u : 0u; } // (wave-uniform: outside the divergent bodies)
+                    }
                     if (live != 0) {
+                        if (COUNT) ++cnt_wave_groups;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (sg[e] > 1.f) {
@@ -280,6 +291,11 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                 __syncthreads();
             }
         }
+    }
+    if (COUNT && lane == 0 && work_count) {
+        atomicAdd(work_count, (unsigned long long)cnt_lane_bins);
+        atomicAdd(work_count + 1, (unsigned long long)cnt_wave_bins);
+        atomicAdd(work_count + 2, (unsigned long long)cnt_wave_groups);
     }
 }
 
@@ -386,8 +402,8 @@ int bcd_pairdist_rw_supported(int D) { return D == 60 || D == 36 || D == 24; }
 // whose lines have arrived.
 int bcd_pairdist_rw_tile_lines() { return RW_TH; }
 
-hipError_t bcd_launch_pairdist_rw_rows(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,
-                                       float uni_n, int tile_row_begin, int tile_row_end, hipStream_t st)
+static hipError_t pairdist_rw_rows(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,
+                                   float uni_n, int tile_row_begin, int tile_row_end, hipStream_t st, unsigned long long *work_count)
 {
     const int tile_rows = (H + RW_TH - 1) / RW_TH;
     if (tile_row_end < 0 || tile_row_end > tile_rows) tile_row_end = tile_rows;
@@ -407,7 +423,13 @@ hipError_t bcd_launch_pairdist_rw_rows(const float *hist, const float *ns, int W
             if (e != hipSuccess) return e;                                                                           \
             if (dev >= 0 && dev < 64) granted[dev].store(1);                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, static_cast<__half *>(T), Cn, d_range_flag, uni_n, tile_row_begin); \
+        if (work_count) { /* the counting instantiation (measurement only) */                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist_rw<DD, UU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                           \
+            hipLaunchKernelGGL((k_pairdist_rw<DD, UU, true>), grid, block, lds, st, hist, ns, W, H, b, static_cast<__half *>(T), Cn, d_range_flag, uni_n, tile_row_begin, work_count); \
+            return hipGetLastError();                                                                                \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_pairdist_rw<DD, UU>), grid, block, lds, st, hist, ns, W, H, b, static_cast<__half *>(T), Cn, d_range_flag, uni_n, tile_row_begin, (unsigned long long *)nullptr); \
         return hipGetLastError();                                                                                    \
     }
 #define BCD_RW_DEPTH(DD) case DD: if (uni_n != 0.f) BCD_RW_LAUNCH(DD, true) else BCD_RW_LAUNCH(DD, false)
@@ -420,6 +442,19 @@ hipError_t bcd_launch_pairdist_rw_rows(const float *hist, const float *ns, int W
 #undef BCD_RW_DEPTH
 #undef BCD_RW_LAUNCH
     return hipErrorInvalidValue;
+}
+
+hipError_t bcd_launch_pairdist_rw_rows(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,
+                                       float uni_n, int tile_row_begin, int tile_row_end, hipStream_t st)
+{
+    return pairdist_rw_rows(hist, ns, W, H, D, b, T, Cn, d_range_flag, uni_n, tile_row_begin, tile_row_end, st, nullptr);
+}
+
+// measurement: the whole frame with the counting instantiation; work_count[0] += evaluated (pair, bin) terms, [1] += bins issued by a wavefront, [2] += groups of four entered
+hipError_t bcd_launch_pairdist_rw_counting(const float *hist, const float *ns, int W, int H, int D, int b, void *T, uint8_t *Cn, int *d_range_flag, float uni_n,
+                                           unsigned long long *work_count, hipStream_t st)
+{
+    return pairdist_rw_rows(hist, ns, W, H, D, b, T, Cn, d_range_flag, uni_n, 0, -1, st, work_count);
 }
 
 hipError_t bcd_launch_pairdist_rw(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,

@@ -47,7 +47,7 @@ SYMBOLS = [
     "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_similarity_masks_deferred", "bcd_hip_similarity_masks_verdict", "bcd_hip_similarity_masks_exact", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
-    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_strip_order_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels", "bcd_hip_selftest_approx_distance", "bcd_hip_eig27_batch",
+    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_strip_order_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels", "bcd_hip_selftest_approx_distance", "bcd_hip_selftest_bin_work", "bcd_hip_eig27_batch",
 ]
 
 _lib = None
@@ -322,6 +322,14 @@ class Context:
         r, n, f = C.c_float(0), C.c_int64(0), C.c_int(0)
         self._chk(lib().bcd_hip_selftest_approx_distance(self.h, _dp(hist), _dp(ns), W, H, D, b, C.byref(r), C.byref(n), C.byref(f)))
         return r.value, n.value, f.value
+
+    def selftest_bin_work(self, hist, ns, b, reps=3):
+        """-> (lane_bins, wave_bins, wave_groups, production kernel ms): the arithmetic of the distance kernel on this frame (counting instantiation)"""
+        H, W, D = hist.shape
+        a, b_, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        ms = C.c_float(0)
+        self._chk(lib().bcd_hip_selftest_bin_work(self.h, _dp(hist), _dp(ns), W, H, D, int(b), int(reps), C.byref(a), C.byref(b_), C.byref(c), C.byref(ms)))
+        return a.value, b_.value, c.value, ms.value
 
     def eig27_batch(self, A):
         """A: (n, 28, 28) symmetric device tensor (row / column 27 zero) -> (eigenvalues (n, 28), eigenvectors (n, 28, 28), kernel ms)"""

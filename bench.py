@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--band-path", action="store_true", help="use the multi-GPU row-band code path even with one rank (debug)")
     ap.add_argument("--check-size", default="640x576", help="N > 1: frame size of the equality check against a single-GPU run on rank 0")
     ap.add_argument("--watchdog", type=int, default=900, help="N > 1: seconds after which a run that has not reached its JSON line dumps every thread's stack and exits (a blocked collective would otherwise hang the launcher)")
+    ap.add_argument("--no-predict", action="store_true", help="skip the `predicted_8gpu` leg (one rank's band of the 4K frame through the band driver with RCCL in loopback, in a child process)")
+    ap.add_argument("--predict-band-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample", default=None, help="frame size of the CPU-baseline sample on all host cores (default: the headline frame itself on hosts with >= 64 cores, 960x540 below)")
     ap.add_argument("--cpu-sample-1core", default="320x240", help="frame size of the one-core CPU-baseline sample")
     return ap.parse_args()
@@ -110,8 +112,84 @@ def per_scale_stats(ctx, S):
     return scales
 
 
+def source_hash(rel):
+    """first 16 hex digits of the sha256 of a source file: profiles taken offline carry the hash of the kernel source they were taken on"""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+PAIRDIST_SOURCE = "bcd_amd/csrc/k_similarity_fast.hip"
+VALU_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (vector), spec
+
+
+def predict_band_child(args):
+    """One rank's share of the 4K frame on this one GPU, through the band driver: world = 8 cuts 3840x2160 (S = 3, boundaries aligned to 4 lines)
+    into bands of 268 / 272 owned lines; rank 3 owns lines [808, 1080) and computes, per scale, its band plus 7 halo lines on either side.  The
+    stand-in is the frame made of lines [800, 1088) of the 4K frame (288 / 144 / 72 lines per scale against 286 / 150 / 82 in the band), run as rank 0
+    of 1 in LOOPBACK: every exchange and all-reduce of the band protocol is enqueued on real RCCL communicators with the band's message sizes
+    (the rank is its own neighbour; what it receives is discarded).  Waiting for real neighbours is NOT in it."""
+    import torch
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    S, b = args.scales, args.search_radius
+    w4, h4, l0, nl = 3840, 2160, 800, 288
+    prm = bh.default_params(b=b, w=1, m=args.skip_prob, random_order=args.random_order, seed=1234)
+    rd = bh.RankDenoiser(0, 1, 0, bh.multi_unique_ids(S + 1))
+    rd.set_loopback(True)
+    rd.configure(w4, nl, 60, S, prm)
+    rd.upload(*core.synthetic_scene(w4, h4, args.spp, 1234, args.sigma, args.spikes, l0, nl))
+    rd.step()
+    rd.step()
+    rd.set_comm_trace(True)
+    rd.step()
+    trace = rd.comm_trace()
+    rd.set_comm_trace(False)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rd.step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / reps
+    rd.close()
+    res = {"band_ms": round(ms, 4), "steps": reps,
+           "exchanges_per_frame": sum(1 for _, k, _, _ in trace if k == 0),
+           "marking_allreduces_per_frame": sum(1 for _, k, _, _ in trace if k == 1),
+           "bytes_per_neighbour": int(sum(up for _, k, up, _ in trace if k == 0)),
+           "largest_message_bytes": int(max([up for _, k, up, _ in trace if k == 0] or [0]))}
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print("PREDICT " + json.dumps(res), flush=True)
+
+
+def predicted_8gpu(args, frame_ms):
+    """runs predict_band_child in a child process with a time limit (a communication kernel that never returns must not cost the bench line)"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--predict-band-child", "--scales", str(args.scales), "--search-radius", str(args.search_radius),
+           "--spp", str(args.spp), "--sigma", str(args.sigma), "--spikes", str(args.spikes), "--skip-prob", str(args.skip_prob), "--random-order", str(args.random_order)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("PREDICT ")]
+        if r.returncode != 0 or not line:
+            return {"error": "child failed (rc %d): %s" % (r.returncode, (r.stdout + r.stderr)[-400:])}
+        res = json.loads(line[-1][len("PREDICT "):])
+    except subprocess.TimeoutExpired:
+        return {"error": "child did not finish within 240 s"}
+    res["frame_ms"] = None if frame_ms is None else round(frame_ms, 4)
+    res["speedup_before_waiting"] = None if frame_ms is None else round(frame_ms / res["band_ms"], 2)
+    res["workload"] = ("one of 8 row bands of the 3840x2160 frame (BASELINE configs[3]): lines [800, 1088) as a frame of its own through the band driver as rank 0 of 1 in "
+                       "loopback -- every exchange / all-reduce of the band protocol on real RCCL communicators with the band's message sizes, the rank being its own "
+                       "neighbour; frame_ms = the whole frame on this GPU (frame_4k).  A PREDICTION from one GPU: waiting for real neighbours and xGMI transfers are not in it")
+    return res
+
+
 def main():
     args = parse()
+    if args.predict_band_child:
+        return predict_band_child(args)
     import torch
     import bcd_amd.core as core
     import bcd_amd.hip as bh
@@ -259,6 +337,28 @@ def main():
     # the three scales run concurrently on separate streams, so a launch's event-to-event time includes the kernels it
     # overlaps with; the same kernel timed in isolation (scales one after the other, three extra untimed steps):
     iso_ms = None
+    frame4k_ms = None
+    valu = None
+    if single and not args.no_extras:
+        # ---- the arithmetic of the distance kernel on the headline frame's finest scale (the bound that binds: SURVEY 8(d) "honest second bound")
+        try:
+            lane_bins, wave_bins, wave_groups, k_ms = ctx.selftest_bin_work(d_in[2], d_in[1], b, 3)
+            nd = (b + 1) + b * (2 * b + 1)
+            slots = W * H * nd * 60
+            flop = 2 * slots + 6 * lane_bins
+            valu = {"scale": 0, "bin_slots": slots, "evaluated_bins": lane_bins, "evaluated_frac": round(lane_bins / slots, 4),
+                    "wave_issued_bins_x64": wave_bins * 64, "wave_issued_frac": round(wave_bins * 64 / slots, 4), "wave_groups_entered": wave_groups,
+                    "flop": flop, "kernel_ms": round(k_ms, 4), "achieved_tflops": round(flop / (k_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(flop / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
+                    "issued_tflops": round((2 * slots + 6 * 64 * wave_bins) / (k_ms * 1e-3) / 1e12, 3),
+                    "flop_model": "per (pixel pair, bin) slot of the 85 half-plane displacements: the skip test b1 + b2 > 1 = 2 (add, compare); per EVALUATED term "
+                                  "(DenoisingUnit.cpp:379-383): subtract, square, reciprocal, fused multiply-add, count = 6.  evaluated_bins is counted on the device by a "
+                                  "counting instantiation of the kernel (bcd_hip_selftest_bin_work), kernel_ms is the production instantiation on the same input, alone on the chip. "
+                                  "issued_tflops prices every lane of a wavefront that issues a bin (a bin is issued when any of its 64 pairs needs it). "
+                                  "The 157.3 TFLOP/s peak counts packed fp32 at full rate; v_pk_fma_f32 was measured at half rate on this chip (tools/ubench/pk_rate.hip), "
+                                  "so a kernel of plain fp32 instructions tops out at half the peak"}
+        except Exception as e:   # (reported, never fatal for the headline)
+            valu = {"error": "%s: %s" % (type(e).__name__, e)}
     if single and not args.no_extras:
         ctx.set_concurrent_scales(False)
         step()
@@ -327,6 +427,7 @@ def main():
                 ctx.denoise(*d4, S, prm, out4)
             torch.cuda.synchronize()
             ms4 = (time.perf_counter() - t1) * 1e3 / 3
+            frame4k_ms = ms4
             extras["frame_4k"] = {"value": round(w4 * h4 / 1e6 / (ms4 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms4, 4), "steps": 3,
                                   "workload": "3840x2160 frame of the same generator and flags (BASELINE configs[3]), inputs resident"}
             # BASELINE configs[4] on this one GPU: large search window, spike prefilter (a step of its own, on the resident copies:
@@ -357,14 +458,22 @@ def main():
                 "isolated_avg_launch_ms": None if iso_ms is None else round(iso_ms, 4),
                 "isolated_frac": None if not iso_ms else round((algo_bytes_per_step / S) / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "note": "VALU-bound kernel (85 displacements x 60 bins of chi-square per pixel); the 3 scales run concurrently on separate streams, so launch durations in the timed region include overlap -- isolated_* = the same kernel with the scales serialised; see DESIGN.md"}
+    roofline["valu"] = valu
+    # numbers taken offline (rocprofv3 --pmc passes) are only quoted while the kernel source they were taken on is the one that runs
+    src_hash = source_hash(PAIRDIST_SOURCE)
+    roofline["kernel_source_sha256_16"] = src_hash
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
             key = "%dx%d_s%d" % (W, H, S)
             if key in tr:
-                roofline["traffic"] = tr[key]["hbm_bytes_per_launch_avg"]
-                roofline["traffic_source"] = "profiled offline: tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload), profiles/pmc_traffic.json"
+                taken_on = tr[key].get("kernel_source_sha256_16")
+                if taken_on == src_hash:
+                    roofline["traffic"] = tr[key]["hbm_bytes_per_launch_avg"]
+                    roofline["traffic_source"] = "profiled offline: tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload), profiles/pmc_traffic.json"
+                else:
+                    roofline["traffic_source"] = "null: profiles/pmc_traffic.json was taken on kernel source %s, this run is %s -- rerun tools/pmc_traffic.sh" % (taken_on, src_hash)
         except Exception:
             pass
 
@@ -375,7 +484,11 @@ def main():
         tabs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.txt")))
         txt = open(tabs[-1]).read()
         m = re.search(r"k_pairdist_rw.*?VALU pipe busy ([0-9.]+) %", txt, re.S)
-        if m:
+        mh = re.search(r"k_similarity_fast\.hip sha256_16=([0-9a-f]+)", txt)
+        if m and (not mh or mh.group(1) != src_hash):
+            roofline["vector_pipe_busy_profiled"] = {"frac": None, "source": "null: %s was taken on kernel source %s, this run is %s -- rerun tools/refresh_profiles.sh" %
+                                                     ("profiles/" + os.path.basename(tabs[-1]), mh.group(1) if mh else "unknown", src_hash)}
+        elif m:
             roofline["vector_pipe_busy_profiled"] = {"frac": round(float(m.group(1)) / 100.0, 3), "source": "profiles/" + os.path.basename(tabs[-1]) +
                                                      " (SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES) per shader engine, 1280x720 scale 0 alone)"}
     except Exception:
@@ -399,6 +512,8 @@ def main():
             res["roofline"].pop("whole_process", None)
             if band_check is not None:
                 res["band_check"] = band_check
+        if single and not (args.no_extras or args.no_predict):
+            res["predicted_8gpu"] = predicted_8gpu(args, frame4k_ms)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
         # native libraries (RCCL's version banner) write to the C stdio buffer: flush it first so that the JSON line is the last line

@@ -291,6 +291,13 @@ int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, 
 int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius,
                                       int *variant, int64_t *mismatches);
 
+/* Measurement (bench.py `roofline.valu`): the arithmetic the production distance kernel performs on this frame, from a counting instantiation
+ * of the same kernel -- lane_bins: (pixel pair, bin) terms evaluated = the reference's own count of bins with b1 + b2 > 1 over the half-plane
+ * displacements (src/core/DenoisingUnit.cpp:379-381); wave_bins: bins a wavefront issues because at least one of its 64 pairs needs them;
+ * wave_groups: groups of four bins entered -- and kernel_ms: the production instantiation on the same input (HIP events, best of reps). */
+int bcd_hip_selftest_bin_work(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius, int reps,
+                              int64_t *lane_bins, int64_t *wave_bins, int64_t *wave_groups, float *kernel_ms);
+
 /* self-test of the approximate pair-distance kernel (k_pairdist_rw) on given inputs: *max_rel_dev = largest relative deviation of a
  * patch distance d(p, p + delta) computed from the approximate planes from the one computed from the exact planes, over all pairs of
  * main pixels (bound 5e-4, measured 2.4e-4; must stay below 2^-10 = 9.8e-4, BCD_APPROX_DELTA, the half-width of the band that is

@@ -2,6 +2,7 @@
 """Copies what tools/refresh_profiles.sh left under gpurun_out/ into profiles/<round>_* (the tracked evidence) and assembles the SQ counter table.
 usage: python tools/collect_profiles.py r03"""
 import glob
+import hashlib
 import os
 import re
 import shutil
@@ -28,7 +29,9 @@ for f in sorted(glob.glob(os.path.join(G, "pmc_final_*_s?.txt"))):
         name = re.sub(r"\(.*", "", m.group(1))
         name = re.sub(r"void |\(anonymous namespace\)::", "", name).strip()
         rows.setdefault(name, {})[m.group(2)] = (int(m.group(3)), float(m.group(4)))
-out = ["# SQ counters of the kernels that ship (rocprofv3 --pmc, three passes with --kernel-trace only; tools/refresh_profiles.sh + tools/collect_profiles.py)",
+SRC_HASH = hashlib.sha256(open(os.path.join(R, "bcd_amd", "csrc", "k_similarity_fast.hip"), "rb").read()).hexdigest()[:16]
+out = ["# k_similarity_fast.hip sha256_16=%s (bench.py quotes the pair-distance kernel's figures only while this is the source that runs)" % SRC_HASH,
+       "# SQ counters of the kernels that ship (rocprofv3 --pmc, three passes with --kernel-trace only; tools/refresh_profiles.sh + tools/collect_profiles.py)",
        "# pairdist: tools/exp_similarity.py --quick (1280x720 scale 0, noisy + clean frame); jacobi: tools/exp_eig.py 32768;",
        "# estimate kernels: bench.py --no-extras with BCD_HIP_SERIAL_SCALES=1 (1080p, 3 scales).  avg per dispatch and SE instance (n = dispatches x 32).", ""]
 for name in sorted(rows):

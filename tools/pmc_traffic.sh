@@ -9,8 +9,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_$C -o t -- python $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 "$@" > $R/gpurun_out/pmc_$C.log 2>&1
 done
 python - $R "$@" <<'PY'
-import sqlite3, sys, json, glob, os
+import sqlite3, sys, json, glob, os, hashlib
 R = sys.argv[1]
+SRC_HASH = hashlib.sha256(open(os.path.join(R, "bcd_amd", "csrc", "k_similarity_fast.hip"), "rb").read()).hexdigest()[:16]
 W, H = 1920, 1080
 for i, a in enumerate(sys.argv):
     if a == "--width": W = int(sys.argv[i + 1])
@@ -34,7 +35,7 @@ write_kb = res["WRITE_SIZE"]["sum_kb"] / res["WRITE_SIZE"]["dispatches"]
 path = os.path.join(R, "gpurun_out", "pmc_traffic.json")
 out = json.load(open(path)) if os.path.exists(path) else {}
 out["%dx%d_s3" % (W, H)] = {"kernel": "k_pairdist_rw<60>", "fetch_size_kb_per_launch_raw": fetch_kb, "write_size_kb_per_launch_raw": write_kb,
-                       "hbm_bytes_per_launch_avg": int((2 * fetch_kb + write_kb) * 1024),
+                       "hbm_bytes_per_launch_avg": int((2 * fetch_kb + write_kb) * 1024), "kernel_source_sha256_16": SRC_HASH,
                        "note": "avg over the 3 scale launches of a 3-scale step; read side = 2 x FETCH_SIZE (gfx950 correction), write side WRITE_SIZE as reported"}
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out))
