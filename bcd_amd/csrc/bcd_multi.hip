@@ -369,17 +369,29 @@ void trace_op(bcd_hip_multi *m, int rank, int ch, int kind, size_t bytes_up, siz
     for (int64_t v : { (int64_t)ch, (int64_t)kind, (int64_t)bytes_up, (int64_t)bytes_down }) m->trace[rank].push_back(v);
 }
 
-bool exchange(bcd_hip_multi *m, int rank, int ch, const void *send_up, void *recv_up, size_t bytes_up, const void *send_down, void *recv_down,
-              size_t bytes_down)
+// one piece of a neighbour exchange: `bytes_up` to / from the rank above, `bytes_down` to / from the rank below (null receive pointers at the borders)
+struct Seg { const void *send_up; void *recv_up; size_t bytes_up; const void *send_down; void *recv_down; size_t bytes_down; };
+
+// several pieces in ONE operation (one RCCL group = one communication kernel; round 4: the two accumulator planes of a scale and the output
+// lines of all scales used to be an operation each)
+bool exchange_n(bcd_hip_multi *m, int rank, int ch, Seg *segs, int n)
 {
     hipStream_t st = m->stream[rank][ch];
     const bool lb = m->loopback;
     const bool up = rank > 0 || lb, down = rank < m->n - 1 || lb;
     const int peer_up = lb ? rank : rank - 1, peer_down = lb ? rank : rank + 1;
-    trace_op(m, rank, ch, 0, up ? bytes_up : 0, down ? bytes_down : 0);
+    size_t tot_up = 0, tot_down = 0;
+    for (int i = 0; i < n; ++i) { tot_up += segs[i].bytes_up; tot_down += segs[i].bytes_down; }
+    trace_op(m, rank, ch, 0, up ? tot_up : 0, down ? tot_down : 0);
     if (lb) { // the rank is its own neighbour: what it "receives" is its own data and goes to scratch unless the caller (the self-test) wants it
-        if (!recv_up) { if (!m->loop_rx[ch][0].ensure(bytes_up)) { fail(m, "out of device memory"); return false; } recv_up = m->loop_rx[ch][0].p; }
-        if (!recv_down) { if (!m->loop_rx[ch][1].ensure(bytes_down)) { fail(m, "out of device memory"); return false; } recv_down = m->loop_rx[ch][1].p; }
+        if (!m->loop_rx[ch][0].ensure(tot_up + 256 * (size_t)n) || !m->loop_rx[ch][1].ensure(tot_down + 256 * (size_t)n)) { fail(m, "out of device memory"); return false; }
+        size_t ou = 0, od = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!segs[i].recv_up) segs[i].recv_up = (char *)m->loop_rx[ch][0].p + ou;
+            if (!segs[i].recv_down) segs[i].recv_down = (char *)m->loop_rx[ch][1].p + od;
+            ou += (segs[i].bytes_up + 255) & ~(size_t)255;
+            od += (segs[i].bytes_down + 255) & ~(size_t)255;
+        }
     }
     if (m->use_rccl) {
         ncclResult_t r = ncclSuccess, e = ncclSuccess;
@@ -387,9 +399,12 @@ bool exchange(bcd_hip_multi *m, int rank, int ch, const void *send_up, void *rec
             std::shared_lock<std::shared_mutex> enq(m->comm_rw); // (an abort waits for this section to end before it frees the communicator)
             if (!m->comm_ready[ch] || m->abort_flag.load()) return false; // aborted meanwhile: fail() has recorded why
             r = ncclGroupStart();
-            // operations to the same peer are matched in issue order: in loopback the first send pairs with the first receive
-            if (r == ncclSuccess && up) { r = ncclSend(send_up, bytes_up, ncclChar, peer_up, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(recv_up, bytes_up, ncclChar, peer_up, m->comm[ch][rank], st); }
-            if (r == ncclSuccess && down) { r = ncclSend(send_down, bytes_down, ncclChar, peer_down, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(recv_down, bytes_down, ncclChar, peer_down, m->comm[ch][rank], st); }
+            // operations to the same peer are matched in issue order (both sides issue the pieces in the same order; in loopback the k-th send pairs with the k-th receive)
+            for (int i = 0; i < n && r == ncclSuccess; ++i) {
+                const Seg &g = segs[i];
+                if (up) { r = ncclSend(g.send_up, g.bytes_up, ncclChar, peer_up, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(g.recv_up, g.bytes_up, ncclChar, peer_up, m->comm[ch][rank], st); }
+                if (r == ncclSuccess && down) { r = ncclSend(g.send_down, g.bytes_down, ncclChar, peer_down, m->comm[ch][rank], st); if (r == ncclSuccess) r = ncclRecv(g.recv_down, g.bytes_down, ncclChar, peer_down, m->comm[ch][rank], st); }
+            }
             e = ncclGroupEnd();
         }
         if (r != ncclSuccess || e != ncclSuccess) { fail(m, std::string("RCCL exchange failed: ") + ncclGetErrorString(r != ncclSuccess ? r : e)); return false; }
@@ -397,13 +412,23 @@ bool exchange(bcd_hip_multi *m, int rank, int ch, const void *send_up, void *rec
     }
     // in-process transport: publish, rendezvous, copy from the neighbours' buffers, rendezvous (buffers may be reused afterwards)
     MCHK(m, rank, hipStreamSynchronize(st));
-    m->offer[ch][rank].up = send_up;
-    m->offer[ch][rank].down = send_down;
-    if (!m->barrier[ch].wait()) return false;
-    if (up) MCHK(m, rank, hipMemcpyAsync(recv_up, m->offer[ch][rank - 1].down, bytes_up, hipMemcpyDefault, st));
-    if (down) MCHK(m, rank, hipMemcpyAsync(recv_down, m->offer[ch][rank + 1].up, bytes_down, hipMemcpyDefault, st));
-    MCHK(m, rank, hipStreamSynchronize(st));
-    return m->barrier[ch].wait();
+    for (int i = 0; i < n; ++i) {
+        m->offer[ch][rank].up = segs[i].send_up;
+        m->offer[ch][rank].down = segs[i].send_down;
+        if (!m->barrier[ch].wait()) return false;
+        if (up) MCHK(m, rank, hipMemcpyAsync(segs[i].recv_up, m->offer[ch][rank - 1].down, segs[i].bytes_up, hipMemcpyDefault, st));
+        if (down) MCHK(m, rank, hipMemcpyAsync(segs[i].recv_down, m->offer[ch][rank + 1].up, segs[i].bytes_down, hipMemcpyDefault, st));
+        MCHK(m, rank, hipStreamSynchronize(st));
+        if (!m->barrier[ch].wait()) return false;
+    }
+    return true;
+}
+
+bool exchange(bcd_hip_multi *m, int rank, int ch, const void *send_up, void *recv_up, size_t bytes_up, const void *send_down, void *recv_down,
+              size_t bytes_down)
+{
+    Seg g{ send_up, recv_up, bytes_up, send_down, recv_down, bytes_down };
+    return exchange_n(m, rank, ch, &g, 1);
 }
 
 // sum of one integer over all ranks (channel ch); every rank gets the total
@@ -562,8 +587,9 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
     int32_t *rx_uc = (int32_t *)B(bcd_hip_multi::RX_UP_C).p, *rx_dc = (int32_t *)B(bcd_hip_multi::RX_DN_C).p;
     if (gated && !m->gate[rank].wait2(s, g.S)) return false; // phase 2: after every scale's marking and the coarser scales' accumulators
     if (talk) {
-        if (!exchange(m, rank, s, sum, rx_us, (size_t)halo * W * 12, sum + (size_t)(rows - halo) * W * 3, rx_ds, (size_t)halo * W * 12)) return false;
-        if (!exchange(m, rank, s, cnt, rx_uc, (size_t)halo * W * 4, cnt + (size_t)(rows - halo) * W, rx_dc, (size_t)halo * W * 4)) return false;
+        Seg acc[2] = { { sum, rx_us, (size_t)halo * W * 12, sum + (size_t)(rows - halo) * W * 3, rx_ds, (size_t)halo * W * 12 },
+                       { cnt, rx_uc, (size_t)halo * W * 4, cnt + (size_t)(rows - halo) * W, rx_dc, (size_t)halo * W * 4 } };
+        if (!exchange_n(m, rank, s, acc, 2)) return false; // sums and counts in one operation
     }
     m->gate[rank].finish2(s);
     float *out = (float *)B(bcd_hip_multi::OUT).p;
@@ -644,11 +670,13 @@ bool rank_compute(const Job &job, int rank)
     auto out_rows = [&](int s, int local_line) { return (float *)B(s, bcd_hip_multi::OUT).p + (size_t)local_line * bands[s].W * 3; };
     const bool talk = g.world > 1 || m->loopback;
     if (S > 1 && talk) {
+        Seg lines[MAX_S];
         for (int s = 0; s < S; ++s) {
             const int n = s < S - 1 ? 2 : 1, o0 = bands[s].own0 - bands[s].loc0, o1 = bands[s].own1 - bands[s].loc0;
             const size_t bytes = (size_t)n * bands[s].W * 12;
-            if (!exchange(m, rank, S, out_rows(s, o0), up ? out_rows(s, o0 - n) : nullptr, bytes, out_rows(s, o1 - n), down ? out_rows(s, o1) : nullptr, bytes)) return false;
+            lines[s] = Seg{ out_rows(s, o0), up ? out_rows(s, o0 - n) : nullptr, bytes, out_rows(s, o1 - n), down ? out_rows(s, o1) : nullptr, bytes };
         }
+        if (!exchange_n(m, rank, S, lines, S)) return false; // the edge lines of every scale's output in one operation
     }
     // ---- merges coarse to fine (MultiscaleDenoiser.cpp:453-466); between two merges one line of the merged output travels
     for (int s = S - 2; s >= 0; --s) {

@@ -25,6 +25,7 @@
 //     lambda_min(M) >= minEig); otherwise the spectral form is evaluated with a compact Jacobi solver;
 //   * sums into LDS windows are plain read-add-write, never ds_add_f32 (193 cycles per wavefront instruction on gfx950).
 #include "bcd_common.h"
+#include <atomic>
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
@@ -993,10 +994,11 @@ template <int PHASE>
 __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                 const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
                                                 int first_item, int nb_items, int *work, Geom27 g, float min_eig, Records27 rec, float *sum,
-                                                int32_t *cnt)
+                                                int32_t *cnt, const int *redo = nullptr /* PHASE 2, optional: [0] count, [1..] the items to process */)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
+    if (PHASE == 2 && redo) nb_items = redo[0];
     // PHASE 1 needs one matrix buffer only (the member chunk; its matrices go from the accumulator registers to the records) and
     // runs 20 wavefronts per CU instead of 12, which is what its member gathers want (half of its wave cycles wait for memory;
     // 28 per CU were measured: no faster, and 4 KB instead of 7 KB per wavefront leave LDS to the kernels running beside it)
@@ -1011,8 +1013,9 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
     // persistent wavefronts: items are handed out through the work queues
   WorkCursor cursor = work_begin();
   for (;;) {
-    const int slot = work_next(work, nb_items, lane, cursor);
+    int slot = work_next(work, nb_items, lane, cursor);
     if (slot < 0) break;
+    if (PHASE == 2 && redo) slot = __builtin_amdgcn_readfirstlane(redo[1 + slot]);
     const int p = list[first_item + slot];
     const int n = decode_members27(mask, p, g, mem, lane);
     const int W = g.W;
@@ -1126,6 +1129,20 @@ __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors
 // =====================================================================================================================
 constexpr int WB = 6, WSIDE = 2 * WB + 1, WAW = WSIDE + 2, WPIX = WAW * WAW;   // 13, 15, 225
 constexpr int WMEM = ((WSIDE * WSIDE + 7) / 8) * 8;                             // member list, padded to whole 16-byte reads
+// (round 4) the same window for any search radius B -- the register-resident finish kernel also serves b = 12 (27 x 27 pixels): SIDE search
+// positions per line, AW window pixels per line, G = floats between the end of one patch line and the start of the next in the window
+constexpr int WIN_SLICE = 11;   // loads per lane and slice when a window is staged
+template <int B> struct WinT {
+    static constexpr int SIDE = 2 * B + 1, AW = SIDE + 2, PIX = AW * AW, G = AW * 3 - 9;
+    static constexpr int MEM = ((SIDE * SIDE + 7) / 8) * 8;                       // member codes (uint16), padded to whole 16-byte reads
+    static constexpr int NWORDS = (SIDE * SIDE + 31) / 32, NBITS = (SIDE * SIDE + 63) / 64; // mask words of a pixel; window positions per lane
+    static constexpr int CSLICES = (PIX * 3 + 64 * WIN_SLICE - 1) / (64 * WIN_SLICE);   // slices of the colour window
+    // LDS layout of k_finish27w (floats): colour window | sums | counts | noise | mean | member codes
+    static constexpr int F2_ACCS = (PIX * 3 + 3) / 4 * 4, F2_ACCC = 2 * F2_ACCS, F2_NOISE = F2_ACCC + (PIX + 3) / 4 * 4;
+    static constexpr int F2_MEAN = F2_NOISE + 56, F2_MEM = F2_MEAN + 32;
+    static constexpr size_t F2_BYTES = (size_t)F2_MEM * sizeof(float) + MEM * sizeof(uint16_t);
+};
+static_assert(WinT<WB>::AW == WAW && WinT<WB>::PIX == WPIX && WinT<WB>::MEM == WMEM && WinT<WB>::G == 36 && WinT<WB>::CSLICES == 1, "b = 6 is the geometry the r3 kernels were written for");
 // LDS layout of PHASE 1 (floats): colour window | covariance window | noise | mean | members (16-byte aligned)
 constexpr int W1_NWIN = (WPIX * 3 + 3) / 4 * 4, W1_NOISE = W1_NWIN + (WPIX * 6 + 3) / 4 * 4, W1_MEM = W1_NOISE + 56 + 28;
 constexpr int W2_MEM = 4 * 784 + 56 + 56 + 28 + 28;                              // PHASE 2: four matrix buffers | cs | noise | mean | fl | members
@@ -1133,40 +1150,42 @@ static_assert(W1_MEM % 4 == 0 && W2_MEM % 4 == 0 && 28 * 29 <= WPIX * 6, "aligne
 
 // similar set of p in window order -> mem[i] = window pixel index of member i; returns |S|.  The mask words of p are wave-uniform
 // (scalar loads); lane l looks at the bits l, l + 64, l + 128 and places its members by prefix population counts.
+template <int B = WB>
 __device__ inline int decode_members_win(const uint32_t *__restrict__ mask, int p, int words, uint16_t *mem, int lane)
 {
-    uint32_t wd[6];
-    int pre[7];
+    using G_ = WinT<B>;
+    constexpr int NW = 2 * G_::NBITS; // (an even number of words: lane l looks at bit l & 31 of word 2 j + (l >> 5))
+    uint32_t wd[NW];
+    int pre[NW + 1];
     pre[0] = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NW; ++i) {
         wd[i] = i < words ? mask[(size_t)p * words + i] : 0u;
         pre[i + 1] = pre[i] + __popc(wd[i]);
     }
     const int hi = lane >> 5, bit = lane & 31;
     const uint32_t below = (1u << bit) - 1u;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < G_::NBITS; ++j) {
         const uint32_t w = hi ? wd[2 * j + 1] : wd[2 * j];
         const int base = hi ? pre[2 * j + 1] : pre[2 * j];
         if ((w >> bit) & 1u) {
             const int k = lane + 64 * j;
-            const int kl = (k * 79) >> 10, kc = k - kl * WSIDE;           // k / 13 for k < 169 (79 / 1024 = 1 / 12.96; exact up to k = 181)
-            mem[base + __popc(w & below)] = (uint16_t)((kl + 1) * WAW + kc + 1);
+            const int kl = k / G_::SIDE, kc = k - kl * G_::SIDE;          // (division by a constant: a multiply and a shift)
+            mem[base + __popc(w & below)] = (uint16_t)((kl + 1) * G_::AW + kc + 1);
         }
     }
     __syncthreads();
-    return pre[6];
+    return pre[NW];
 }
 
 // one 15 x 15 window of an interleaved image with D floats per pixel -> LDS (cells outside the image: unspecified; no member patch touches them),
 // in slices of WIN_SLICE loads per lane: win_issue puts the loads of slice `first` in flight, win_commit stores them
-constexpr int WIN_SLICE = 11;
-template <int D>
+template <int D, int B = WB>
 __device__ inline void win_issue(float (&v)[WIN_SLICE], const float *__restrict__ img, int first, int pr, int pc, int W, int H, int lane)
 {
-    constexpr int ROW = WAW * D, N = WAW * ROW;
-    const int row0 = pr - (WB + 1), col0 = pc - (WB + 1);
+    constexpr int AW = WinT<B>::AW, ROW = AW * D, N = AW * ROW;
+    const int row0 = pr - (B + 1), col0 = pc - (B + 1);
 #pragma unroll
     for (int u = 0; u < WIN_SLICE; ++u) {
         // (cells outside the image are never part of a member's patch: their content is irrelevant, so the address is clamped
@@ -1177,10 +1196,10 @@ __device__ inline void win_issue(float (&v)[WIN_SLICE], const float *__restrict_
         v[u] = img[(gy * W + gx) * D + ch]; // (32-bit index: DeepImage indices are ints, checked by the host)
     }
 }
-template <int D>
+template <int D, int B = WB>
 __device__ inline void win_commit(float *win, const float (&v)[WIN_SLICE], int first, int lane)
 {
-    constexpr int N = WAW * WAW * D;
+    constexpr int N = WinT<B>::PIX * D;
 #pragma unroll
     for (int u = 0; u < WIN_SLICE; ++u) {
         const int e = lane + 64 * (first + u);
@@ -1492,21 +1511,22 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float
 // No matrix goes through LDS (the previous form -- k_bayes27<2>'s, kept for the other search radii -- spent 0.2 of its 0.5 ms per 32 768
 // pixels in LDS round trips of these stages), and LDS holds only the windows: 7.4 KB per wavefront instead of 17.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int F2_ACCS = (WPIX * 3 + 3) / 4 * 4, F2_ACCC = 2 * F2_ACCS, F2_NOISE = F2_ACCC + (WPIX + 3) / 4 * 4;
-constexpr int F2_MEAN = F2_NOISE + 56, F2_MEM = F2_MEAN + 32;   // floats; then WMEM member codes
-
+// (LDS layout: WinT<B>::F2_*.)  B = 6: 15 x 15 window, 7.4 KB per wavefront; B = 12 (round 4): 27 x 27, 22 KB -- seven wavefronts per CU.
+template <int B>
 __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
                                                      const int32_t *__restrict__ list, int first_item, int nb_items, int *work, Geom27 g,
                                                      float min_eig, Records27 rec, float *sum, int32_t *cnt, int *redo /* [0] count, [1..] items */,
                                                      int *redo_total /* statistics: items handed over, all launches of the scale */)
 {
+    using G_ = WinT<B>;
+    constexpr int AW = G_::AW, PIX = G_::PIX, GAP = G_::G; // window pixels per line / in all; floats from the end of a patch line to the start of the next
     extern __shared__ float lds[];
     const int lane0 = threadIdx.x;
-    float *cwin = lds, *accS = lds + F2_ACCS;
-    int *accC = reinterpret_cast<int *>(lds + F2_ACCC);
-    float *noise = lds + F2_NOISE, *mean = lds + F2_MEAN;
-    uint16_t *mem = reinterpret_cast<uint16_t *>(lds + F2_MEM);
-    for (int e = lane0; e < WMEM; e += 64) mem[e] = (uint16_t)(WAW + 1); // (entries past |S| are read, never used: keep them inside the window)
+    float *cwin = lds, *accS = lds + G_::F2_ACCS;
+    int *accC = reinterpret_cast<int *>(lds + G_::F2_ACCC);
+    float *noise = lds + G_::F2_NOISE, *mean = lds + G_::F2_MEAN;
+    uint16_t *mem = reinterpret_cast<uint16_t *>(lds + G_::F2_MEM);
+    for (int e = lane0; e < G_::MEM; e += 64) mem[e] = (uint16_t)(AW + 1); // (entries past |S| are read, never used: keep them inside the window)
     if (lane0 < 32) mean[lane0] = 0.f;                                   // (components 27..31: zero padding)
     __syncthreads();
     const int W = g.W, H = g.H;
@@ -1545,13 +1565,15 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
         const float aux_n = recX[min(lane, P * 6 - 1)], aux_m = recX[P * 6 + min(lane, K - 1)];
         const int p = __builtin_amdgcn_readfirstlane(list[first_item + slot]);
         const int pr = p / W, pc = p - pr * W;
-        float wv[WIN_SLICE];
-        win_issue<3>(wv, colors, 0, pr, pc, W, H, lane);
+        float wv[G_::CSLICES][WIN_SLICE];
+#pragma unroll
+        for (int c = 0; c < G_::CSLICES; ++c) win_issue<3, B>(wv[c], colors, c * WIN_SLICE, pr, pc, W, H, lane);
         __builtin_amdgcn_sched_barrier(0);
         if (lane < P * 6) noise[lane] = aux_n;
         if (lane < K) mean[lane] = aux_m;
-        const int n = decode_members_win(mask, p, g.words, mem, lane);   // (ends with a barrier: noise and mean are visible too)
-        win_commit<3>(cwin, wv, 0, lane);   // (nothing else uses the LDS windows during the algebra; the loads return with the record's)
+        const int n = decode_members_win<B>(mask, p, g.words, mem, lane);   // (ends with a barrier: noise and mean are visible too)
+#pragma unroll
+        for (int c = 0; c < G_::CSLICES; ++c) win_commit<3, B>(cwin, wv[c], c * WIN_SLICE, lane);   // (nothing else uses the LDS windows during the algebra; the loads return with the record's)
         __builtin_amdgcn_sched_barrier(0);
 
         // N in the accumulator layout: element (r(e, h), idx) of the block-diagonal noise covariance
@@ -1628,65 +1650,67 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- the zeroed aggregation window
-        for (int e = lane; e < F2_NOISE - F2_ACCS; e += 64) accS[e] = 0.f;   // (sums and counts are contiguous)
+        for (int e = lane; e < G_::F2_NOISE - G_::F2_ACCS; e += 64) accS[e] = 0.f;   // (sums and counts are contiguous)
         __syncthreads();
         // ---- output pass, 32 members per product: lane (j, h) feeds B = x_j[r(s, h)] and gets back components r(e, h) of member j
         for (int i0 = 0; i0 < n; i0 += 32) {
             const bool valid = i0 + idx < n;
             const int wp = mem[valid ? i0 + idx : 0];
-            const int base = (wp - WAW - 1) * 3;                // top-left pixel of the member's patch in the window, floats
-            // component r = r0 + 4 h is r + 36 (r / 9) floats into the patch: r0 + 36 (r0 / 9) plus 4 h -- or 40 h where r0 + 4 is on the
-            // next patch line -- i.e. a compile-time offset from one of two per-lane bases, for the operand reads and for the sums alike
-            const float *x4 = cwin + base + 4 * h, *x40 = cwin + base + 40 * h;
+            const int base = (wp - AW - 1) * 3;                 // top-left pixel of the member's patch in the window, floats
+            // component r = r0 + 4 h is r + GAP (r / 9) floats into the patch (GAP = 36 for the 15-pixel window): r0 + GAP (r0 / 9) plus 4 h -- or
+            // (4 + GAP) h where r0 + 4 is on the next patch line -- i.e. a compile-time offset from one of two per-lane bases, for the operand
+            // reads and for the sums alike
+            const float *x4 = cwin + base + 4 * h, *x40 = cwin + base + (4 + GAP) * h;
             v16f y = c0;
 #pragma unroll
             for (int s_ = 0; s_ < 15; ++s_) {
                 const int r0 = (s_ & 3) + 8 * (s_ >> 2);
                 float bq;
-                if (r0 <= 19) bq = ((r0 + 4) / 9 != r0 / 9 ? x40 : x4)[r0 + 36 * (r0 / 9)];
-                else bq = (h ? cwin + base : x4 + r0 + 72)[0];   // r0 = 24..26: half 1 is padding (its A operand is zero: any finite cell)
+                if (r0 <= 19) bq = ((r0 + 4) / 9 != r0 / 9 ? x40 : x4)[r0 + GAP * (r0 / 9)];
+                else bq = (h ? cwin + base : x4 + r0 + 2 * GAP)[0];   // r0 = 24..26: half 1 is padding (its A operand is zero: any finite cell)
                 y = __builtin_amdgcn_mfma_f32_32x32x2f32(FT[s_], bq, y, 0, 0, 0);
             }
             if (valid) {
-                float *d4 = accS + base + 4 * h, *d40 = accS + base + 40 * h;
+                float *d4 = accS + base + 4 * h, *d40 = accS + base + (4 + GAP) * h;
                 // Plain read-add-write, not ds_add_f32: the LDS float atomic is served one lane at a time on gfx950 (193 cycles of the CU's
                 // LDS pipe per wavefront instruction, measured: tools/ubench/lds_rate.hip; a read is 2.5 and a write 4.7), and there is
                 // nobody to be atomic against -- one wavefront per workgroup, and within one instruction the 64 addresses are distinct:
-                // two members' patches are whole pixels (multiples of 3 floats) apart, the two halves' components 4 or 40 floats.
+                // two members' patches are whole pixels (multiples of 3 floats) apart, the two halves' components 4 or 4 + GAP floats (GAP is a
+                // multiple of 3: neither is).
 #pragma unroll
                 for (int e = 0; e < 12; ++e) {                     // r0 <= 19: both halves inside the 27 components
                     const int r0 = (e & 3) + 8 * (e >> 2);
-                    float *q = ((r0 + 4) / 9 != r0 / 9 ? d40 : d4) + r0 + 36 * (r0 / 9);
+                    float *q = ((r0 + 4) / 9 != r0 / 9 ? d40 : d4) + r0 + GAP * (r0 / 9);
                     *q = *q + y[e];
                     // (the NEXT component of another lane may be this address: program order must be kept -- the compiler only reasons about
                     // one lane, where the addresses differ; the hardware serves a wavefront's LDS instructions in order)
                     asm volatile("" ::: "memory");
                 }
-                // the 9 pixels of the patch, counted once each: pixel q is (q % 3) + 15 (q / 3) cells from the top-left one; half 0 takes
-                // q = 0..4, half 1 q = 5..8
-                int *c17 = accC + (wp - WAW - 1) + 17 * h, *c29 = accC + (wp - WAW - 1) + 29 * h;
+                // the 9 pixels of the patch, counted once each: pixel q is (q % 3) + AW (q / 3) cells from the top-left one; half 0 takes
+                // q = 0..4 (cells 0, 1, 2, AW, AW + 1), half 1 q = 5..8 (AW + 2, 2 AW, 2 AW + 1, 2 AW + 2)
+                int *c17 = accC + (wp - AW - 1) + (AW + 2) * h, *c29 = accC + (wp - AW - 1) + (2 * AW - 1) * h;
                 atomicAdd(c17, 1);
                 atomicAdd(c29 + 1, 1);
                 atomicAdd(c29 + 2, 1);
-                atomicAdd(c17 + 15, 1);
+                atomicAdd(c17 + AW, 1);
                 if (!h) {
 #pragma unroll
-                    for (int e = 12; e < 15; ++e) { float *q = d4 + 24 + (e - 12) + 72; *q = *q + y[e]; asm volatile("" ::: "memory"); } // r0 = 24..26
-                    atomicAdd(c17 + 16, 1);
+                    for (int e = 12; e < 15; ++e) { float *q = d4 + 24 + (e - 12) + 2 * GAP; *q = *q + y[e]; asm volatile("" ::: "memory"); } // r0 = 24..26
+                    atomicAdd(c17 + AW + 1, 1);
                 }
             }
         }
         __syncthreads();
         // aggregateOutputPatches (:672-693): one global atomic per touched value of the window, rows contiguous
         {
-            constexpr int row3 = WAW * 3;
-            const long long base = (long long)p - (long long)(WB + 1) * W - (WB + 1); // window origin; untouched cells may lie outside the image
-            for (int e = lane; e < WAW * row3; e += 64) {
+            constexpr int row3 = AW * 3;
+            const long long base = (long long)p - (long long)(B + 1) * W - (B + 1); // window origin; untouched cells may lie outside the image
+            for (int e = lane; e < AW * row3; e += 64) {
                 int wy = e / row3, r = e - wy * row3, wx = r / 3;
-                if (accC[wy * WAW + wx] != 0) unsafeAtomicAdd(sum + (base + (long long)wy * W) * 3 + r, accS[e]);
+                if (accC[wy * AW + wx] != 0) unsafeAtomicAdd(sum + (base + (long long)wy * W) * 3 + r, accS[e]);
             }
-            for (int e = lane; e < WPIX; e += 64) {
-                int wy = e / WAW, wx = e - wy * WAW, c = accC[e];
+            for (int e = lane; e < PIX; e += 64) {
+                int wy = e / AW, wx = e - wy * AW, c = accC[e];
                 if (c != 0) atomicAdd(cnt + (base + (long long)wy * W + wx), c);
             }
         }
@@ -1743,8 +1767,8 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
                                d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, nullptr);
         else {
             // the register-resident finish; the items whose sweep inverse fails its checks (rare) come back on a list for the LDS kernel
-            const size_t wl3 = (size_t)F2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
-            hipLaunchKernelGGL(k_finish27w, dim3(std::min(nb_items, num_cus * 12)), dim3(64), wl3, st, colors, mask, list, first_item, nb_items,
+            const size_t wl3 = WinT<WB>::F2_BYTES;
+            hipLaunchKernelGGL(k_finish27w<WB>, dim3(std::min(nb_items, num_cus * 12)), dim3(64), wl3, st, colors, mask, list, first_item, nb_items,
                                d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo, d_spectral);
             // (normally an empty list: a small grid, so that its 17 KB workgroups do not queue for LDS behind the kernels of the other scales --
             // a full-size launch that only reads "0 items" was seen waiting 0.7 ms for room.  A long list is still processed, by fewer wavefronts.)
@@ -1756,11 +1780,35 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         }
         return hipGetLastError();
     }
+    constexpr int WB2 = 12; // the large search window of BASELINE configs[4]: register-resident finish on a 27 x 27 pixel window (round 4)
+    static const bool finish_lds_b12 = [] { const char *e = getenv("BCD_HIP_FINISH_LDS"); return e && e[0] == '1'; }();
+    const bool finish_regs = b == WB2 && !gather_only && !finish_lds_b12;
+    int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP);
     hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
-                       d_work, g, min_eig, rec, sum, cnt);
+                       d_work, g, min_eig, rec, sum, cnt, (const int *)nullptr);
     { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st); if (e != hipSuccess) return e; }
+    if (finish_regs) {
+        // the prepare kernel of this path does not know the redo list: its counter is cleared here (one fill per chunk)
+        { hipError_t e = hipMemsetAsync(redo, 0, sizeof(int), st); if (e != hipSuccess) return e; }
+        const size_t wl3 = WinT<WB2>::F2_BYTES;
+        static std::atomic<int> granted[64];
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        if (wl3 > 64 * 1024 && (dev < 0 || dev >= 64 || granted[dev].load() == 0)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish27w<WB2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl3);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) granted[dev].store(1);
+        }
+        const int per_cu3 = (int)std::min<size_t>(12, (size_t)160 * 1024 / wl3);
+        hipLaunchKernelGGL(k_finish27w<WB2>, dim3(std::min(nb_items, num_cus * per_cu3)), dim3(64), wl3, st, colors, mask, list, first_item, nb_items,
+                           d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo, d_spectral);
+        if (!defer_redo)
+            hipLaunchKernelGGL(k_bayes27<2>, dim3(std::min(nb_items, num_cus * 2)), dim3(64), lds2, st, colors, pixcov, mask, list, first_item, nb_items,
+                               d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, (const int *)redo);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_bayes27<2>, dim3(std::min(nb_items, num_cus * per_cu2)), dim3(64), lds2, st, colors, pixcov, mask, list, first_item, nb_items,
-                       d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt);
+                       d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, (const int *)nullptr);
     return hipGetLastError();
 }
 
@@ -1768,7 +1816,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
 hipError_t bcd_launch_bayes27_redo(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int first_item, int nb_items,
                                    int *d_work, int num_cus, int W, int H, int b, float min_eig, float *records, float *sum, int32_t *cnt, hipStream_t st)
 {
-    if (nb_items <= 0 || b != WB) return hipSuccess;
+    if (nb_items <= 0 || (b != WB && b != 12)) return hipSuccess;
     Geom27 g;
     g.W = W; g.H = H; g.b = b; g.side = 2 * b + 1; g.words = (g.side * g.side + 31) / 32; g.maxS = g.side * g.side;
     Records27 rec;
@@ -1778,6 +1826,11 @@ hipError_t bcd_launch_bayes27_redo(const float *colors, const float *pixcov, con
     rec.aux = rec.C + (size_t)nb_items * MSZ;
     rec.eig = rec.aux + (size_t)nb_items * AUX27;
     int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP);
+    if (b != WB) { // the large window: the gather kernel walks the list
+        hipLaunchKernelGGL(k_bayes27<2>, dim3(std::min(nb_items, num_cus * 2)), dim3(64), bcd_bayes27_lds_bytes(b), st, colors, pixcov, mask, list, first_item, nb_items,
+                           d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, (const int *)redo);
+        return hipGetLastError();
+    }
     const size_t wl2 = (size_t)W2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
     hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * 2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
                        d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo);

@@ -966,12 +966,12 @@ def test_native_multi_rank_driver_ordered_communication(hipctx, monkeypatch, ran
 
 
 def _check_phase_major_order(trace, S, W, halo):
-    """the issue order of bcd_multi.hip's CommGate: marking operations of scale S-1, ..., scale 0, then the accumulator exchanges (sum: halo x W x 12
-    bytes, count: halo x W x 4) of scale S-1, ..., scale 0, then the merges' exchanges (channel S)"""
+    """the issue order of bcd_multi.hip's CommGate: marking operations of scale S-1, ..., scale 0, then the accumulator exchange (sums + counts: halo x W x 16
+    bytes) of scale S-1, ..., scale 0, then the merges' exchanges (channel S)"""
     chans = [ch for ch, _, _, _ in trace]
-    acc = lambda i: trace[i][1] == 0 and max(trace[i][2], trace[i][3]) in (halo * (W >> trace[i][0]) * 12, halo * (W >> trace[i][0]) * 4)
-    p2 = {c: [i for i in range(len(trace)) if chans[i] == c][-2:] for c in range(S)}            # the last two operations of a scale's channel
-    assert all(len(v) == 2 and acc(v[0]) and acc(v[1]) for v in p2.values())
+    acc = lambda i: trace[i][1] == 0 and max(trace[i][2], trace[i][3]) == halo * (W >> trace[i][0]) * 16   # sums (12 bytes per pixel) + counts (4) in one operation
+    p2 = {c: [i for i in range(len(trace)) if chans[i] == c][-1:] for c in range(S)}            # the last operation of a scale's channel
+    assert all(len(v) == 1 and acc(v[0]) for v in p2.values())
     p1 = {c: [i for i in range(len(trace)) if chans[i] == c and i not in p2[c]] for c in range(S)}
     for c in range(S - 1):
         assert not p1[c] or not p1[c + 1] or max(p1[c + 1]) < min(p1[c])                       # marking: coarser scales first
@@ -1449,7 +1449,7 @@ def test_whole_frame_through_the_rccl_transport_in_loopback(hipctx, m):
     halo = b + 1
     for s in range(S):
         sizes = [(up, dn) for ch, k, up, dn in trace if ch == s and k == 0]
-        assert ((halo * (W >> s) * 12,) * 2 in sizes) and ((halo * (W >> s) * 4,) * 2 in sizes)     # accumulator halos of the scale, both neighbours
+        assert (halo * (W >> s) * 16,) * 2 in sizes                                                 # accumulator halos of the scale (sums + counts), both neighbours
     assert any(k == 1 for _, k, _, _ in trace) == (m > 0)       # the marking all-reduce
     _check_phase_major_order(trace, S, W, halo)                 # issue order: marking coarse to fine, accumulators coarse to fine, merges
 
