@@ -10,8 +10,16 @@ python tools/timeline.py $DB 6.2 > gpurun_out/final_timeline.txt
 for t in final_noextras final_default final_serial; do grep '^{' gpurun_out/${t}_bench.log | tail -1 > gpurun_out/${t}_line.json; done
 python bench.py --steps 30 --warmup 5 > gpurun_out/final_bench_unprofiled.log 2>&1
 grep '^{' gpurun_out/final_bench_unprofiled.log | tail -1 > gpurun_out/final_unprofiled_line.json
-# HBM traffic of the pair-distance kernel (TCC counters, separate passes)
+# BASELINE configs[3] / [4] on one GPU (round 4): per-kernel tables of the 4K frame and of the 4K b = 12 frame
+tools/prof.sh final_4k --no-extras --width 3840 --height 2160 --spp 8 --sigma 0.15 --spikes 0 --steps 6 --warmup 2 > /dev/null
+tools/prof.sh final_4k_b12 --no-extras --width 3840 --height 2160 --spp 8 --sigma 0.25 --spikes 0.01 --search-radius 12 --steps 4 --warmup 1 > /dev/null
+BCD_HIP_SERIAL_SCALES=1 tools/prof.sh final_4k_b12_serial --no-extras --width 3840 --height 2160 --spp 8 --sigma 0.25 --spikes 0.01 --search-radius 12 --steps 4 --warmup 1 > /dev/null
+# one rank's band of the 4K frame through the band driver with RCCL in loopback (bench.py predicted_8gpu): kernel timeline of one step
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d $R/gpurun_out/prof_final_band -o band -- python $R/bench.py --predict-band-child > $R/gpurun_out/final_band.log 2>&1)
+python tools/timeline.py $(ls gpurun_out/prof_final_band/*.db | head -1) 3.2 > gpurun_out/final_band_timeline.txt
+# HBM traffic of the pair-distance kernel (TCC counters, separate passes): the headline size and the 4K frame
 tools/pmc_traffic.sh > gpurun_out/final_pmc_traffic.log 2>&1
+tools/pmc_traffic.sh --width 3840 --height 2160 --spp 8 --sigma 0.15 --spikes 0 >> gpurun_out/final_pmc_traffic.log 2>&1
 # SQ counters of the kernels that ship
 S1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"
 S2="SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"
