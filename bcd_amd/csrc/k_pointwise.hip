@@ -154,8 +154,15 @@ __global__ void k_spike(const float *__restrict__ col, const float *__restrict__
                         const float *__restrict__ cov, int W, int H, int D, float factor,
                         float *__restrict__ ocol, float *__restrict__ ons, float *__restrict__ ohist, float *__restrict__ ocov, int row_begin)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x, l = row_begin + blockIdx.y;
-    if (c >= W) return;
+    // (round 4) the decision is per pixel, the copies are per workgroup: the 64 source indices go through LDS and the 64 lanes then move the 64
+    // pixels' values as contiguous runs (16 bytes per lane for the histograms).  One lane copying the 60 bins of its own pixel was 4 bytes per lane
+    // at a stride of 240: 5 ms for a 4K frame, now bound by the 2 x 2.4 GB it moves.
+    __shared__ unsigned int s_src[64];
+    const int c0 = blockIdx.x * 64, c = c0 + threadIdx.x, l = row_begin + blockIdx.y;
+    const bool in_row = c < W;
+    const int ncols = min(64, W - c0);
+    size_t dst = (size_t)l * W + min(c, W - 1), src = dst;
+    if (in_row) {
     int cl = l < 1 ? 1 : (l > H - 2 ? H - 2 : l);
     int cc = c < 1 ? 1 : (c > W - 2 ? W - 2 : c);
     float v[3][9];
@@ -176,7 +183,6 @@ __global__ void k_spike(const float *__restrict__ col, const float *__restrict__
         float sd = sqrtf(total / 8);
         spike = spike || (fabsf(me[ch] - avg) > factor * sd);
     }
-    size_t dst = (size_t)l * W + c, src = dst;
     if (spike) {
         int best = 0;
         float bestd = -1.f;
@@ -188,10 +194,20 @@ __global__ void k_spike(const float *__restrict__ col, const float *__restrict__
         }
         src = (size_t)(cl - 1 + best / 3) * W + (cc - 1 + best % 3);
     }
-    for (int j = 0; j < 3; ++j) ocol[dst * 3 + j] = col[src * 3 + j];
-    ons[dst] = ns[src];
-    for (int j = 0; j < D; ++j) ohist[dst * D + j] = hist[src * D + j];
-    for (int j = 0; j < 6; ++j) ocov[dst * 6 + j] = cov[src * 6 + j];
+    }
+    s_src[threadIdx.x] = (unsigned int)src; // (pixel indices fit 31 bits: checked by the host entry points)
+    __syncthreads();
+    const size_t row_base = (size_t)l * W + c0; // first destination pixel of the workgroup
+    for (int e = threadIdx.x; e < ncols * 3; e += 64) { const int px = e / 3; ocol[row_base * 3 + e] = col[(size_t)s_src[px] * 3 + (e - px * 3)]; }
+    if (in_row) ons[dst] = ns[src];
+    for (int e = threadIdx.x; e < ncols * 6; e += 64) { const int px = e / 6; ocov[row_base * 6 + e] = cov[(size_t)s_src[px] * 6 + (e - px * 6)]; }
+    if ((D & 3) == 0) {
+        const int Q = D >> 2;
+        const float4 *h4 = reinterpret_cast<const float4 *>(hist);
+        float4 *o4 = reinterpret_cast<float4 *>(ohist);
+        for (int e = threadIdx.x; e < ncols * Q; e += 64) { const int px = e / Q; o4[row_base * Q + e] = h4[(size_t)s_src[px] * Q + (e - px * Q)]; }
+    } else
+        for (int e = threadIdx.x; e < ncols * D; e += 64) { const int px = e / D; ohist[row_base * D + e] = hist[(size_t)s_src[px] * D + (e - px * D)]; }
 }
 
 // SamplesAccumulator::addSample + computeSampleStatistics on the device (src/core/SamplesAccumulator.cpp:44-141):
