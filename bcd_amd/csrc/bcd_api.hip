@@ -31,6 +31,12 @@ int bcd_pairdist_rw_supported(int D);
 hipError_t bcd_launch_pairdist_rw(const float *, const float *, int, int, int, int, void * /* binary16 T planes */, uint8_t *, int *, float, hipStream_t);
 hipError_t bcd_launch_pairdist_rw_rows(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, int, int, hipStream_t);
 int bcd_pairdist_rw_tile_lines();
+struct BcdSparseUploader;
+BcdSparseUploader *bcd_sparse_create();
+void bcd_sparse_destroy(BcdSparseUploader *);
+void bcd_sparse_frame_begin(BcdSparseUploader *);
+void bcd_sparse_frame_bytes(const BcdSparseUploader *, long long *, long long *);
+hipError_t bcd_sparse_upload(BcdSparseUploader *, float *, const float *, size_t, hipStream_t);
 hipError_t bcd_launch_pairdist_rw_counting(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_spike_rows(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *, float *, float *, int, int,
                                  hipStream_t);
@@ -141,8 +147,14 @@ struct bcd_hip_ctx {
     DevBuf host_stage[9];      // host-buffer entry points: device copies of the four inputs, the output, the prefiltered inputs (grow-only)
     hipEvent_t ev_pyramid = nullptr;
     hipStream_t upload_stream = nullptr;        // host-buffer entry points: uploads run beside the kernels of the lines that have arrived
+    hipStream_t upload_stream2 = nullptr;       // ... colours and covariances beside the histogram pieces (helper thread)
+    hipEvent_t ev_upload2 = nullptr;
     std::vector<hipEvent_t> ev_upload;
     bool stream_uploads = true;                 // BCD_HIP_STREAM_UPLOADS=0: upload everything, then compute
+    // (round 4) the histogram image crosses PCIe without its zeros (bcd_sparse_upload.hip); BCD_HIP_SPARSE_UPLOAD=0: plain copies
+    bool sparse_uploads = true;
+    BcdSparseUploader *sparse = nullptr;
+    long long upload_raw_bytes = 0, upload_sent_bytes = 0; // histogram image of the last host-buffer frame: as it is / as it travelled
     // progress reporting (IDenoiser::setProgressCallback; Denoiser.cpp:181-192 of the reference): every scale adds its share when
     // its marking is done and when its estimate is done; calls are serialised and monotone
     bcd_hip_progress_fn progress_fn = nullptr;
@@ -760,6 +772,8 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
     ctx->fast_similarity = !(env && env[0] == '1');
     env = getenv("BCD_HIP_STREAM_UPLOADS");
     ctx->stream_uploads = !(env && env[0] == '0');
+    env = getenv("BCD_HIP_SPARSE_UPLOAD");
+    ctx->sparse_uploads = !(env && env[0] == '0');
     *out = ctx;
     return BCD_HIP_OK;
 }
@@ -778,6 +792,9 @@ void bcd_hip_ctx_destroy(bcd_hip_ctx *ctx)
     if (ctx->ev_pyramid) (void)hipEventDestroy(ctx->ev_pyramid);
     for (hipEvent_t ev : ctx->ev_upload) (void)hipEventDestroy(ev);
     if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
+    if (ctx->upload_stream2) (void)hipStreamDestroy(ctx->upload_stream2);
+    if (ctx->ev_upload2) (void)hipEventDestroy(ctx->ev_upload2);
+    if (ctx->sparse) bcd_sparse_destroy(ctx->sparse);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1074,12 +1091,44 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         // colours, sample counts and covariances first, whole (83 MB at 1080p; the prefilter and the distance kernel need them with the
         // first histogram lines), then the histograms -- 87 % of the bytes -- in row chunks
-        for (int i : { 0, 1, 3 }) HIPCHK(ctx, hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->upload_stream));
+        // Without the prefilter only the sample counts are needed with the first histogram lines (the distance kernel); colours and covariances
+        // are first read by the pyramid and the estimate stage.  Their (pageable, host-blocking) copies then run on a helper thread and a
+        // stream of their own beside the histogram pieces, whose pace is set by the host-side packing and leaves the link half idle (round 4).
+        std::thread side_copy;
+        hipError_t side_rc = hipSuccess;
+        struct SideJoin { std::thread &t; ~SideJoin() { if (t.joinable()) t.join(); } } side_join{ side_copy };
+        const bool side = !prefilter && ctx->sparse_uploads && (D & 3) == 0;
+        if (side) {
+            if (!ctx->upload_stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->upload_stream2, hipStreamNonBlocking));
+            if (!ctx->ev_upload2) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_upload2, hipEventDisableTiming));
+            HIPCHK(ctx, hipMemcpyAsync(d[1], src[1], sz[1] * sizeof(float), hipMemcpyHostToDevice, ctx->upload_stream));
+            const int dev = ctx->device;
+            hipStream_t s2 = ctx->upload_stream2;
+            hipEvent_t e2 = ctx->ev_upload2;
+            float *dc = d[0], *dv = d[3];
+            const float *hc = src[0], *hv = src[3];
+            const size_t nc = sz[0] * sizeof(float), nv = sz[3] * sizeof(float);
+            side_copy = std::thread([=, &side_rc]() {
+                hipError_t e = hipSetDevice(dev);
+                if (e == hipSuccess) e = hipMemcpyAsync(dc, hc, nc, hipMemcpyHostToDevice, s2);
+                if (e == hipSuccess) e = hipMemcpyAsync(dv, hv, nv, hipMemcpyHostToDevice, s2);
+                if (e == hipSuccess) e = hipEventRecord(e2, s2);
+                side_rc = e;
+            });
+        } else
+            for (int i : { 0, 1, 3 }) HIPCHK(ctx, hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->upload_stream));
+        const bool sparse = ctx->sparse_uploads && (D & 3) == 0;
+        if (sparse) {
+            if (!ctx->sparse && !(ctx->sparse = bcd_sparse_create())) { set_err(ctx, "out of host memory"); return BCD_HIP_ENOMEM; }
+            bcd_sparse_frame_begin(ctx->sparse);
+        }
+        ctx->upload_raw_bytes = ctx->upload_sent_bytes = (long long)sz[2] * 4;
         for (int r0 = 0; r0 < H; r0 += chunk, ++k) {
             const int r1 = std::min(H, r0 + chunk);
             {
                 const size_t off = (size_t)r0 * W * D, n = (size_t)(r1 - r0) * W * D;
-                HIPCHK(ctx, hipMemcpyAsync(d[2] + off, h_hist + off, n * sizeof(float), hipMemcpyHostToDevice, ctx->upload_stream));
+                if (sparse) HIPCHK(ctx, bcd_sparse_upload(ctx->sparse, d[2] + off, h_hist + off, n, ctx->upload_stream)); // (off % 4 == 0: D % 4 == 0 on this path)
+                else HIPCHK(ctx, hipMemcpyAsync(d[2] + off, h_hist + off, n * sizeof(float), hipMemcpyHostToDevice, ctx->upload_stream));
             }
             if ((int)ctx->ev_upload.size() <= k) {
                 hipEvent_t ev;
@@ -1102,6 +1151,12 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
                 tiles_done = t_end;
             }
         }
+        if (sparse) bcd_sparse_frame_bytes(ctx->sparse, &ctx->upload_raw_bytes, &ctx->upload_sent_bytes);
+        if (side) { // colours and covariances have been enqueued by now (the helper thread is joined), the frame's kernels wait for their arrival
+            side_copy.join();
+            HIPCHK(ctx, side_rc);
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload2, 0));
+        }
         wk.planes.ready = true; wk.planes.hist = d[7]; wk.planes.ns = d[6]; wk.planes.W = W; wk.planes.H = H; wk.planes.D = D; wk.planes.b = b;
         wk.planes.tau = prm->hist_dist_threshold; wk.planes.uni_n = uni_n;
     }
@@ -1114,6 +1169,14 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
     if (opt && opt->zero_bad_values) HIPCHK(ctx, bcd_launch_zero_bad(d[4], (int64_t)np * 3, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_out, d[4], sz[4] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_last_upload_bytes(const bcd_hip_ctx *ctx, int64_t *hist_bytes, int64_t *hist_bytes_sent)
+{
+    if (!ctx || !hist_bytes || !hist_bytes_sent) return BCD_HIP_EINVAL;
+    *hist_bytes = ctx->upload_raw_bytes;
+    *hist_bytes_sent = ctx->upload_sent_bytes;
     return BCD_HIP_OK;
 }
 

@@ -40,7 +40,7 @@ class ScaleStats(C.Structure):
 SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
     "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_set_cu_share", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
-    "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_set_progress_callback",
+    "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_last_upload_bytes", "bcd_hip_selftest_pack32", "bcd_hip_set_progress_callback",
     "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_set_progress_callback", "bcd_hip_multi_set_frame_timeout", "bcd_hip_multi_set_comm_trace", "bcd_hip_multi_get_comm_trace", "bcd_hip_multi_denoise_host",
     "bcd_hip_multi_unique_id", "bcd_hip_multi_create_rank", "bcd_hip_multi_rank_configure", "bcd_hip_multi_rank_upload", "bcd_hip_multi_rank_step",
     "bcd_hip_multi_rank_download", "bcd_hip_multi_rank_renew_ids", "bcd_hip_multi_set_loopback", "bcd_hip_multi_selftest_transport",
@@ -151,6 +151,12 @@ class Context:
         opt = HostOptions(spike_factor, 1 if zero_bad_values else 0)
         self._chk(lib().bcd_hip_denoise_host_ex(self.h, f(col), f(ns), f(hist), f(cov), W, H, D, nscales, C.byref(prm), C.byref(opt), f(out)))
         return out
+
+    def last_upload_bytes(self):
+        """(bytes of the histogram image of the last denoise_host call, bytes of it that crossed PCIe)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(lib().bcd_hip_last_upload_bytes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_progress_callback(self, fn):
         """fn(progress) or None; the ctypes thunk is kept alive on the context"""

@@ -388,9 +388,12 @@ def main():
         for _ in range(3):
             ctx.denoise_host(*h_frame, S, prm)
         ms_e2e = (time.perf_counter() - t1) * 1e3 / 3
-        pcie_bytes = W * H * ((60 + 1 + 3 + 6) * 4 + 12)
+        hist_raw, hist_sent = ctx.last_upload_bytes()
+        pcie_bytes = W * H * ((1 + 3 + 6) * 4 + 12) + hist_sent
         extras["end_to_end"] = {"value": round(W * H / 1e6 / (ms_e2e * 1e-3), 3), "unit": "Mpix/s", "ms_per_frame": round(ms_e2e, 3), "steps": 3,
                                 "pcie_bytes_per_frame": pcie_bytes, "pcie_gbs_if_all_of_the_time_were_transfer": round(pcie_bytes / (ms_e2e * 1e-3) / 1e9, 1),
+                                "histogram_bytes": hist_raw, "histogram_bytes_sent": hist_sent,
+                                "upload": "histogram image packed on the host (one bit per value + the non-zero values, lossless) while the previous piece travels, rebuilt in HBM by a kernel" if hist_sent < hist_raw else "plain copies",
                                 "workload": "the headline frame through bcd_hip_denoise_host (pageable host buffers in, host buffer out; engine context and device "
                                             "staging buffers persistent): what bcd::Denoiser::denoise() / bcd_cli callers see, minus file IO"}
         # on the default frame most processed pixels take the fallback path; the low-noise variant (sigma 0.10, no

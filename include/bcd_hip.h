@@ -210,6 +210,17 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
                             const float *h_histograms, const float *h_covariances,
                             int W, int H, int D, int nb_scales, const bcd_hip_params *prm, const bcd_hip_host_options *opt, float *h_out);
 
+/* The histogram image of the last bcd_hip_denoise_host(_ex) call: its size, and the bytes that crossed the link.  On frames of >= 256 lines the
+ * image travels without its zeros -- host threads pack every piece into one bit per value ("is not +0.0f", a test on the bit pattern: lossless)
+ * plus the remaining values while the previous piece travels, a kernel rebuilds the fp32 image in HBM; an image with more than 60 % of
+ * non-zero values is copied as it is.  BCD_HIP_SPARSE_UPLOAD=0 turns it off, BCD_HIP_UPLOAD_THREADS=<n> sets the packing threads (default:
+ * half the host's hardware threads, at most 16). */
+int bcd_hip_last_upload_bytes(const bcd_hip_ctx *ctx, int64_t *hist_bytes, int64_t *hist_bytes_sent);
+/* host-side self-test of the packer (no device needed): packs the 32 values at in32 with the form this process uses -- returned: 0 scalar,
+ * 2 AVX2, 5 AVX-512 (BCD_HIP_UPLOAD_SIMD=scalar|avx2|avx512 forces one the host has) -- into out64 (>= 64 values of room), sets the mask bits
+ * and the number of values kept */
+int bcd_hip_selftest_pack32(const uint32_t *in32, uint32_t *out64, uint32_t *bits, int *count);
+
 /* ---- stages (device pointers) -- exposed for parity tests and multi-GPU composition ------------ */
 /* Denoiser::computePixelCovFromSampleCov   src/core/Denoiser.cpp:357-373 */
 int bcd_hip_pixel_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_nsamples, int W, int H, float *d_out);

@@ -60,3 +60,34 @@ def test_device_entry_points_fail_loudly_without_gpu():
     col, ns, hist, cov = core.synthetic_scene(16, 12, 2)
     ok, out, _ = core.denoise(col, ns, hist, cov, 1)
     assert not ok                                            # bcd::Denoiser::denoise() returns false, like bad inputs
+
+
+def test_sparse_upload_packer_every_simd_form_the_host_has():
+    """the host half of the sparse histogram upload (bcd_sparse_upload.hip): one 32-value group -> mask bits + the values whose bit pattern is not
+    zero, in order; scalar, AVX2 and AVX-512 forms must agree with the definition (incl. -0.0f = 0x80000000, which is a VALUE).  Each form in a
+    child process (the choice is made once per process)"""
+    import subprocess
+    import sys
+    code = """
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+import bcd_amd.hip as bh
+lib = bh.lib()
+rng = np.random.default_rng(1)
+kind = -1
+for trial in range(1500):
+    dens = rng.choice([0.0, 0.05, 0.3, 0.7, 1.0])
+    v = ((rng.random(32) < dens) * rng.integers(1, 2**32, 32, dtype=np.uint64)).astype(np.uint32)
+    if trial %% 7 == 0: v[rng.integers(32)] = 0x80000000
+    out = np.zeros(64, np.uint32); bits = C.c_uint32(0); cnt = C.c_int(0)
+    kind = lib.bcd_hip_selftest_pack32(v.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(bits), C.byref(cnt))
+    want = v[v != 0]
+    assert cnt.value == len(want) and bits.value == sum(1 << i for i in range(32) if v[i] != 0) and np.array_equal(out[:len(want)], want)
+print("KIND", kind)
+""" % ROOT
+    kinds = set()
+    for simd in ("scalar", "avx2", "avx512"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BCD_HIP_UPLOAD_SIMD=simd), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-800:]
+        kinds.add(int(r.stdout.split("KIND")[1]))
+    assert 0 in kinds                                        # the scalar form always exists; the others when the host has them

@@ -1503,6 +1503,41 @@ def test_streamed_host_upload_equals_the_resident_path(hipctx, spike_factor):
 
 
 @pytest.mark.gpu
+def test_sparse_histogram_upload_is_lossless_and_falls_back_on_dense_images(hipctx, monkeypatch):
+    """bcd_hip_denoise_host on frames of >= 256 lines sends the histogram image without its zeros (bit-pattern test: -0.0f and denormals travel as
+    values), packed by host threads piece by piece and rebuilt by a kernel: the result must be bit-identical to the plain-copy path's inputs --
+    checked through the frame (same kernels afterwards) and through the byte counters -- and an image that is mostly non-zero is copied as it is"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H, S = 320, 288, 3
+    col, ns, hist, cov = core.synthetic_scene(W, H, 16, 11, 0.2, 0.01)
+    hist = hist.copy()
+    hist[5, 7, 3] = np.float32(-0.0)                      # (bit pattern 0x80000000: a value for the packer, zero for the arithmetic)
+    hist[100, 200, 59] = np.float32(1e-41)                # a denormal
+    prm = bh.default_params(m=1.0, random_order=1, seed=5)
+    got = hipctx.denoise_host(col, ns, hist, cov, S, prm)
+    raw, sent = hipctx.last_upload_bytes()
+    assert raw == hist.size * 4 and sent < 0.6 * raw      # 16 spp over 60 bins: most values are zero
+    want = hipctx.denoise(*dev(col, ns, hist, cov), S, prm).cpu().numpy()
+    assert rel_linf(got, want) < 1e-6                     # (the accumulators' atomics: ~1e-7)
+    monkeypatch.setenv("BCD_HIP_SPARSE_UPLOAD", "0")
+    plain = bh.Context(0)
+    try:
+        ref = plain.denoise_host(col, ns, hist, cov, S, prm)
+        assert plain.last_upload_bytes() == (raw, raw)
+    finally:
+        plain.close()
+    assert rel_linf(got, ref) < 1e-6
+    # a dense image (every bin of every pixel occupied): recognised on the first piece, copied as it is; same result as the resident path
+    dense = (hist + np.float32(0.25)).astype(np.float32)
+    got_d = hipctx.denoise_host(col, ns, dense, cov, S, prm)
+    assert hipctx.last_upload_bytes() == (raw, raw)
+    want_d = hipctx.denoise(*dev(col, ns, dense, cov), S, prm).cpu().numpy()
+    ok = np.isfinite(want_d)
+    assert np.array_equal(np.isfinite(got_d), ok) and rel_linf(np.where(ok, got_d, 0), np.where(ok, want_d, 0)) < 1e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sigma,spp", [(0.35, 32), (0.10, 32), (0.35, 8)])
 def test_textured_frame_masks_and_parity(hipctx, sigma, spp):
     """the band-limited texture scene (SyntheticScene pattern 1): distances spread continuously across the threshold, so the approximate
