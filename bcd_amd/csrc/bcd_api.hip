@@ -61,7 +61,7 @@ hipError_t bcd_launch_mark_deps(const uint32_t *, const int32_t *, uint8_t *, ui
 hipError_t bcd_launch_mark_round(const uint32_t *, uint8_t *, int, int, int, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_sum_counter_lines(const int *, int, int *, hipStream_t);
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
-hipError_t bcd_launch_jacobi27_batch(const float *, int, int *, int, float *, float *, hipStream_t);
+hipError_t bcd_launch_jacobi27_batch(const float *, int, int *, int, float *, float *, hipStream_t, float = 1e-12f, float * = nullptr);
 size_t bcd_bayes_lds_bytes(int w, int b);
 size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
 size_t bcd_bayes27_record_bytes();
