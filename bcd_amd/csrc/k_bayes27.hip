@@ -828,16 +828,16 @@ __device__ __attribute__((noinline)) void mfma27(float *out, int ldo, const floa
 }
 
 // ---- clampNegativeEigenValues (:606-630) from an eigensolver that stopped EARLY (round 4) ------------------------------------------------
-// The solver leaves A_k = V^T A V with a residual off-diagonal part E (off^2 <= 1e-8 diag^2 instead of 1e-12: five sweeps instead of six to
-// seven).  The positive part of A = V A_k V^T is V f(A_k) V^T, and f(D + E) = f(D) + E o Phi + O(|E|^2) with the divided differences
+// The solver leaves A_k = V^T A V with a residual off-diagonal part E (off^2 <= 2e-9 diag^2 instead of 1e-12: five sweeps instead of six to
+// seven for most matrices).  The positive part of A = V A_k V^T is V f(A_k) V^T, and f(D + E) = f(D) + E o Phi + O(|E|^2) with the divided differences
 //     Phi_ij = (f(d_i) - f(d_j)) / (d_i - d_j),   f = max(0, .):   1 if both eigenvalues are positive, 0 if neither is, d+ / (d+ - d-) across zero
 // (Daleckii-Krein; Phi in [0, 1], no small denominators: f is linear on either side of zero, so a pair on one side is exact whatever its gap).
 // What the correction cannot absorb is a residual between two estimates of opposite sign that are closer to each other than the residual is
 // large (error ~ |e_ij|, like the plain form): frames with ill-conditioned inverses feel the threshold -- BASELINE configs[3]'s 8-spp 4K frame is
-// 1.6e-5 from the oracle at 1e-8 (2.9e-6 with the plain rule at 1e-12, 2.9e-4 at 1e-6 corrected); the 32-spp frames stay at 4e-7 ... 9e-7.
+// 9.8e-6 from the oracle at 2e-9 (1.6e-5 at 1e-8; 2.9e-6 with the plain rule at 1e-12; 2.9e-4 at 1e-6 corrected); the 32-spp frames stay at 4e-7 ... 9e-7.
 // A per-pair stopping rule (every opposite-sign pair decoupled, loose bound on the rest) was built and measured out: in fp32 it needs the
 // sixth sweep as often as the plain rule does, and its test costs 5 % of a sweep.
-constexpr float JACOBI_CONV2_CORRECTED = 1e-8f; // off / diag <= 1e-4
+constexpr float JACOBI_CONV2_CORRECTED = 2e-9f; // off / diag <= 4.5e-5
 
 __device__ inline float pos_phi(float di, float dj)
 {

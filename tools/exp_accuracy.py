@@ -16,7 +16,7 @@ def run(name, W, H, spp, gseed, sigma, spikes, seed, S=3, pattern=0, m=1.0):
     ok = np.isfinite(want)
     e = float(np.max(np.abs(np.where(ok, got, 0) - np.where(ok, want, 0))) / np.max(np.abs(np.where(ok, want, 0))))
     print("%s: rel Linf vs oracle %.2e (full estimates scale0: %d)" % (name, e, ctx.stats(0).processed - ctx.stats(0).fallback), flush=True)
-run("quarter-hd noisy", 480, 270, 32, 1234, 0.35, 0.01, 1234)
-run("textured 640x360", 640, 360, 32, 1234, 0.35, 0.0, 3, pattern=1)
-run("720p m0", 1280, 720, 32, 1234, 0.35, 0.01, 1234, m=0.0)
+if "--only4k" not in sys.argv: run("quarter-hd noisy", 480, 270, 32, 1234, 0.35, 0.01, 1234)
+if "--only4k" not in sys.argv: run("textured 640x360", 640, 360, 32, 1234, 0.35, 0.0, 3, pattern=1)
+if "--only4k" not in sys.argv: run("720p m0", 1280, 720, 32, 1234, 0.35, 0.01, 1234, m=0.0)
 run("4k config3 (8 spp)", 3840, 2160, 8, 3, 0.15, 0.0, 17)
