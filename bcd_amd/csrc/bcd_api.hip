@@ -1204,6 +1204,23 @@ int bcd_hip_pixel_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_ns, i
     return BCD_HIP_OK;
 }
 
+int bcd_hip_scale_begin(bcd_hip_ctx *ctx, const float *d_cov, const float *d_ns, int W, int H, float *d_pixcov, float *d_sum, int32_t *d_count)
+{
+    if (!ctx || !d_cov || !d_ns || !d_pixcov || !d_sum || !d_count || W <= 0 || H <= 0) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
+    Work &wk = ctx->main;
+    constexpr size_t LINE_INTS = (size_t)BCD_CNT_LINES * BCD_CNT_STRIDE;
+    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+    RCCHK(ensure(ctx, wk.cnt_lines, ROUND_BATCH * LINE_INTS * sizeof(int)));
+    RCCHK(ensure(ctx, wk.work_q, BCD_WORK_INTS * sizeof(int32_t)));
+    HIPCHK(ctx, bcd_launch_pixel_cov_clear(d_cov, d_ns, (int64_t)W * H, d_pixcov, d_sum, d_count, wk.stream));
+    HIPCHK(ctx, bcd_launch_scale_begin((int *)wk.counters.p, 64, -1, -1, (int *)wk.cnt_lines.p, (int)(ROUND_BATCH * LINE_INTS), (int *)wk.work_q.p, BCD_WORK_INTS, wk.stream));
+    // ("clean" = zero because nobody has used it since: every user of these buffers takes the note and clears it)
+    wk.clean_flags = wk.clean_lines = wk.clean_dc = wk.clean_wq = true;
+    wk.planes.ready = false;
+    return BCD_HIP_OK;
+}
+
 int bcd_hip_similarity_masks(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int w, int b, float tau,
                              uint32_t *d_mask, int32_t *d_count)
 {

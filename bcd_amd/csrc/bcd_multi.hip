@@ -517,7 +517,8 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
     if (s > 0) MCHK(m, rank, hipStreamWaitEvent(st, m->ev_level[rank][s], 0));
     // the finest scale is the critical path of the band: the coarse scales' persistent estimate kernels keep to a quarter of the CU slots
     ECHK(m, rank, c, bcd_hip_set_cu_share(c, s == 0 || g.S == 1 ? 100 : 25));
-    ECHK(m, rank, c, bcd_hip_pixel_cov(c, cov, ns, W, rows, pixcov));
+    // per-pixel covariances, the accumulators cleared in the same pass, and every counter / flag / work queue of the chain in one launch
+    ECHK(m, rank, c, bcd_hip_scale_begin(c, cov, ns, W, rows, pixcov, sum, cnt));
     // Similar-patch masks with the production kernels; whether they are valid (inputs inside the guarded range, borderline list not
     // overflowed) comes back with the first host round trip that follows anyway -- the first marking batch -- instead of one of its own.
     const float tau = job.prm.hist_dist_threshold;
@@ -579,8 +580,6 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
     // halo lines are processed by their owner
     if (r0 > 0) MCHK(m, rank, hipMemsetAsync(state, 0, (size_t)r0 * W, st));
     if (r1 < rows) MCHK(m, rank, hipMemsetAsync(state + (size_t)r1 * W, 0, (size_t)(rows - r1) * W, st));
-    MCHK(m, rank, hipMemsetAsync(sum, 0, npix * 12, st));
-    MCHK(m, rank, hipMemsetAsync(cnt, 0, npix * 4, st));
     ECHK(m, rank, c, bcd_hip_bayes_accumulate(c, col, pixcov, mask, nsim, state, W, rows, w, b, job.prm.min_eigen_value, sum, cnt));
     // accumulator halos: the (b + w) lines written outside the owned band belong to the neighbours
     float *rx_us = (float *)B(bcd_hip_multi::RX_UP_S).p, *rx_ds = (float *)B(bcd_hip_multi::RX_DN_S).p;

@@ -222,6 +222,10 @@ int bcd_hip_last_upload_bytes(const bcd_hip_ctx *ctx, int64_t *hist_bytes, int64
 int bcd_hip_selftest_pack32(const uint32_t *in32, uint32_t *out64, uint32_t *bits, int *count);
 
 /* ---- stages (device pointers) -- exposed for parity tests and multi-GPU composition ------------ */
+/* The head of a scale's chain in two launches (the band driver's form of what bcd_hip_denoise does per scale): the per-pixel covariances
+ * (bcd_hip_pixel_cov) with the accumulators d_sum (3 floats per pixel) / d_count cleared in the same pass, and every counter, flag and work queue
+ * the following stage calls on this context start from (similarity masks, marking steps, the estimate) cleared in one launch instead of a fill each */
+int bcd_hip_scale_begin(bcd_hip_ctx *ctx, const float *d_covariances, const float *d_nsamples, int W, int H, float *d_pixcov, float *d_sum, int32_t *d_count);
 /* Denoiser::computePixelCovFromSampleCov   src/core/Denoiser.cpp:357-373 */
 int bcd_hip_pixel_cov(bcd_hip_ctx *ctx, const float *d_cov, const float *d_nsamples, int W, int H, float *d_out);
 /* DenoisingUnit::selectSimilarPatches for every main pixel   src/core/DenoisingUnit.cpp:196-219,336-386
