@@ -45,6 +45,33 @@ struct Geom27 {
 // FLAT instructions (aperture check, both memory counters, a fraction of the ds_read / ds_write rate).
 #define LDS_POINTER(p) __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)(p)))
 
+// divided difference of f = max(0, .) at two eigenvalue estimates (see pos_part_lds)
+__device__ inline float pos_phi(float di, float dj)
+{
+    const float hi = fmaxf(di, dj), lo = fminf(di, dj);
+    if (lo > 0.f) return 1.f;
+    if (hi <= 0.f) return 0.f;
+    return hi * __builtin_amdgcn_rcpf(hi - lo); // (hi > 0 >= lo: the denominator is >= hi)
+}
+
+// what the eigensolvers leave in the record next to the eigenvalue estimates and V: row r of E o Phi -- the residual off-diagonal part of
+// V^T A V times the divided differences of max(0, .) at the estimates, zero on the diagonal -- which the finish kernels turn into the
+// first-order correction V (E o Phi) V^T of the positive part (pos_part_lds).  row: the lane's row in LDS, diag: all 28 estimates in LDS.
+__device__ inline void jacobi_write_correction(float *out_row, const float *row, const float *diag, int r)
+{
+    const float d_r = diag[r];
+#pragma unroll
+    for (int q4 = 0; q4 < 7; ++q4) {
+        const float4 e4 = reinterpret_cast<const float4 *>(row)[q4], d4 = reinterpret_cast<const float4 *>(diag)[q4];
+        float4 o;
+        o.x = 4 * q4 == r ? 0.f : e4.x * pos_phi(d_r, d4.x);
+        o.y = 4 * q4 + 1 == r ? 0.f : e4.y * pos_phi(d_r, d4.y);
+        o.z = 4 * q4 + 2 == r ? 0.f : e4.z * pos_phi(d_r, d4.z);
+        o.w = 4 * q4 + 3 == r ? 0.f : e4.w * pos_phi(d_r, d4.w);
+        reinterpret_cast<float4 *>(out_row)[q4] = o;
+    }
+}
+
 __device__ inline float wsum(float v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -316,11 +343,13 @@ __global__ __launch_bounds__(64, 3) void k_jacobi27_batch(const float *Ain, int 
         }
         if (live) {
             if (isRow) eig[(size_t)item * KP + r] = Ah[jrow(r) + r];
-            if (isRow && Aout) { // what is left of the matrix (rows and columns in slot order, like eig and the columns of V)
-                float4 *o = reinterpret_cast<float4 *>(Aout + (size_t)item * (KP * JLD) + r * JLD);
-#pragma unroll
-                for (int q4 = 0; q4 < JLD / 4; ++q4) o[q4] = reinterpret_cast<const float4 *>(Ah + jrow(r))[q4];
-            }
+        }
+        if (Aout) { // (wave-uniform)
+            if (isRow) cs_h[r] = Ah[jrow(r) + r];
+            wave_sync();
+            if (isRow && live) jacobi_write_correction(Aout + (size_t)item * (KP * JLD) + r * JLD, Ah + jrow(r), cs_h, r);
+        }
+        if (live) {
             if (r < K) {
                 float4 *o = reinterpret_cast<float4 *>(Vout + (size_t)item * (KP * JLD) + r * JLD);
 #pragma unroll
@@ -595,11 +624,13 @@ __global__ __launch_bounds__(64, 3) void k_jacobi27_quads(const float *Ain, int 
         }
         if (live) {
             if (isRow) eig[(size_t)item * KP + r] = src[r];
-            if (isRow && Aout) { // what is left of the matrix (rows and columns in slot order, like eig and the columns of V)
-                float4 *o = reinterpret_cast<float4 *>(Aout + (size_t)item * (KP * JLD) + r * JLD);
-#pragma unroll
-                for (int q4 = 0; q4 < JLD / 4; ++q4) o[q4] = reinterpret_cast<const float4 *>(src)[q4];
-            }
+        }
+        if (Aout) { // (wave-uniform)
+            if (isRow) rot_h[r] = src[r];
+            wave_sync();
+            if (isRow && live) jacobi_write_correction(Aout + (size_t)item * (KP * JLD) + r * JLD, src, rot_h, r);
+        }
+        if (live) {
             if (r < K) {
                 float4 *o = reinterpret_cast<float4 *>(Vout + (size_t)item * (KP * JLD) + r * JLD);
 #pragma unroll
@@ -839,13 +870,6 @@ __device__ __attribute__((noinline)) void mfma27(float *out, int ldo, const floa
 // sixth sweep as often as the plain rule does, and its test costs 5 % of a sweep.
 constexpr float JACOBI_CONV2_CORRECTED = 2e-9f; // off / diag <= 4.5e-5
 
-__device__ inline float pos_phi(float di, float dj)
-{
-    const float hi = fmaxf(di, dj), lo = fminf(di, dj);
-    if (lo > 0.f) return 1.f;
-    if (hi <= 0.f) return 0.f;
-    return hi * __builtin_amdgcn_rcpf(hi - lo); // (hi > 0 >= lo: the denominator is >= hi)
-}
 
 // Bm (LD layout) <- V f(D) V^T + V (E o Phi) V^T; Mb: 28 x 28 scratch (JLD layout), eigs: 28 floats of scratch, V: LDS copy of the record's V (JLD
 // layout), recAk / recEig: the solver's output in the record (global memory)
@@ -855,10 +879,7 @@ __device__ __attribute__((noinline)) void pos_part_lds(float *Bm, float *Mb, flo
     LDS_POINTER(Bm); LDS_POINTER(Mb); LDS_POINTER(eigs); LDS_POINTER(V);
     if (lane < KP) eigs[lane] = recEig[lane];
     __syncthreads();
-    for (int e = lane; e < KP * JLD; e += 64) { // the correction matrix E o Phi (zero diagonal)
-        const int r = e / JLD, c = e - r * JLD;
-        Mb[e] = r == c ? 0.f : recAk[e] * pos_phi(eigs[r], eigs[c]);
-    }
+    for (int e = lane; e < KP * JLD; e += 64) Mb[e] = recAk[e]; // the correction matrix E o Phi (zero diagonal), as the eigensolver wrote it
     __syncthreads();
     if (lane < KP) eigs[lane] = fmaxf(0.f, eigs[lane]);
     __syncthreads();
@@ -1605,8 +1626,8 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
         // sched_barrier: left alone, the scheduler hoists every load of the item to the top and needs 264 registers -- 64 of them spilled
         // at three wavefronts per SIMD; in stage order the peak is about 110.)
         const float *recV = rec.V + (size_t)slot * MSZ, *recC = rec.C + (size_t)slot * MSZ, *recX = rec.aux + (size_t)slot * AUX27;
-        // row `idx` of V and of A_k = V^T A V (what the eigensolver left: eigenvalue estimates on the diagonal, a small residual E off it), and
-        // the eigenvalue estimates, at the columns r(s, h) = (s & 3) + 8 (s >> 2) + 4 h of the accumulator layout: four 16-byte loads each
+        // row `idx` of V and of the correction matrix E o Phi the eigensolver left in place of its input, and the eigenvalue estimates, at the
+        // columns r(s, h) = (s & 3) + 8 (s >> 2) + 4 h of the accumulator layout: four 16-byte loads each
         float vB[16], aK[16], dK[16];
         {
             const float *recAk = rec.A + (size_t)slot * MSZ;
@@ -1622,7 +1643,6 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
                 dK[4 * t] = te.x; dK[4 * t + 1] = te.y; dK[4 * t + 2] = te.z; dK[4 * t + 3] = te.w;
             }
         }
-        const float d_me = rec.eig[(size_t)slot * KP + min(idx, K - 1)];
         const float aux_n = recX[min(lane, P * 6 - 1)], aux_m = recX[P * 6 + min(lane, K - 1)];
         const int p = __builtin_amdgcn_readfirstlane(list[first_item + slot]);
         const int pr = p / W, pc = p - pr * W;
@@ -1654,23 +1674,20 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
         v16f acc;
         {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = Nop[e];
-#pragma unroll
-            for (int s_ = 0; s_ < 15; ++s_) {   // the main term as ever: positive multiples of v v^T on top of N, bitwise symmetric
-                const float v = col_ok ? vB[s_] : 0.f;
-                vB[s_] = v;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v * fmaxf(0.f, dK[s_]), v, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {      // the correction matrix E o Phi (zero diagonal), row idx at the columns r(e, h)
-                const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
-                aK[e] = (col_ok && c != idx) ? aK[e] * pos_phi(d_me, dK[e]) : 0.f;
+            for (int e = 0; e < 16; ++e) {      // (columns 27..31 of the operands: padding)
+                aK[e] = col_ok ? aK[e] : 0.f;     // row idx of the correction matrix E o Phi at the columns r(e, h), as the eigensolver wrote it
+                vB[e] = col_ok ? vB[e] : 0.f;
             }
             v16f U;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) U[e] = 0.f;
+            for (int e = 0; e < 16; ++e) { acc[e] = Nop[e]; U[e] = 0.f; }
+            // the main term as ever (positive multiples of v v^T on top of N, bitwise symmetric) and U = (E o Phi) V^T: two independent chains,
+            // interleaved so that each covers the other's latency
 #pragma unroll
-            for (int s_ = 0; s_ < 15; ++s_) U = __builtin_amdgcn_mfma_f32_32x32x2f32(aK[s_], vB[s_], U, 0, 0, 0);       // U = (E o Phi) V^T
+            for (int s_ = 0; s_ < 15; ++s_) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vB[s_] * fmaxf(0.f, dK[s_]), vB[s_], acc, 0, 0, 0);
+                U = __builtin_amdgcn_mfma_f32_32x32x2f32(aK[s_], vB[s_], U, 0, 0, 0);
+            }
 #pragma unroll
             for (int s_ = 0; s_ < 15; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vB[s_], U[s_], acc, 0, 0, 0);   // + V U
         }
