@@ -1060,6 +1060,11 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
     // Everything else needs the whole frame (pyramid, the marking order) and follows the last chunk.
     const int b = prm->search_radius, tile = bcd_pairdist_rw_tile_lines();
     const bool stream_in = ctx->stream_uploads && fast_similarity_applies(ctx, D, prm->patch_radius, prm->hist_dist_threshold) && H >= 256;
+    // BCD_HIP_HOST_TIMING=1: where the host-buffer call spends its time, on stderr (diagnostic)
+    static const bool host_timing = [] { const char *e = getenv("BCD_HIP_HOST_TIMING"); return e && e[0] == '1'; }();
+    const auto ht0 = std::chrono::steady_clock::now();
+    auto ht_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count(); };
+    double ht_enq = 0.0, ht_up = 0.0, ht_dn = 0.0;
     if (!stream_in) {
         for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         if (prefilter) HIPCHK(ctx, bcd_launch_spike(d[0], d[1], d[2], d[3], W, H, D, opt->spike_factor, d[5], d[6], d[7], d[8], ctx->stream));
@@ -1152,6 +1157,8 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
             }
         }
         if (sparse) bcd_sparse_frame_bytes(ctx->sparse, &ctx->upload_raw_bytes, &ctx->upload_sent_bytes);
+        ht_enq = ht_ms(); // every piece packed and enqueued
+        if (host_timing) { HIPCHK(ctx, hipStreamSynchronize(ctx->upload_stream)); ht_up = ht_ms(); } // (timing only: the last piece has arrived)
         if (side) { // colours and covariances have been enqueued by now (the helper thread is joined), the frame's kernels wait for their arrival
             side_copy.join();
             HIPCHK(ctx, side_rc);
@@ -1167,8 +1174,12 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
     }
     // checkAndPutToZeroNegativeInfNaNValues (src/cli/main.cpp:389-420, 470)
     if (opt && opt->zero_bad_values) HIPCHK(ctx, bcd_launch_zero_bad(d[4], (int64_t)np * 3, ctx->stream));
+    if (host_timing) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ht_dn = ht_ms(); }
     HIPCHK(ctx, hipMemcpyAsync(h_out, d[4], sz[4] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (host_timing)
+        fprintf(stderr, "bcd_hip_denoise_host %dx%d: pieces packed + enqueued at %.2f ms, last piece on the device at %.2f, frame denoised at %.2f, result on the host at %.2f ms\n",
+                W, H, ht_enq, ht_up, ht_dn, ht_ms());
     return BCD_HIP_OK;
 }
 
