@@ -343,17 +343,29 @@ hipError_t bcd_sparse_upload(BcdSparseUploader *u, float *dst, const float *src,
     if (n == 0) return hipSuccess;
     size_t done = 0;
     hipError_t e;
-    if (!u->dense && (e = u->submit(src, std::min(n, SP_PIECE))) != hipSuccess) return e;
+    bool packing = false; // a job on buf[cur] is in flight (its threads read the caller's buffer: never return while it runs)
+    auto settle = [&](hipError_t rc) {
+        if (packing) { Piece &p = u->buf[u->cur]; u->drain(&p); std::unique_lock<std::mutex> lk(u->mu); u->cv_done.wait(lk, [&] { return p.remaining.load() == 0; }); }
+        return rc;
+    };
+    if (!u->dense) {
+        if ((e = u->submit(src, std::min(n, SP_PIECE))) != hipSuccess) return e;
+        packing = true;
+    }
     while (done < n) {
         const size_t len = std::min(n - done, SP_PIECE);
         if (u->dense) { // (found out on an earlier piece)
             u->raw_bytes += (long long)(n - done) * 4; u->sent_bytes += (long long)(n - done) * 4;
-            return hipMemcpyAsync(dst + done, src + done, (n - done) * 4, hipMemcpyHostToDevice, st);
+            return settle(hipMemcpyAsync(dst + done, src + done, (n - done) * 4, hipMemcpyHostToDevice, st));
         }
         // this piece is being packed into buf[cur]; finish it and send it, then start on the next one -- whose packing overlaps this piece's transfer
+        packing = false; // (flush waits for the job itself)
         if ((e = u->flush(dst + done, st)) != hipSuccess) return e;
         done += len;
-        if (done < n && !u->dense && (e = u->submit(src + done, std::min(n - done, SP_PIECE))) != hipSuccess) return e;
+        if (done < n && !u->dense) {
+            if ((e = u->submit(src + done, std::min(n - done, SP_PIECE))) != hipSuccess) return e;
+            packing = true;
+        }
     }
-    return hipSuccess;
+    return settle(hipSuccess);
 }
