@@ -37,6 +37,8 @@ void bcd_sparse_destroy(BcdSparseUploader *);
 void bcd_sparse_frame_begin(BcdSparseUploader *);
 void bcd_sparse_frame_bytes(const BcdSparseUploader *, long long *, long long *);
 hipError_t bcd_sparse_upload(BcdSparseUploader *, float *, const float *, size_t, hipStream_t);
+int bcd_pairdist_nz_supported(int D, int b);
+hipError_t bcd_launch_pairdist_nz(const float *, const float *, int, int, int, int, void *, uint8_t *, long long, long long, int *, float, int, hipStream_t, unsigned long long *prof = nullptr);
 hipError_t bcd_launch_pairdist_rw_counting(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_spike_rows(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *, float *, float *, int, int,
                                  hipStream_t);
@@ -1576,6 +1578,83 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
     (void)hipFree(T2);
     (void)hipFree(C2);
     if (rc != BCD_HIP_OK) set_err(ctx, "approximate-distance self-test failed to run");
+    return rc;
+}
+
+// self-test + timing of the own-list distance kernel (k_similarity_nz.hip) against the exact planes and against the dense approximate kernel
+int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int search_radius, float tau, int variant, int reps,
+                                 float *max_rel_dev, int64_t *count_mismatches, int *flags, float *ms_nz, float *ms_nz_plane_major, float *ms_dense, int64_t *prof7)
+{
+    if (!ctx || !d_hist || !d_ns || !max_rel_dev || !count_mismatches || !flags || !ms_nz || !ms_nz_plane_major || !ms_dense || W <= 0 || H <= 0 || reps < 1) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
+    if (!bcd_pairdist_nz_supported(D, search_radius)) { set_err(ctx, "no own-list kernel for this depth / search radius"); return BCD_HIP_EUNSUPPORTED; }
+    Work &wk = ctx->main;
+    const size_t npix = (size_t)W * H;
+    const int nd = bcd_delta_count(search_radius);
+    RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
+    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
+    float *T2 = nullptr;
+    uint8_t *C2 = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&T2, npix * nd * sizeof(float)));
+    if (hipMalloc((void **)&C2, npix * nd) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = BCD_HIP_OK;
+    do {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+        int *d_flag = (int *)wk.counters.p + 40;
+        unsigned int *d_res = reinterpret_cast<unsigned int *>((int32_t *)wk.counters.p + 32);
+        if (hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream) != hipSuccess || hipMemsetAsync(d_res, 0, 2 * sizeof(unsigned int), wk.stream) != hipSuccess ||
+            hipMemsetAsync(wk.T.p, 0, npix * nd * sizeof(float), wk.stream) != hipSuccess || hipMemsetAsync(wk.Cn.p, 0, npix * nd, wk.stream) != hipSuccess ||
+            hipMemsetAsync(T2, 0, npix * nd * sizeof(float), wk.stream) != hipSuccess || hipMemsetAsync(C2, 0, npix * nd, wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+        // own-list planes in the plane-major layout against the exact planes (compiler's division, general formula)
+        if (bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, 1, (long long)npix, d_flag, tau, variant, wk.stream) != hipSuccess ||
+            bcd_launch_pairdist(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, d_flag + 1, 0.f, wk.stream) != hipSuccess ||
+            bcd_launch_max_rel_dev((const float *)wk.T.p, T2, (const uint8_t *)wk.Cn.p, C2, W, H, search_radius, d_res, wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+        unsigned int h[2] = { 0u, 0u };
+        int flag = 0;
+        if (hipMemcpyAsync(h, d_res, sizeof(h), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
+            hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+        memcpy(max_rel_dev, &h[0], sizeof(float));
+        *count_mismatches = (int64_t)h[1];
+        *flags = flag;
+        // timing: own-list kernel, pixel-major planes (into the scratch planes) and plane-major; the dense kernel
+        float best[3] = { -1.f, -1.f, -1.f };
+        for (int which = 0; which < 3 && rc == BCD_HIP_OK; ++which)
+            for (int r = 0; r < reps + 1; ++r) {
+                hipError_t e = hipEventRecord(e0, wk.stream);
+                if (e == hipSuccess) {
+                    if (which == 0) e = bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, T2, C2, (long long)nd, 1, d_flag, tau, variant, wk.stream);
+                    else if (which == 1) e = bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, 1, (long long)npix, d_flag, tau, variant, wk.stream);
+                    else e = bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag + 1, -1.f, wk.stream);
+                }
+                if (e != hipSuccess || hipEventRecord(e1, wk.stream) != hipSuccess || hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (r > 0 && (best[which] < 0.f || ms < best[which])) best[which] = ms;
+            }
+        *ms_nz = best[0]; *ms_nz_plane_major = best[1]; *ms_dense = best[2];
+        if (prof7 && rc == BCD_HIP_OK) { // the counting instantiation (second of two launches; its own duration in microseconds in prof7[6])
+            unsigned long long *d_prof = reinterpret_cast<unsigned long long *>((int32_t *)wk.counters.p + 48); // (words 48..59)
+            unsigned long long hp[6] = { 0, 0, 0, 0, 0, 0 };
+            float ms = 0.f;
+            for (int r = 0; r < 2 && rc == BCD_HIP_OK; ++r)
+                if (hipMemsetAsync(d_prof, 0, sizeof(hp), wk.stream) != hipSuccess || hipEventRecord(e0, wk.stream) != hipSuccess ||
+                    bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, T2, C2, (long long)nd, 1, d_flag, tau, variant, wk.stream, d_prof) != hipSuccess ||
+                    hipEventRecord(e1, wk.stream) != hipSuccess ||
+                    hipMemcpyAsync(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost, wk.stream) != hipSuccess || hipStreamSynchronize(wk.stream) != hipSuccess) rc = BCD_HIP_EDEVICE;
+            if (rc != BCD_HIP_OK) break;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            for (int i = 0; i < 6; ++i) prof7[i] = (int64_t)hp[i];
+            prof7[6] = (int64_t)(ms * 1000.f);
+        }
+    } while (false);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(T2);
+    (void)hipFree(C2);
+    if (rc != BCD_HIP_OK) set_err(ctx, "own-list distance self-test failed to run");
     return rc;
 }
 

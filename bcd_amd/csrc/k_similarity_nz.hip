@@ -1,0 +1,363 @@
+// k_similarity_nz.hip -- pair-distance planes over the OWN pixel's non-zero bins (round 5).
+//
+// The reference's bin rule (src/core/DenoisingUnit.cpp:379-383) skips a bin when b1 + b2 <= 1.  For a bin with b1 == 0 the term is
+// therefore (n1 b2)^2 / (n1 n2 b2) = (n1/n2) b2 if b2 > 1 and nothing otherwise -- a closed form that needs no pass over the bin.  With
+//     NZ(x) = { k : b1_k > 0 },   S(y) = sum_k [b2_k > 1] b2_k,   C1(y) = #{ k : b2_k > 1 }     (S, C1: one float + one int per pixel)
+// the pair sums of k_similarity_fast.hip become
+//     T(x,y) = (n2/n1) sum_{k in NZ(x), b1+b2>1} (b1 - (n1/n2) b2)^2 / (b1 + b2)  +  (n1/n2) ( S(y) - sum_{k in NZ(x), b2>1} b2_k )
+//     C(x,y) = #{ k in NZ(x) : b1+b2 > 1, b2 <= 1 } + C1(y)                  (b2 > 1 implies b1 + b2 > 1)
+// so the loop runs over the own pixel's list only: 18.8 bins instead of 60 on the noisy bench frame, 9.3 on a clean one, 78 % of
+// them live (tools/exp_nz_slots.py).  The list must be wave-uniform to pay, hence the lane mapping:
+//   A item: ONE own pixel, lane l = displacement 13 dl + dc = l + 1 (the first 64 of the 84 half-plane displacements of b = 6); the
+//           bin index and b1 are scalars (b1 by a scalar load), the neighbour bin is one ds_read_b32 at pixel stride 61 (conflict-free:
+//           the bank is 29 (13 dl + dc) mod 32 when the line stride is 13 * 61 mod 32).
+//   B item: THREE horizontally adjacent own pixels x the remaining 20 displacements (lanes 0..59) + their self pairs (lanes 60..62);
+//           the loop runs over the union of the three lists (24.8 bins), b1 is a second ds_read_b32.
+// A workgroup (16 wavefronts, one per CU: 157 KB of LDS) stages the histograms of a 24 x 11 tile of own pixels and of the 6 lines
+// below / 6 columns either side once, derives S and C1 of every staged pixel, and its wavefronts then draw items from an LDS counter
+// (B items first: they are the longer ones).  No rolling window and no barrier between items.
+//
+// T is still the approximate plane of k_similarity_fast.hip (rcp + fma, any summation order, binary16 store), consumed by the same
+// mask / verify kernels; C is exact.  The subtraction S - A2 adds an ABSOLUTE error to that file's relative bound.  With u = 2^-24,
+// L = |list|, t = d^2 / s:  s' = s (1 + e), |e| <= u;  d' = RN(b1 - rho' b2) with rho' = rho (1 + 3u) (rcp + product; rho' == 1 exactly
+// for equal counts), so |d' - d| <= u |d| + 3u rho b2;  the term RN(d'^2) rcp(s') entering the fma carries (1 + 4u);  all terms of A1,
+// A2 and S are >= 0 and each is a sequential sum of <= L, <= L and C1 terms.  Together
+//     |T' - T*| <= u [ (L + 10) q A1 + (C1 + 4) rho S + (L + 4) rho A2 + T ]  +  [n1 != n2] 6u max(1, rho) B(y),   B(y) = sum_k b2_k
+// (the last term bounds q * 6u rho max(1, rho) sum_live b2: b2 |d| / s <= max(1, rho) b2).  The kernel CHECKS, per pair, that this stays
+// below the part of the band the relative errors leave free,
+//     bound <= NZ_ABS_MARGIN * tau * C        (2^-12: the band 2^-10 = 9.8e-4 minus binary16 4.9e-4 minus the fp32 relative part 2e-5 is > 2^-12)
+// and a pair that fails raises range_flag bit 2: the host repeats the scale with the dense kernel.  On the bench frames the bound is
+// ~1e-4 against a limit of ~4e-3 at scale 0; coarse scales of noisy frames (512 samples per pixel, S ~ 1500) come close to the limit --
+// those have long lists and belong to the dense kernel anyway.  C == 0 implies C1 = 0 and no live bin: S = A1 = A2 = 0, T == 0 exactly.
+#include "bcd_common.h"
+#include <hip/hip_fp16.h>
+#include <atomic>
+#include <algorithm>
+
+namespace {
+
+constexpr int NZ_B = 6, NZ_SIDE = 2 * NZ_B + 1;
+constexpr int NZ_TC = 24, NZ_TR = 11;                      // own pixels of a tile (columns a multiple of 3: B items)
+constexpr int NZ_NCS = NZ_TC + 2 * NZ_B, NZ_NLS = NZ_TR + NZ_B; // staged columns / lines
+constexpr int NZ_THREADS = 1024;
+constexpr int NZ_NB = (NZ_TC / 3) * NZ_TR, NZ_NA = NZ_TC * NZ_TR, NZ_ITEMS = NZ_NA + NZ_NB;
+constexpr float NZ_BIN_MAX = 1048576.f, NZ_N_MIN = 0.0009765625f, NZ_N_MAX = 65536.f; // the guarded range of k_similarity.hip
+constexpr float NZ_ABS_MARGIN = 0.000244140625f; // 2^-12
+
+constexpr int nz_row_stride(int ps)
+{
+    int rs = NZ_NCS * ps;
+    while (((rs - NZ_SIDE * ps) & 31) != 0) ++rs; // line stride = 13 pixel strides (mod 32 banks): lane l of an A item hits bank 29 (l + 1)
+    return rs;
+}
+
+template <int D> struct NzLayout {
+    static_assert(D % 4 == 0, "whole float4 groups");
+    static constexpr int PS = D + 1;               // odd pixel stride (dwords)
+    static constexpr int RS = nz_row_stride(PS);
+    static constexpr int Q = D / 4;
+    static constexpr int NPIX = NZ_NLS * NZ_NCS;
+    static constexpr int RING = NZ_NLS * RS;       // dwords
+    static constexpr int LDS_DWORDS = RING + 4 * NPIX + 4;
+    static constexpr int NLOAD = (NPIX * Q + NZ_THREADS - 1) / NZ_THREADS; // float4 per thread of the staged tile
+};
+
+__device__ inline int nz_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// One (pixel pair) lane of an item: the loop over the wave-uniform bin list `m`.  b1 comes (OWN = 0) from the own pixel's histogram in
+// global memory by a scalar load, (OWN = 1) per lane from LDS (B items: three own pixels), (OWN = 2) from lane k of `own_v` (v_readlane).
+// The next bin's operands travel while the current one is evaluated; two copies of the body alternate the registers.
+template <int OWN, int BODY, bool RHO1>
+__device__ inline void nz_pair_loop(unsigned long long m, const float *__restrict__ own_g, const float *own_l, float own_v, const float *nb, float rho,
+                                    float &A1_, float &A2_, int &Cm_)
+{
+    float A1 = 0.f, A2 = 0.f;
+    int Cm = 0;
+    auto own = [&](int k) __attribute__((always_inline)) {
+        if (OWN == 0) return own_g[k];
+        if (OWN == 1) return own_l[k];
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, own_v), k));
+    };
+    auto eval = [&](float b1, float b2) __attribute__((always_inline)) {
+        const float s = b1 + b2;
+        if (BODY == 0) {
+            if (s > 1.f) { // DenoisingUnit.cpp:379
+                asm volatile(""); // keep the branch (exec mask): no if-conversion into selects
+                const float d = RHO1 ? b1 - b2 : fmaf(-rho, b2, b1);
+                A1 = fmaf(d * d, __builtin_amdgcn_rcpf(s), A1);
+                const bool big = b2 > 1.f; // the closed form counted this bin: take it back
+                A2 += big ? b2 : 0.f;
+                Cm += big ? 0 : 1;
+            }
+        } else { // straight-line: every lane evaluates, selects keep the dead ones out (s <= 1: r = 0; b2 > 1 implies s > 1)
+            const bool live = s > 1.f, big = b2 > 1.f;
+            const float r = live ? __builtin_amdgcn_rcpf(s) : 0.f;
+            const float d = RHO1 ? b1 - b2 : fmaf(-rho, b2, b1);
+            A1 = fmaf(d * d, r, A1);
+            A2 += big ? b2 : 0.f;
+            Cm += (live && !big) ? 1 : 0;
+        }
+    };
+    if (m != 0ull) {
+        int k = __builtin_ctzll(m);
+        m &= m - 1;
+        float b1 = own(k), b2 = nb[k];
+#pragma unroll 2
+        while (m != 0ull) {
+            k = __builtin_ctzll(m);
+            m &= m - 1;
+            const float b1n = own(k), b2n = nb[k];
+            eval(b1, b2);
+            b1 = b1n; b2 = b2n;
+        }
+        eval(b1, b2);
+    }
+    A1_ = A1; A2_ = A2; Cm_ = Cm;
+}
+
+template <int D, bool READLANE, int BODY, bool PROF>
+__global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H,
+                                                               __half *__restrict__ T, uint8_t *__restrict__ Cn, long long t_ps, long long t_ds,
+                                                               int *range_flag, float tau, int tiles_x, int ntiles, unsigned long long *prof)
+{
+    using L = NzLayout<D>;
+    constexpr int PS = L::PS, RS = L::RS, Q = L::Q, NPIX = L::NPIX;
+    extern __shared__ float nz_lds[];
+    float *ring = nz_lds;
+    float *s_n = ring + L::RING;
+    float *s_S = s_n + NPIX;
+    float *s_B = s_S + NPIX;
+    int *s_C1 = reinterpret_cast<int *>(s_B + NPIX);
+    int *s_counter = s_C1 + NPIX;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    // Persistent workgroup (one per CU).  The tiles are dealt in row-major order, a contiguous share per XCD (workgroup w runs on XCD w & 7), and
+    // the workgroups of an XCD take consecutive tiles of that share: the ~32 tiles in flight on an XCD are neighbours in a tile row and find the
+    // columns they share in that XCD's L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3; // (gridDim.x is a multiple of 8)
+    const int tq = ntiles / 8, trem = ntiles - 8 * tq;
+    const int share_begin = xcd * tq + min(xcd, trem), share_end = share_begin + tq + (xcd < trem ? 1 : 0);
+
+    // per-thread share of a tile's staged histograms: NLOAD 16-byte groups (LDS offsets do not depend on the tile)
+    float4 v[L::NLOAD];
+    float nv = -1.f;
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {
+        const int c0 = (tile % tiles_x) * NZ_TC, r0 = (tile / tiles_x) * NZ_TR;
+#pragma unroll
+        for (int u = 0; u < L::NLOAD; ++u) {
+            const int j = tid + u * NZ_THREADS;
+            const int px = j / Q, q = j - px * Q, line = px / NZ_NCS, col = px - line * NZ_NCS;
+            const int gr = r0 + line, gc = c0 - NZ_B + col;
+            const bool in = j < NPIX * Q && gr < H && gc >= 0 && gc < W;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in) v[u] = reinterpret_cast<const float4 *>(hist)[((size_t)gr * W + gc) * Q + q];
+        }
+        nv = -1.f; // (outside the image)
+        if (tid < NPIX) {
+            const int line = tid / NZ_NCS, col = tid - line * NZ_NCS, gr = r0 + line, gc = c0 - NZ_B + col;
+            if (gr < H && gc >= 0 && gc < W) nv = ns[(size_t)gr * W + gc];
+        }
+    };
+    long long pc[5] = { 0, 0, 0, 0, 0 }, slots = 0;
+    bool imprecise = false, tile_uni = false;
+    int tile = share_begin + slot;
+    if (tile < share_end) prefetch(tile);
+    for (; tile < share_end; tile += per_xcd) {
+    const int c0 = (tile % tiles_x) * NZ_TC, r0 = (tile / tiles_x) * NZ_TR;
+    const long long t0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    // ---- the prefetched tile -> LDS: lines r0 .. r0 + TR + 5, columns c0 - 6 .. c0 + TC + 5 (zeros outside the image) ----
+    {
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < L::NLOAD; ++u) {
+            const int j = tid + u * NZ_THREADS;
+            const int px = j / Q, q = j - px * Q, line = px / NZ_NCS, col = px - line * NZ_NCS;
+            if (j < NPIX * Q) {
+                float *p = ring + line * RS + col * PS + 4 * q;
+                p[0] = v[u].x; p[1] = v[u].y; p[2] = v[u].z; p[3] = v[u].w;
+            }
+            const float lo = fminf(fminf(v[u].x, v[u].y), fminf(v[u].z, v[u].w)), hi = fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w));
+            // (NaN: fminf / fmaxf drop it, so test the values themselves too)
+            bad = bad || !(lo >= 0.f && hi <= NZ_BIN_MAX) || !(v[u].x == v[u].x && v[u].y == v[u].y && v[u].z == v[u].z && v[u].w == v[u].w);
+        }
+        const bool in_image = !(nv == -1.f); // (a NaN count is inside, and bad)
+        if (tid < NPIX) { bad = bad || (in_image && !(nv >= NZ_N_MIN && nv <= NZ_N_MAX)); s_n[tid] = in_image ? nv : 1.f; }
+        if (tid == 0) *s_counter = 0;
+        if (__syncthreads_or(bad) && tid == 0) atomicOr(range_flag, 1);
+        // one sample count on the whole staged tile (pixels outside the image have no pairs that are kept): rho = q = 1, no loads
+        tile_uni = __syncthreads_and(tid >= NPIX || !in_image || nv == s_n[NZ_B]) != 0; // (s_n[B]: the tile's first own pixel, always inside)
+    }
+    const long long t1 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    // ---- S(y), C1(y) of every staged pixel ----
+    if (tid < NPIX) {
+        const int line = tid / NZ_NCS, col = tid - line * NZ_NCS;
+        const float *p = ring + line * RS + col * PS;
+        float S = 0.f, Bs = 0.f;
+        int C1 = 0;
+#pragma unroll 12
+        for (int k = 0; k < D; ++k) {
+            const float v = p[k];
+            Bs += v;
+            if (v > 1.f) { S += v; ++C1; }
+        }
+        s_S[tid] = S;
+        s_B[tid] = Bs;
+        s_C1[tid] = C1;
+    }
+    __syncthreads();
+    // the next tile's histograms travel while this one is evaluated
+    if (tile + per_xcd < share_end) prefetch(tile + per_xcd);
+    const long long t2 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    // ---- per-lane displacement tables ----
+    // A: lane l <-> 13 dl + dc = l + 1
+    const int ipA = lane + 1, dlA = (ipA + NZ_B) / NZ_SIDE, dcA = ipA - NZ_SIDE * dlA;
+    const int offA = dlA * RS + dcA * PS, spA = dlA * NZ_NCS + dcA;
+    // B: lanes 0..59 = own pixel j = l / 20, displacement 65 + l % 20; lanes 60..62 = self pair of own pixel l - 60; lane 63 idle
+    const int jB = lane < 60 ? lane / 20 : min(lane - 60, 2);
+    const int ipB = lane < 60 ? 65 + (lane - 20 * jB) : 0;
+    const int dlB = (ipB + NZ_B) / NZ_SIDE, dcB = ipB - NZ_SIDE * dlB; // (ipB == 0: dl = dc = 0)
+    const int ownB = jB * PS, offB = ownB + dlB * RS + dcB * PS, spB = jB + dlB * NZ_NCS + dcB;
+    const float margin = NZ_ABS_MARGIN * tau * 16777216.f; // (the bound is formed in units of u = 2^-24)
+    const unsigned int eA = (unsigned int)ipA * (unsigned int)t_ds, eB = (unsigned int)ipB * (unsigned int)t_ds; // (plane elements fit 32 bits: checked by the launcher)
+
+    auto grab = [&]() __attribute__((always_inline)) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(s_counter, 1);
+        return nz_uniform(v);
+    };
+    int it = grab();
+    while (it < NZ_ITEMS) {
+        const int next = grab();
+        if (it >= NZ_NB) {
+            // ---- A item: one own pixel, displacements 1..64 ----
+            const int a = it - NZ_NB, orow = a / NZ_TC, ocol = a - orow * NZ_TC;
+            const int gr = r0 + orow, gc = c0 + ocol;
+            if (gr < H && gc < W) {
+                const int o = orow * RS + (ocol + NZ_B) * PS, spo = orow * NZ_NCS + ocol + NZ_B;
+                const float hv = lane < D ? ring[o + lane] : 0.f;
+                const float Sy = s_S[spo + spA];
+                const int C1y = s_C1[spo + spA];
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hv > 0.f);
+                const unsigned int pix = (unsigned int)(gr * W + gc);
+                float A1, A2, rho = 1.f, qq = 1.f, extra = 0.f;
+                int Cm;
+                if (PROF) slots += __builtin_popcountll(m);
+                if (tile_uni)
+                    nz_pair_loop<READLANE ? 2 : 0, BODY, true>(m, hist + (size_t)pix * D, nullptr, hv, ring + o + offA, 1.f, A1, A2, Cm);
+                else {
+                    const float n1 = s_n[spo], n2 = s_n[spo + spA];
+                    if (n1 != n2) { rho = n1 * __builtin_amdgcn_rcpf(n2); qq = n2 * __builtin_amdgcn_rcpf(n1); extra = 6.f * fmaxf(1.f, rho) * s_B[spo + spA]; }
+                    nz_pair_loop<READLANE ? 2 : 0, BODY, false>(m, hist + (size_t)pix * D, nullptr, hv, ring + o + offA, rho, A1, A2, Cm);
+                }
+                const int C = Cm + C1y, Ln = __builtin_popcountll(m);
+                const float Tv = fmaf(qq, A1, rho * (Sy - A2));
+                const int nc = gc + dcA, nr = gr + dlA;
+                if (nc >= 0 && nc < W && nr < H) {
+                    // (the bound of the header with the larger of its two factors on every term)
+                    const float bound = fmaf((float)(max(Ln, C1y) + 10), fmaf(qq, A1, rho * (Sy + A2)), Tv + extra);
+                    imprecise = imprecise || bound > margin * (float)C;
+                    const unsigned int e = eA + pix * (unsigned int)t_ps;
+                    T[e] = __float2half_rn(fmaxf(Tv, 0.f));
+                    Cn[e] = (uint8_t)C;
+                }
+            }
+        } else {
+            // ---- B item: three own pixels, displacements 65..84 and the self pairs ----
+            const int orow = it / (NZ_TC / 3), ocol = 3 * (it - orow * (NZ_TC / 3));
+            const int gr = r0 + orow, gc0 = c0 + ocol;
+            if (gr < H && gc0 < W) {
+                const int o = orow * RS + (ocol + NZ_B) * PS, spo = orow * NZ_NCS + ocol + NZ_B;
+                const float h0 = lane < D ? ring[o + lane] : 0.f, h1 = lane < D ? ring[o + PS + lane] : 0.f, h2 = lane < D ? ring[o + 2 * PS + lane] : 0.f;
+                const float Sy = s_S[spo + spB];
+                const int C1y = s_C1[spo + spB];
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(h0 > 0.f || h1 > 0.f || h2 > 0.f);
+                const int gc = gc0 + jB;
+                const unsigned int pix = (unsigned int)(gr * W + gc);
+                float A1, A2, rho = 1.f, qq = 1.f, extra = 0.f;
+                int Cm;
+                if (PROF) slots += __builtin_popcountll(m);
+                if (tile_uni)
+                    nz_pair_loop<1, BODY, true>(m, nullptr, ring + o + ownB, 0.f, ring + o + offB, 1.f, A1, A2, Cm);
+                else {
+                    const float n1 = s_n[spo + jB], n2 = s_n[spo + spB];
+                    if (n1 != n2) { rho = n1 * __builtin_amdgcn_rcpf(n2); qq = n2 * __builtin_amdgcn_rcpf(n1); extra = 6.f * fmaxf(1.f, rho) * s_B[spo + spB]; }
+                    nz_pair_loop<1, BODY, false>(m, nullptr, ring + o + ownB, 0.f, ring + o + offB, rho, A1, A2, Cm);
+                }
+                const int C = Cm + C1y, Ln = __builtin_popcountll(m);
+                const float Tv = fmaf(qq, A1, rho * (Sy - A2));
+                const int nc = gc + dcB, nr = gr + dlB;
+                if (lane < 63 && gc < W && nc >= 0 && nc < W && nr < H) {
+                    const float bound = fmaf((float)(max(Ln, C1y) + 10), fmaf(qq, A1, rho * (Sy + A2)), Tv + extra);
+                    imprecise = imprecise || bound > margin * (float)C;
+                    const unsigned int e = eB + pix * (unsigned int)t_ps;
+                    T[e] = __float2half_rn(fmaxf(Tv, 0.f));
+                    Cn[e] = (uint8_t)C;
+                }
+            }
+        }
+        it = next;
+    }
+    if (PROF) { // (measurement only) cycles: staging, S pass, wavefronts inside the item loop, item phase of the workgroup x wavefronts; bin slots
+        const long long t3 = (long long)__builtin_readcyclecounter();
+        __syncthreads();
+        const long long t4 = (long long)__builtin_readcyclecounter();
+        pc[0] += t1 - t0; pc[1] += t2 - t1; pc[2] += t3 - t2; pc[3] += (t4 - t2) * (NZ_THREADS / 64); pc[4] += t4 - t0;
+    } else
+        __syncthreads(); // every wavefront is done with the tile before the next one overwrites it
+    }
+    if (__builtin_amdgcn_ballot_w64(imprecise) != 0ull && lane == 0) atomicOr(range_flag, 4);
+    if (PROF) {
+        if (lane == 0) { atomicAdd(prof + 2, (unsigned long long)pc[2]); atomicAdd(prof + 5, (unsigned long long)slots); }
+        if (tid == 0) {
+            atomicAdd(prof + 0, (unsigned long long)pc[0]); atomicAdd(prof + 1, (unsigned long long)pc[1]);
+            atomicAdd(prof + 3, (unsigned long long)pc[3]); atomicAdd(prof + 4, (unsigned long long)pc[4]);
+        }
+    }
+}
+
+} // namespace
+
+int bcd_pairdist_nz_supported(int D, int b) { return b == NZ_B && (D == 60 || D == 36 || D == 24); }
+
+// T / Cn element (pixel, displacement index i) lives at i * t_ds + pixel * t_ps: (1, W*H) is the plane-major layout of k_pairdist_rw,
+// (stride >= 85, 1) a pixel-major one.  variant: bit 0 = own bins by v_readlane instead of scalar loads, bit 1 = straight-line bin body
+hipError_t bcd_launch_pairdist_nz(const float *hist, const float *ns, int W, int H, int D, int b, void *T, uint8_t *Cn, long long t_ps, long long t_ds,
+                                  int *d_range_flag, float tau, int variant, hipStream_t st, unsigned long long *prof = nullptr)
+{
+    if (!bcd_pairdist_nz_supported(D, b) || (long long)W * H * (NZ_SIDE * NZ_B + NZ_B + 1) >= (1ll << 31)) return hipErrorInvalidValue;
+    const int tx = (W + NZ_TC - 1) / NZ_TC, ty = (H + NZ_TR - 1) / NZ_TR;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    // one persistent workgroup per CU (157 KB of LDS each), a multiple of the 8 XCDs
+    static std::atomic<int> cus_of[64];
+    int cus = (dev >= 0 && dev < 64) ? cus_of[dev].load() : 0;
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev < 0 ? 0 : dev) != hipSuccess || cus <= 0) cus = 256;
+        if (dev >= 0 && dev < 64) cus_of[dev].store(cus);
+    }
+    const int nwg = std::max(8, std::min((cus / 8) * 8, ((tx * ty + 7) / 8) * 8));
+#define BCD_NZ_LAUNCH2(DD, RL, BD, PF)                                                                                             \
+    {                                                                                                                      \
+        const size_t lds = (size_t)NzLayout<DD>::LDS_DWORDS * 4;                                                           \
+        static std::atomic<int> granted[64];                                                                               \
+        if (dev < 0 || dev >= 64 || granted[dev].load() == 0) {                                                            \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist_nz<DD, RL, BD, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                                 \
+            if (dev >= 0 && dev < 64) granted[dev].store(1);                                                               \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((k_pairdist_nz<DD, RL, BD, PF>), dim3(nwg), dim3(NZ_THREADS), lds, st, hist, ns, W, H, static_cast<__half *>(T), Cn, t_ps, t_ds, d_range_flag, tau, tx, tx * ty, prof); \
+        return hipGetLastError();                                                                                          \
+    }
+#define BCD_NZ_LAUNCH1(DD, RL, BD) { if (prof) BCD_NZ_LAUNCH2(DD, RL, BD, true) else BCD_NZ_LAUNCH2(DD, RL, BD, false) }
+#define BCD_NZ_LAUNCH(DD) case DD: if (variant == 1) BCD_NZ_LAUNCH1(DD, true, 0) else if (variant == 2) BCD_NZ_LAUNCH1(DD, false, 1) else if (variant == 3) BCD_NZ_LAUNCH1(DD, true, 1) else BCD_NZ_LAUNCH1(DD, false, 0)
+    switch (D) {
+    BCD_NZ_LAUNCH(60)
+    BCD_NZ_LAUNCH(36)
+    BCD_NZ_LAUNCH(24)
+    default: break;
+    }
+#undef BCD_NZ_LAUNCH
+#undef BCD_NZ_LAUNCH1
+#undef BCD_NZ_LAUNCH2
+    return hipErrorInvalidValue;
+}

@@ -321,6 +321,15 @@ int bcd_hip_selftest_bin_work(bcd_hip_ctx *ctx, const float *d_hist, const float
 int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius,
                                      float *max_rel_dev, int64_t *count_mismatches, int *flags);
 
+/* self-test + timing of the own-list pair-distance kernel (k_pairdist_nz: the loop runs over the own pixel's non-zero bins, the bins with
+ * b1 = 0 enter by the closed form the rule of src/core/DenoisingUnit.cpp:379-383 allows; search radius 6 only): *max_rel_dev /
+ * *count_mismatches as above (against the exact planes), *flags = the kernel's range (1) / absolute-error (4) flag bits; best-of-reps kernel times:
+ * *ms_nz (pixel-major planes), *ms_nz_plane_major, *ms_dense (k_pairdist_rw on the same input).  variant: bit 0 = own bins by v_readlane instead of scalar loads, bit 1 = straight-line bin body;
+ * prof7 (may be NULL): shader-clock sums of a counting launch -- staging, S pass, wavefronts inside the item loop, item phase x 16, whole workgroups --, the bin slots
+ * issued and that launch's duration in microseconds */
+int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius, float tau, int variant,
+                                 int reps, float *max_rel_dev, int64_t *count_mismatches, int *flags, float *ms_nz, float *ms_nz_plane_major, float *ms_dense, int64_t *prof7);
+
 /* the eigensolver of the Bayesian steps on its own (Eigen::SelfAdjointEigenSolver of DenoisingUnit.cpp:589,617 for 27 x 27 matrices):
  * d_A = n symmetric matrices, 28 x 28 floats each, row-major, row / column 27 zero; d_eig[n][28] = eigenvalues (unordered, entry 27 = 0),
  * d_V[n][28][28] = eigenvectors in columns, same order (rows 0..26 written); *ms = kernel time (may be NULL).  Parity / timing aid. */

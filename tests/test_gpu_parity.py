@@ -813,6 +813,34 @@ def test_fast_similarity_path_equals_exact_kernels(hipctx, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["bench_noisy", "bench_clean", "mixed_counts", "ragged", "one_tile"])
+@pytest.mark.parametrize("variant", [1, 3])
+def test_own_list_distance_kernel_counts_exact_and_distances_inside_the_band(hipctx, kind, variant):
+    """k_pairdist_nz (round 5 experiment, not on the production path): the pair sums over the own pixel's non-zero bins with the closed form of
+    DenoisingUnit.cpp:379-383 for its empty bins -- bin counts identical to the exact planes', patch distances inside the verified band,
+    no range / absolute-error flag on these inputs; mixed sample counts take the general formula"""
+    import bcd_amd.core as core
+    if kind == "bench_noisy":
+        col, ns, hist, cov = core.synthetic_scene(320, 200, 32, 1234, 0.35, 0.01)
+    elif kind == "bench_clean":
+        col, ns, hist, cov = core.synthetic_scene(320, 200, 32, 1234, 0.10, 0.0)
+    elif kind == "mixed_counts":
+        rng = np.random.default_rng(3)
+        samples, _ = ol.synth_samples(200, 64, 16, seed=5, sigma=0.3, spike_prob=0.01)
+        keep = rng.random(samples.shape[0]) < 0.75
+        keep[::16] = True
+        ns, mean, cov, hist = ol.oracle_ops()["accumulate"](np.ascontiguousarray(samples[keep]), 200, 64)
+    elif kind == "ragged":
+        col, ns, hist, cov = core.synthetic_scene(131, 37, 8, 11, 0.3, 0.01)
+    else:
+        col, ns, hist, cov = core.synthetic_scene(19, 9, 8, 2, 0.3, 0.01)
+    d_hist, d_ns = dev(hist, ns)
+    rel, count_mismatches, flags, ms_nz, ms_pl, ms_dense = hipctx.selftest_nz_distance(d_hist, d_ns, 6, 1.0, variant, 1)
+    assert count_mismatches == 0 and flags == 0
+    assert rel < 2.0 ** -10 / 1.9, rel
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tau", [2.0 ** -6, 0.01, 64.0, 100.0])
 def test_similarity_thresholds_at_and_beyond_the_range_of_the_approximate_planes(hipctx, tau):
     """the binary16 planes of the fast path serve thresholds in [2^-6, 64] only (subnormals below, +inf above); outside, the exact
