@@ -103,6 +103,14 @@ def spike_filter(col, ns, hist, cov, factor=2.0):
     return c, n, h, v
 
 
+def spike_filter_host(col, ns, hist, cov, factor=2.0):
+    """SpikeRemovalFilter::filterOnHost (the loops filter() runs when no HIP device is usable)"""
+    H, W, D = hist.shape
+    c, n, h, v = col.copy(), ns.copy(), hist.copy(), cov.copy()
+    lib().bcdcore_spike_filter_host(_fp(c), _fp(n), _fp(h), _fp(v), W, H, D, C.c_float(factor))
+    return c, n, h, v
+
+
 def merge_hist_ns(hist, ns):
     H, W, D = hist.shape
     out = np.empty((H, W, D + 1), np.float32)

@@ -27,6 +27,8 @@ hipError_t bcd_launch_compare_planes(const float *, const uint8_t *, const float
 hipError_t bcd_launch_selftest_div(uint32_t, int, int, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t,
                             const BcdBorderline *, const float *, const float *, int);
+hipError_t bcd_launch_fwd_masks_rows(const float *, const uint8_t *, int, int, int, float, uint32_t *, hipStream_t, const BcdBorderline *, int, int);
+hipError_t bcd_launch_masks_finish(int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t, const BcdBorderline *, const float *, const float *, int);
 int bcd_pairdist_rw_supported(int D);
 hipError_t bcd_launch_pairdist_rw(const float *, const float *, int, int, int, int, void * /* binary16 T planes */, uint8_t *, int *, float, hipStream_t);
 hipError_t bcd_launch_pairdist_rw_rows(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, int, int, hipStream_t);
@@ -38,6 +40,8 @@ void bcd_sparse_frame_begin(BcdSparseUploader *);
 void bcd_sparse_frame_bytes(const BcdSparseUploader *, long long *, long long *);
 hipError_t bcd_sparse_upload(BcdSparseUploader *, float *, const float *, size_t, hipStream_t);
 int bcd_pairdist_nz_supported(int D, int b);
+void bcd_bayes27_set_strict_eigensolver(int on);
+hipError_t bcd_launch_fwd_masks_pm(const void *, const uint8_t *, int, int, float, uint32_t *, const BcdBorderline *, hipStream_t);
 hipError_t bcd_launch_pairdist_nz(const float *, const float *, int, int, int, int, void *, uint8_t *, long long, long long, int *, float, int, hipStream_t, unsigned long long *prof = nullptr);
 hipError_t bcd_launch_pairdist_rw_counting(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_spike_rows(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *, float *, float *, int, int,
@@ -110,13 +114,17 @@ struct Work {
     hipStream_t aux = nullptr;     // side stream: the fallback-pixel kernel runs beside the (latency-bound) full estimate kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_pixcov = nullptr; // the per-pixel covariances (side stream, beside the distance kernel) are complete
+    std::vector<hipEvent_t> ev_chunk;  // head pipeline (round 5): the distance planes of a chunk of tile rows are complete
     // approximate distance planes computed ahead of similarity() by a caller that streams the frame in (bcd_hip_denoise_host_ex): valid for
     // exactly this problem; similarity() consumes the note
     struct { bool ready = false; const float *hist = nullptr, *ns = nullptr; int W = 0, H = 0, D = 0, b = 0; float tau = 0.f, uni_n = 0.f; } planes;
     // uniform-sample-count speculation of the approximate distance kernel (similarity()): did the last frames on this workspace fail it?
     bool nonuniform = false;
-    unsigned uni_probe = 0;
     bool speculated = false;       // the current pass launched the uniform kernel on the first pixel's count, unchecked by the host
+    bool nz_imprecise = false;     // the own-list kernel raised its absolute-error flag on a frame of this size on this workspace: the dense kernel's general formula serves that size
+    int nz_imprecise_W = 0, nz_imprecise_H = 0;
+    bool nz_used = false;          // the current pass ran the own-list kernel (k_similarity_nz.hip)
+    int nz_W = 0, nz_H = 0;        // ... on a frame of this size
     // (round 4) k_scale_begin cleared these at the head of the scale's stream: the first user takes them as they are, a repeated use (second
     // similarity attempt, second marking batch, second chunk of a long list) clears its own as before
     bool clean_flags = false, clean_lines = false, clean_dc = false, clean_wq = false;
@@ -256,6 +264,10 @@ int check_params(bcd_hip_ctx *ctx, int W, int H, int D, const bcd_hip_params *pr
 
 // did the last similarity() pass on this workspace leave the range flag raised or overflow its borderline list?  (valid after the
 // stream has been synchronised; the caller then repeats the pass with exact_mode = 1)
+// a user of the workspace's counters / flags / work queues / sub-counter lines outside the scale chain (self-tests, the eigensolver entry point): whatever
+// k_scale_begin left clean is not clean any more
+void touch(Work &wk) { wk.clean_flags = wk.clean_lines = wk.clean_dc = wk.clean_wq = false; }
+
 bool similarity_needs_redo(const Work &wk)
 {
     return wk.h_counters[40] != 0 || (wk.border_capacity > 0 && (wk.h_counters[42] != 0 || wk.h_counters[43] > wk.border_capacity));
@@ -272,6 +284,10 @@ int similarity_redo_mode(Work &wk)
     const bool overflow = fast && wk.h_counters[43] > wk.border_capacity;
     if (fast && (wk.speculated || other_count)) wk.nonuniform = other_count;
     if (flag == 0 && !other_count && !overflow) return 0;
+    if (fast && wk.nz_used && (flag & 4) != 0) { // the own-list kernel's absolute-error check: the dense kernel's general formula serves this workspace from now on
+        wk.nz_imprecise = true; wk.nz_imprecise_W = wk.nz_W; wk.nz_imprecise_H = wk.nz_H;
+        if ((flag & ~4) == 0) return 3;
+    }
     return (flag == 0 && other_count) ? 3 : 1; // (a void launch has no meaningful list count: other_count alone decides)
 }
 
@@ -311,9 +327,15 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     // planes of exactly this problem already computed by the caller (its launches raised the flags in d_flag[0] themselves)?
     const bool pre = wk.planes.ready && exact_mode != 1 && wk.planes.hist == d_hist && wk.planes.ns == d_ns && wk.planes.W == W && wk.planes.H == H &&
                      wk.planes.D == D && wk.planes.b == b && wk.planes.tau == tau && w == 1;
+    const bool planes_kept = wk.planes.ready; // (k_scale_begin kept words [0] and [2] for the launches that made them)
     wk.planes.ready = false;
-    if (wk.clean_flags) wk.clean_flags = false; // (cleared by k_scale_begin, which kept the words of planes computed ahead)
-    else if (pre) { // (flags [0] and [2] belong to the launches that made the planes)
+    if (wk.clean_flags) { // cleared by k_scale_begin, which kept the words of planes computed ahead ...
+        wk.clean_flags = false;
+        if (planes_kept && !pre) { // ... of ANOTHER problem (serialised scales: the coarsest scale runs first on this workspace): their flags are not this pass's
+            HIPCHK(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), wk.stream));
+            HIPCHK(ctx, hipMemsetAsync(d_flag + 2, 0, sizeof(int), wk.stream));
+        }
+    } else if (pre) { // (flags [0] and [2] belong to the launches that made the planes)
         HIPCHK(ctx, hipMemsetAsync(d_flag + 1, 0, sizeof(int), wk.stream));
         HIPCHK(ctx, hipMemsetAsync(d_flag + 3, 0, sizeof(int), wk.stream));
     } else HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream));
@@ -321,43 +343,99 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     wk.h_counters[42] = 0;
     wk.h_counters[43] = 0;
     wk.border_capacity = 0;
+    wk.nz_used = false;
+    wk.nz_W = W; wk.nz_H = H;
     // fixed samples per pixel, a power of two (the usual case): the distance kernel drops the sample-count products (exactly,
     // see k_pairdist).  One small reduction and one host round trip at the head of the chain (~30 us).
     float uni_n = pre ? wk.planes.uni_n : 0.f;
     const bool fast_path = exact_mode != 1 && fast_similarity_applies(ctx, D, w, tau);
     wk.speculated = false;
-    if (fast_path && !pre) {
-        // No scan and no round trip at the head of the chain: the approximate kernel takes the first pixel's count as THE count and checks
-        // every pixel against it itself (flag bit 1 -> the pass is repeated with the general formula).  A workspace whose recent frames were
-        // not uniform (adaptive sampling) goes to the general formula directly and looks again every 32nd pass.
-        if (exact_mode != 3 && (!wk.nonuniform || (++wk.uni_probe & 31u) == 0u)) { uni_n = -1.f; wk.speculated = true; }
-    } else if (exact_mode != 1 && !pre) {
+    auto scan_uniform_count = [&]() -> int { // one small reduction and one host round trip (~30 us): uni_n = the frame's power-of-two count, or 0
         HIPCHK(ctx, bcd_launch_uniform_n(d_ns, (int64_t)npix, d_flag + 1, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 41, d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 42, d_ns, sizeof(float), hipMemcpyDeviceToHost, wk.stream));
         HIPCHK(ctx, hipStreamSynchronize(wk.stream));
         float n0;
         memcpy(&n0, wk.h_counters + 42, sizeof(n0));
+        wk.h_counters[42] = 0;
         int e = 0;
         if (wk.h_counters[41] == 0 && n0 >= 1.f && n0 <= 65536.f && frexpf(n0, &e) == 0.5f) uni_n = n0;
-    }
+        return BCD_HIP_OK;
+    };
+    if (fast_path && !pre) {
+        // No scan and no round trip at the head of the chain: the approximate kernel takes the first pixel's count as THE count and checks
+        // every pixel against it itself (flag bit 1 -> the pass is repeated with the general formula).  A workspace whose LAST frame was not
+        // uniform (adaptive sampling) looks first (round 5: it used to take the general formula blindly and look again every 32nd pass, which
+        // cost a uniform frame that followed frames with mixed counts the general formula for up to 31 passes).
+        if (exact_mode != 3 && !wk.nonuniform) { uni_n = -1.f; wk.speculated = true; }
+        else if (exact_mode != 3) {
+            RCCHK(scan_uniform_count());
+            wk.nonuniform = uni_n == 0.f;
+        }
+    } else if (exact_mode != 1 && !pre)
+        RCCHK(scan_uniform_count());
     // the approximate path keeps its T plane in binary16: thresholds it cannot decide safely take the exact kernels (bcd_common.h)
     const bool fast = fast_path;
     if (fast) {
         const int capacity = (int)std::min<size_t>(std::max<size_t>(npix, 1u << 16), 1u << 28);
         RCCHK(ensure(ctx, wk.border, (size_t)capacity * sizeof(uint2)));
         wk.border_capacity = capacity;
+        // (round 5, experiment hook, off by default) Head pipeline: BCD_HIP_HEAD_CHUNKS=n launches the distance kernel of a large scale in n chunks of
+        // tile rows and the forward-mask kernel of a chunk on the side stream while the next chunk's distance planes are being computed.  Measured
+        // at 1080p: 4.80 ms per step with one launch, 4.79 with 2 chunks, 4.94 with 4, 5.28 with 8 -- every chunk boundary drains the chip (the last
+        // workgroups of a chunk run alone), which costs what hiding the 0.2 ms mask kernel saves.
+        static const int head_chunks = [] { const char *e = getenv("BCD_HIP_HEAD_CHUNKS"); const int v = e ? atoi(e) : 1; return std::max(1, std::min(v, 16)); }();
+        const int tile_lines = bcd_pairdist_rw_tile_lines(), tile_rows = (H + tile_lines - 1) / tile_lines;
+        const int chunks = (!pre && head_chunks > 1 && npix >= 400000 && tile_rows >= 8 * head_chunks && uni_n != 0.f) ? head_chunks : 1;
+        BcdBorderline bl = { 0.f, (uint2 *)wk.border.p, d_flag + 3, capacity };
+        // (round 5) General sample counts (adaptive sampling, 24 spp, ...; src/core/DenoisingUnit.cpp:371-383 handles any n1, n2): the own-list kernel
+        // evaluates them at the cost of uniform ones (1.9 - 2.0 ms at 1080p against 2.9 - 3.0 ms for the dense kernel's general formula).
+        // Its planes are pixel-major and have a mask kernel of their own.  It raises flag bit 2 when its absolute-error check fails (coarse scales of
+        // frames with hundreds of samples per pixel): the pass is then repeated with the dense kernel, and the workspace remembers.
+        static const bool nz_off = [] { const char *e = getenv("BCD_HIP_NO_OWN_LIST"); return e && e[0] == '1'; }();
+        const bool use_nz = !pre && uni_n == 0.f && !nz_off && !(wk.nz_imprecise && wk.nz_imprecise_W == W && wk.nz_imprecise_H == H) && bcd_pairdist_nz_supported(D, b) && npix * (size_t)nd < ((size_t)1 << 31);
+        wk.nz_used = use_nz;
         if (pre) { if (e0) --wk.ev_used; } // (nothing to time: the planes are there)
-        else {
+        else if (use_nz) {
+            if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
+            HIPCHK(ctx, bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, (long long)nd, 1, d_flag, tau, 3, wk.stream));
+            if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
+        } else if (chunks == 1) {
             if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
             HIPCHK(ctx, bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream));
             if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
+        } else {
+            while ((int)wk.ev_chunk.size() < chunks) {
+                hipEvent_t ev;
+                HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                wk.ev_chunk.push_back(ev);
+            }
+            if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
+            int line0 = 0;
+            for (int i = 0; i < chunks; ++i) {
+                const int t0 = (int)((int64_t)tile_rows * i / chunks), t1 = (int)((int64_t)tile_rows * (i + 1) / chunks);
+                HIPCHK(ctx, bcd_launch_pairdist_rw_rows(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, t0, t1, wk.stream));
+                HIPCHK(ctx, hipEventRecord(wk.ev_chunk[i], wk.stream));
+                // forward bits of the lines whose three plane lines are complete: up to the chunk's last line but three (the last chunk: to the end)
+                const int line1 = i + 1 == chunks ? H : t1 * tile_lines - 4;
+                HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_chunk[i], 0));
+                HIPCHK(ctx, bcd_launch_fwd_masks_rows((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, b, tau, (uint32_t *)wk.fwd.p, wk.aux, &bl, line0, line1));
+                line0 = line1;
+            }
+            if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
+            HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
+            HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_join, 0));
         }
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 42, d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, wk.stream)); // "another sample count" (plain-store flag)
-        BcdBorderline bl = { 0.f, (uint2 *)wk.border.p, d_flag + 3, capacity };
-        HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream,
-                                     &bl, d_hist, d_ns, D));
+        if (use_nz) {
+            HIPCHK(ctx, bcd_launch_fwd_masks_pm(wk.T.p, (const uint8_t *)wk.Cn.p, W, H, tau, (uint32_t *)wk.fwd.p, &bl, wk.stream));
+            HIPCHK(ctx, bcd_launch_masks_finish(W, H, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream, &bl, d_hist, d_ns, D));
+        } else if (chunks == 1)
+            HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream,
+                                         &bl, d_hist, d_ns, D));
+        else
+            HIPCHK(ctx, bcd_launch_masks_finish(W, H, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream, &bl, d_hist, d_ns, D));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 43, d_flag + 3, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         if (exact_mode == 0) {
             HIPCHK(ctx, hipStreamSynchronize(wk.stream));
@@ -365,6 +443,10 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
             if (redo == 3) {
                 RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 3));
                 HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+                if (similarity_needs_redo(wk) && similarity_redo_mode(wk) == 3) { // (the own-list kernel declined: once more with the dense kernel)
+                    RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 3));
+                    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+                }
                 if (similarity_needs_redo(wk)) return similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 1);
             } else if (redo == 1)
                 return similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 1);
@@ -492,16 +574,22 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     // the two paths only meet in the atomic accumulators: the fallback pixels run on a side stream.  The tiled fallback kernel needs no
     // list (it reads states and |S| itself), so it starts at once -- beside the list compaction and the host round trip for the number of
     // full estimates, during which this scale would otherwise leave the chip idle -- and is out of the way when the prepare kernel arrives
-    if (weak_tiles) {
+    static const bool weak_first = [] { const char *e = getenv("BCD_HIP_WEAK_FIRST"); return e && e[0] == '1'; }(); // (experiment hook: the round-4 order)
+    auto fork_weak_tiles = [&]() -> int {
         HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
         HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
         HIPCHK(ctx, bcd_launch_bayes_weak_tiles(d_colors, d_mask, d_state, d_nsim, K + 1, W, H, b, d_sum, d_count, wk.aux));
         HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
-    }
+        return BCD_HIP_OK;
+    };
+    if (weak_tiles && weak_first) RCCHK(fork_weak_tiles());
     if (wk.clean_dc) wk.clean_dc = false; // (k_scale_begin)
     else HIPCHK(ctx, hipMemsetAsync(d_c, 0, 8 * sizeof(int32_t), wk.stream));
     HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)wk.strong.p, (int32_t *)wk.weak.p, d_c, wk.stream));
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream));
+    // (round 5) the list compaction is 253 workgroups of 1024 threads: 18 us alone, 150 us when the fallback kernel's 8 160 tiles were launched
+    // first and every CU had to drain before one of them fitted.  The fallback kernel starts BEHIND it (it still overlaps the host round trip).
+    if (weak_tiles && !weak_first) RCCHK(fork_weak_tiles());
     const int64_t cap = std::max<int64_t>(1, npix);
     // The estimate kernels are persistent (a wavefront per CU slot, items from a counter), so whatever they occupy stays
     // occupied until they end.  In a multiscale call the finest scale is the critical path and the coarse scales have slack: they
@@ -599,7 +687,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
                                            (int *)wk.work_q.p, BCD_WORK_INTS, wk.stream));
         wk.clean_flags = wk.clean_lines = wk.clean_dc = wk.clean_wq = true;
     }
-    for (int attempt = 0, mode = 2; attempt < 3; ++attempt) { // production kernels; if they complain: general formula, then exact kernels
+    for (int attempt = 0, mode = 2; attempt < 4; ++attempt) { // production kernels; if they complain: general formula (own-list kernel, then the dense one), then exact kernels
         RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, mode));
         if (prof && attempt == 0) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
         RCCHK(active_set(ctx, wk, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, W, H, w, b, row_begin, row_end,
@@ -608,7 +696,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
         if (!(prm->marked_skip_probability > 0.f)) HIPCHK(ctx, hipStreamSynchronize(wk.stream)); // no marking batch brought the flag back
         const int redo = similarity_redo_mode(wk);
         if (redo == 0) break; // inputs inside the guarded range, uniform-count guess right, borderline list not overflowed
-        mode = (redo == 3 && mode == 2) ? 3 : 1;
+        mode = (redo == 3 && (mode == 2 || wk.nz_used)) ? 3 : 1; // (wk.nz_used: the own-list kernel declined and the workspace has noted it -- the dense kernel is next)
     }
     progress_add(ctx, 0.5 * (double)npix); // similar patches selected, processed set known
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
@@ -633,7 +721,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     int64_t ns = 0, nw = 0, tot = 0;
     bayes_counts(wk, &ns, &nw, &tot);
     st.processed = ns + nw; st.fallback = nw; st.similar_total = tot;
-    st.similarity_path = wk.border_capacity > 0 ? 1 : 0;
+    st.similarity_path = wk.border_capacity > 0 ? (wk.nz_used ? 2 : 1) : 0;
     st.borderline_pairs = wk.border_capacity > 0 ? wk.h_counters[43] : 0;
     st.cu_share = ctx->cu_share_pct * (&wk != &ctx->main ? ctx->coarse_share : 100) / 100;
     st.spectral_inverses = wk.h_counters[23];
@@ -708,6 +796,8 @@ void work_destroy(Work &w)
     for (int i = 0; i < 4; ++i) if (w.ev_stage[i]) (void)hipEventDestroy(w.ev_stage[i]);
     if (w.ev_done) (void)hipEventDestroy(w.ev_done);
     if (w.ev_built) (void)hipEventDestroy(w.ev_built);
+    for (hipEvent_t ev : w.ev_chunk) (void)hipEventDestroy(ev);
+    w.ev_chunk.clear();
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
     if (w.ev_join) (void)hipEventDestroy(w.ev_join);
     if (w.ev_pixcov) (void)hipEventDestroy(w.ev_pixcov);
@@ -814,6 +904,12 @@ int bcd_hip_set_concurrent_scales(bcd_hip_ctx *ctx, int enabled)
 {
     if (!ctx) return BCD_HIP_EINVAL;
     ctx->concurrent_scales = enabled != 0;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_set_strict_eigensolver(int enabled)
+{
+    bcd_bayes27_set_strict_eigensolver(enabled);
     return BCD_HIP_OK;
 }
 
@@ -1425,6 +1521,7 @@ int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, con
 {
     if (!ctx || !d_hist || !d_ns || !mismatches || W <= 0 || H <= 0 || D <= 0 || search_radius < 1) return bad(ctx, "bad argument");
     DEVICE_GUARD(ctx);
+    touch(ctx->main);
     Work &wk = ctx->main;
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
@@ -1482,6 +1579,7 @@ int bcd_hip_selftest_bin_work(bcd_hip_ctx *ctx, const float *d_hist, const float
 {
     if (!ctx || !d_hist || !d_ns || !lane_bins || !wave_bins || !wave_groups || !kernel_ms || W <= 0 || H <= 0 || search_radius < 1 || reps < 1) return bad(ctx, "bad argument");
     DEVICE_GUARD(ctx);
+    touch(ctx->main);
     if (!bcd_pairdist_rw_supported(D)) { set_err(ctx, "no approximate kernel for this histogram depth"); return BCD_HIP_EUNSUPPORTED; }
     Work &wk = ctx->main;
     const size_t npix = (size_t)W * H;
@@ -1532,6 +1630,7 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
 {
     if (!ctx || !d_hist || !d_ns || !max_rel_dev || !count_mismatches || W <= 0 || H <= 0 || search_radius < 1) return bad(ctx, "bad argument");
     DEVICE_GUARD(ctx);
+    touch(ctx->main);
     if (!bcd_pairdist_rw_supported(D)) { set_err(ctx, "no approximate kernel for this histogram depth"); return BCD_HIP_EUNSUPPORTED; }
     Work &wk = ctx->main;
     const size_t npix = (size_t)W * H;
@@ -1583,10 +1682,11 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
 
 // self-test + timing of the own-list distance kernel (k_similarity_nz.hip) against the exact planes and against the dense approximate kernel
 int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int search_radius, float tau, int variant, int reps,
-                                 float *max_rel_dev, int64_t *count_mismatches, int *flags, float *ms_nz, float *ms_nz_plane_major, float *ms_dense, int64_t *prof7)
+                                 float *max_rel_dev, int64_t *count_mismatches, int *flags, float *ms_nz, float *ms_nz_plane_major, float *ms_dense, int64_t *prof8)
 {
     if (!ctx || !d_hist || !d_ns || !max_rel_dev || !count_mismatches || !flags || !ms_nz || !ms_nz_plane_major || !ms_dense || W <= 0 || H <= 0 || reps < 1) return bad(ctx, "bad argument");
     DEVICE_GUARD(ctx);
+    touch(ctx->main);
     if (!bcd_pairdist_nz_supported(D, search_radius)) { set_err(ctx, "no own-list kernel for this depth / search radius"); return BCD_HIP_EUNSUPPORTED; }
     Work &wk = ctx->main;
     const size_t npix = (size_t)W * H;
@@ -1620,14 +1720,14 @@ int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const fl
         *count_mismatches = (int64_t)h[1];
         *flags = flag;
         // timing: own-list kernel, pixel-major planes (into the scratch planes) and plane-major; the dense kernel
-        float best[3] = { -1.f, -1.f, -1.f };
-        for (int which = 0; which < 3 && rc == BCD_HIP_OK; ++which)
+        float best[4] = { -1.f, -1.f, -1.f, -1.f };
+        for (int which = 0; which < 4 && rc == BCD_HIP_OK; ++which)
             for (int r = 0; r < reps + 1; ++r) {
                 hipError_t e = hipEventRecord(e0, wk.stream);
                 if (e == hipSuccess) {
                     if (which == 0) e = bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, T2, C2, (long long)nd, 1, d_flag, tau, variant, wk.stream);
                     else if (which == 1) e = bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, 1, (long long)npix, d_flag, tau, variant, wk.stream);
-                    else e = bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag + 1, -1.f, wk.stream);
+                    else e = bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag + 1, which == 2 ? -1.f : 0.f, wk.stream);
                 }
                 if (e != hipSuccess || hipEventRecord(e1, wk.stream) != hipSuccess || hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
                 float ms = 0.f;
@@ -1635,7 +1735,7 @@ int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const fl
                 if (r > 0 && (best[which] < 0.f || ms < best[which])) best[which] = ms;
             }
         *ms_nz = best[0]; *ms_nz_plane_major = best[1]; *ms_dense = best[2];
-        if (prof7 && rc == BCD_HIP_OK) { // the counting instantiation (second of two launches; its own duration in microseconds in prof7[6])
+        if (prof8 && rc == BCD_HIP_OK) { // the counting instantiation (second of two launches; its own duration in microseconds in prof8[6])
             unsigned long long *d_prof = reinterpret_cast<unsigned long long *>((int32_t *)wk.counters.p + 48); // (words 48..59)
             unsigned long long hp[6] = { 0, 0, 0, 0, 0, 0 };
             float ms = 0.f;
@@ -1646,8 +1746,9 @@ int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const fl
                     hipMemcpyAsync(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost, wk.stream) != hipSuccess || hipStreamSynchronize(wk.stream) != hipSuccess) rc = BCD_HIP_EDEVICE;
             if (rc != BCD_HIP_OK) break;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            for (int i = 0; i < 6; ++i) prof7[i] = (int64_t)hp[i];
-            prof7[6] = (int64_t)(ms * 1000.f);
+            for (int i = 0; i < 6; ++i) prof8[i] = (int64_t)hp[i];
+            prof8[6] = (int64_t)(ms * 1000.f);
+            prof8[7] = (int64_t)(best[3] * 1000.f); // the dense kernel with the general (non-uniform) formula, microseconds
         }
     } while (false);
     if (e0) (void)hipEventDestroy(e0);
@@ -1662,6 +1763,7 @@ int bcd_hip_eig27_batch(bcd_hip_ctx *ctx, const float *d_A, int n, float *d_eig,
 {
     if (!ctx || !d_A || !d_eig || !d_V || n <= 0) return bad(ctx, "bad argument");
     DEVICE_GUARD(ctx);
+    touch(ctx->main);
     Work &wk = ctx->main;
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.work_q, BCD_WORK_INTS * sizeof(int32_t)));
@@ -1679,6 +1781,7 @@ int bcd_hip_selftest_division(bcd_hip_ctx *ctx, uint32_t seed, int64_t samples, 
 {
     if (!ctx || !mismatches || samples <= 0) return bad(ctx, "bad argument");
     DEVICE_GUARD(ctx);
+    touch(ctx->main);
     RCCHK(ensure(ctx, ctx->main.counters, 64 * sizeof(int32_t)));
     unsigned long long *d = reinterpret_cast<unsigned long long *>((int32_t *)ctx->main.counters.p + 32);
     HIPCHK(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));

@@ -36,6 +36,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -235,7 +236,12 @@ struct bcd_hip_multi {
     std::mutex comm_mutex;
     // rank threads hold comm_rw shared while they ENQUEUE on a communicator (group start .. group end, the all-reduce call); an abort takes it
     // exclusively, so ncclCommAbort -- which frees the communicator -- never runs while a thread is inside an RCCL call on it
-    std::shared_mutex comm_rw;
+    std::shared_timed_mutex comm_rw;
+    // ... but a rank thread can be stuck INSIDE such a call (blocking communicators: ncclGroupEnd / the first send to a peer that has died
+    // never returns).  The abort therefore waits for the section only this long and then proceeds anyway: ncclCommAbort is what releases a
+    // blocked call (round-4 ADVICE: with an unbounded wait the watchdog could no longer end a frame whose peer is gone).
+    int abort_wait_ms = 5000;                 // BCD_HIP_MULTI_ABORT_WAIT_MS
+    bool abort_forced = false;                // the last abort did not get the section to itself (diagnostics / self-test)
     bool comm_aborted = false;
     // loopback (bcd_hip_multi_set_loopback; one rank, tests on a one-GPU box): the rank is its own neighbour on both sides -- every exchange and
     // all-reduce of a frame is enqueued on real RCCL communicators (ncclCommInitRank with n = 1, grouped self send / recv), in the order and with
@@ -253,11 +259,26 @@ struct bcd_hip_multi {
 
 namespace {
 
+// which RCCL serves this library: version of the loaded library and the file ncclCommInitRank was resolved from.  The process may hold another
+// copy (PyTorch bundles one): libbcd_hip.so links librccl.so.1 by SONAME, so the dynamic loader gives it the copy that is already mapped under
+// that SONAME, if any -- this string is how a run says which one it got (bench.py prints it next to the copies mapped into the process).
+std::string rccl_identity()
+{
+    int v = 0;
+    (void)ncclGetVersion(&v);
+    Dl_info info;
+    memset(&info, 0, sizeof(info));
+    const char *path = (dladdr(reinterpret_cast<const void *>(&ncclCommInitRank), &info) != 0 && info.dli_fname) ? info.dli_fname : "?";
+    return "rccl version " + std::to_string(v) + " from " + path;
+}
+
 // RCCL transport: stop the communication kernels of every local communicator (idempotent; prepare() creates new ones)
 void abort_comms(bcd_hip_multi *m)
 {
     if (!m->use_rccl) return;
-    std::unique_lock<std::shared_mutex> excl(m->comm_rw); // no rank thread is inside an RCCL call on these communicators
+    std::unique_lock<std::shared_timed_mutex> excl(m->comm_rw, std::defer_lock);
+    // normally no rank thread is inside an RCCL call on these communicators when they are freed; a thread that is STUCK in one is released by the abort itself
+    m->abort_forced = !excl.try_lock_for(std::chrono::milliseconds(std::max(0, m->abort_wait_ms)));
     std::lock_guard<std::mutex> lk(m->comm_mutex);
     for (int c = 0; c <= MAX_S; ++c) {
         if (!m->comm_ready[c]) continue;
@@ -396,7 +417,7 @@ bool exchange_n(bcd_hip_multi *m, int rank, int ch, Seg *segs, int n)
     if (m->use_rccl) {
         ncclResult_t r = ncclSuccess, e = ncclSuccess;
         {
-            std::shared_lock<std::shared_mutex> enq(m->comm_rw); // (an abort waits for this section to end before it frees the communicator)
+            std::shared_lock<std::shared_timed_mutex> enq(m->comm_rw); // (an abort waits -- a bounded time -- for this section to end before it frees the communicator)
             if (!m->comm_ready[ch] || m->abort_flag.load()) return false; // aborted meanwhile: fail() has recorded why
             r = ncclGroupStart();
             // operations to the same peer are matched in issue order (both sides issue the pieces in the same order; in loopback the k-th send pairs with the k-th receive)
@@ -440,7 +461,7 @@ bool allreduce(bcd_hip_multi *m, int rank, int ch, long long *value)
         MCHK(m, rank, hipMemcpyAsync(m->d_red[rank][ch], value, sizeof(long long), hipMemcpyHostToDevice, st));
         ncclResult_t r;
         {
-            std::shared_lock<std::shared_mutex> enq(m->comm_rw);
+            std::shared_lock<std::shared_timed_mutex> enq(m->comm_rw);
             if (!m->comm_ready[ch] || m->abort_flag.load()) return false;
             r = ncclAllReduce(m->d_red[rank][ch], m->d_red[rank][ch], 1, ncclInt64, ncclSum, m->comm[ch][rank], st);
         }
@@ -751,6 +772,10 @@ int prepare(bcd_hip_multi *m, int S)
             } else
                 r = ncclCommInitAll(m->comm[c], m->n, m->devices);
             if (r != ncclSuccess) { fail(m, std::string("RCCL communicator creation failed: ") + ncclGetErrorString(r)); return BCD_HIP_EDEVICE; }
+            if (c == 0) {
+                static const bool verbose = [] { const char *e = getenv("BCD_HIP_MULTI_VERBOSE"); return e && e[0] == '1'; }();
+                if (verbose) fprintf(stderr, "[bcd_hip_multi] rank %d of %d: communicators from %s\n", m->local_rank < 0 ? 0 : m->local_rank, m->n, rccl_identity().c_str());
+            }
             std::lock_guard<std::mutex> lk(m->comm_mutex);
             m->comm_ready[c] = true;
         }
@@ -815,6 +840,7 @@ int bcd_hip_multi_create(bcd_hip_multi **out, const int *devices, int n_ranks)
     for (int c = 0; c <= MAX_S; ++c) { m->barrier[c].parties = n_ranks; m->barrier[c].abort_flag = &m->abort_flag; }
     for (int r = 0; r < n_ranks; ++r) m->gate[r].abort_flag = &m->abort_flag;
     if (const char *t = getenv("BCD_HIP_MULTI_TIMEOUT_S")) m->frame_timeout_ms = atoi(t) * 1000;
+    if (const char *t = getenv("BCD_HIP_MULTI_ABORT_WAIT_MS")) m->abort_wait_ms = atoi(t);
     const char *ordered = getenv("BCD_HIP_MULTI_ORDERED");
     m->ordered = m->use_rccl || (ordered && atoi(ordered) != 0);
     m->stats.n_ranks = n_ranks;
@@ -919,6 +945,15 @@ int bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const fl
     for (int r = 0; r < m->n; ++r)
         if (!ok[r]) { fail(m, "a rank failed"); return BCD_HIP_EDEVICE; }
     m->stats.frames += 1;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_multi_rccl_info(char *out, int capacity)
+{
+    if (!out || capacity <= 0) return BCD_HIP_EINVAL;
+    const std::string t = rccl_identity();
+    strncpy(out, t.c_str(), (size_t)capacity - 1);
+    out[capacity - 1] = 0;
     return BCD_HIP_OK;
 }
 
@@ -1037,7 +1072,27 @@ int bcd_hip_multi_selftest_transport(int device, long long halo_bytes, char *rep
     if ((rc = prepare(m, S)) != BCD_HIP_OK) return bail("prepare after the abort", rc);
     for (int ch = 0; ch <= S; ++ch)
         if ((rc = round(ch, 91u + (unsigned)ch, "exchange after abort + rebuild")) != BCD_HIP_OK) return rc;
-    say("ok: ncclCommInitRank(n=1) x2, grouped self send/recv + int64 all-reduce on 2 channels, ncclCommAbort, rebuild from fresh ids, second exchange");
+    // a rank thread stuck inside an RCCL call (a peer that never joins) holds the enqueue section for good: the abort must not wait for it for ever
+    {
+        std::atomic<bool> held{ false }, release{ false };
+        std::thread stuck([&] {
+            std::shared_lock<std::shared_timed_mutex> enq(m->comm_rw);
+            held.store(true);
+            while (!release.load()) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        });
+        while (!held.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        const int keep = m->abort_wait_ms;
+        m->abort_wait_ms = 200;
+        const auto t0 = std::chrono::steady_clock::now();
+        fail(m, "self-test: failure while a rank thread is stuck in an RCCL call");
+        const double waited_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        m->abort_wait_ms = keep;
+        release.store(true);
+        stuck.join();
+        if (!m->abort_forced || m->comm_ready[0] || waited_ms > 5000.0) { say("an abort behind a stuck enqueue section did not go through in bounded time"); return BCD_HIP_EDEVICE; }
+    }
+    say("ok: ncclCommInitRank(n=1) x2, grouped self send/recv + int64 all-reduce on 2 channels, ncclCommAbort, rebuild from fresh ids, second exchange, "
+        "abort behind a stuck enqueue section after a bounded wait; " + rccl_identity());
     return BCD_HIP_OK;
 }
 

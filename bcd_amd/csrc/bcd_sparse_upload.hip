@@ -78,6 +78,8 @@ struct Piece {
     // for a job only ever touches the counters of the buffer it was handed, never those of a newer job on another buffer)
     std::atomic<int> next{ 0 }, remaining{ 0 };
     std::atomic<size_t> cursor{ 0 };                 // values appended to h_vals so far
+    int drainers = 0;                                // pool threads inside drain() on this buffer (guarded by the uploader's mutex): submit() waits for 0
+                                                     // before it re-arms the counters, so a late worker can never claim a task of a job that is being set up
     uint32_t *masks() const { return h_meta; }                  // (laid out for the piece at hand: nblk blocks)
     uint32_t *voff() const { return h_meta + nblk * 64; }
     uint32_t *vcnt() const { return h_meta + nblk * 65; }
@@ -227,8 +229,13 @@ struct BcdSparseUploader {
                 if (quit) return;
                 seen = epoch;
                 pc = job;
+                ++pc->drainers; // (counted under the lock that submit() holds while it resets the job fields: the two never overlap)
             }
             drain(pc);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pc->drainers == 0) cv_done.notify_all();
+            }
         }
     }
     void drain(Piece *pc)
@@ -288,13 +295,17 @@ struct BcdSparseUploader {
         if (p.ev_pending) { hipError_t e = hipEventSynchronize(p.ev); if (e != hipSuccess) return e; p.ev_pending = false; } // its last upload has left the staging
         hipError_t e = size_for(p, std::max(n, SP_PIECE));
         if (e != hipSuccess) return e;
-        p.src = src; p.n = n; p.nblk = (n + SP_BLOCK - 1) / SP_BLOCK;
-        p.segs = (int)((p.nblk + SP_TASK - 1) / SP_TASK);
-        p.cursor.store(0);
-        p.remaining.store(p.segs);
-        p.next.store(0);
         {
-            std::lock_guard<std::mutex> lk(mu);
+            // A pool thread that was handed this buffer for an EARLIER job may still be on its way into (or out of) drain(): it would claim from
+            // `next` while the fields below change (round-4 ADVICE: a stale index below the new `segs` packs a task twice, `remaining` hits
+            // zero early, the cursor moves twice).  Wait until nobody is inside, then re-arm the job under the same lock the workers take to enter.
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return p.drainers == 0; });
+            p.src = src; p.n = n; p.nblk = (n + SP_BLOCK - 1) / SP_BLOCK;
+            p.segs = (int)((p.nblk + SP_TASK - 1) / SP_TASK);
+            p.cursor.store(0);
+            p.remaining.store(p.segs);
+            p.next.store(0);
             job = &p;
             ++epoch;
         }
@@ -341,6 +352,8 @@ void bcd_sparse_frame_bytes(const BcdSparseUploader *u, long long *raw, long lon
 hipError_t bcd_sparse_upload(BcdSparseUploader *u, float *dst, const float *src, size_t n, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
+    // (the unpack kernel stores 16-byte groups: a destination that is not 16-byte aligned travels as a plain copy)
+    if (((uintptr_t)dst & 15) != 0) { u->raw_bytes += (long long)n * 4; u->sent_bytes += (long long)n * 4; return hipMemcpyAsync(dst, src, n * 4, hipMemcpyHostToDevice, st); }
     size_t done = 0;
     hipError_t e;
     bool packing = false; // a job on buf[cur] is in flight (its threads read the caller's buffer: never return while it runs)

@@ -869,6 +869,7 @@ __device__ __attribute__((noinline)) void mfma27(float *out, int ldo, const floa
 // A per-pair stopping rule (every opposite-sign pair decoupled, loose bound on the rest) was built and measured out: in fp32 it needs the
 // sixth sweep as often as the plain rule does, and its test costs 5 % of a sweep.
 constexpr float JACOBI_CONV2_CORRECTED = 2e-9f; // off / diag <= 4.5e-5
+constexpr float JACOBI_CONV2_STRICT = 1e-12f;   // the round-3 rule: one sweep more, the correction then has nothing left to do
 
 
 // Bm (LD layout) <- V f(D) V^T + V (E o Phi) V^T; Mb: 28 x 28 scratch (JLD layout), eigs: 28 floats of scratch, V: LDS copy of the record's V (JLD
@@ -1828,6 +1829,18 @@ size_t bcd_bayes27_record_bytes() { return (size_t)(3 * MSZ + AUX27 + KP) * size
 
 hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blocks, float *eig, float *V, hipStream_t st, float conv2 = 1e-12f, float *Aout = nullptr);
 
+// Stopping rule of the estimate chain's eigensolver: 2e-9 + first-order correction (production), or -- strict mode, BCD_HIP_STRICT_EIGEN=1 or
+// bcd_hip_set_strict_eigensolver -- the fully converged 1e-12 (the looser rule spends accuracy on ill-conditioned low-spp frames, 9.8e-6
+// instead of 2.9e-6 on the 4K 8-spp frame; a caller who wants the margin back can have it for ~1.5 % of the step)
+static std::atomic<int> g_strict_eigen{ -1 };
+void bcd_bayes27_set_strict_eigensolver(int on) { g_strict_eigen.store(on ? 1 : 0); }
+static float jacobi_conv2()
+{
+    int v = g_strict_eigen.load();
+    if (v < 0) { const char *e = getenv("BCD_HIP_STRICT_EIGEN"); v = (e && e[0] == '1') ? 1 : 0; g_strict_eigen.store(v); }
+    return v ? JACOBI_CONV2_STRICT : JACOBI_CONV2_CORRECTED;
+}
+
 // Full estimate of items [first_item, first_item + nb_items) of `list`: three launches; `records` holds nb_items records
 // (bcd_bayes27_record_bytes() each), d_work BCD_WORK_INTS zeroed ints (the work queues of the three kernels).
 hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int first_item, int nb_items,
@@ -1857,7 +1870,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP); // (the register-resident finish; cleared by the prepare kernel)
         hipLaunchKernelGGL(k_bayes27w<1>, dim3(std::min(nb_items, num_cus * w_cu1)), dim3(64), wl1, st, colors, pixcov, mask, list, first_item, nb_items,
                            d_work, g, min_eig, rec, sum, cnt, lds_algebra ? nullptr : redo);
-        { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st, JACOBI_CONV2_CORRECTED, rec.A); if (e != hipSuccess) return e; }
+        { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st, jacobi_conv2(), rec.A); if (e != hipSuccess) return e; }
         if (lds_algebra)
             hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * w_cu2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
                                d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, nullptr);
@@ -1882,7 +1895,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP);
     hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
                        d_work, g, min_eig, rec, sum, cnt, (const int *)nullptr);
-    { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st, JACOBI_CONV2_CORRECTED, rec.A); if (e != hipSuccess) return e; }
+    { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st, jacobi_conv2(), rec.A); if (e != hipSuccess) return e; }
     if (finish_regs) {
         // the prepare kernel of this path does not know the redo list: its counter is cleared here (one fill per chunk)
         { hipError_t e = hipMemsetAsync(redo, 0, sizeof(int), st); if (e != hipSuccess) return e; }

@@ -152,7 +152,7 @@ __global__ void k_interpolate(const float *__restrict__ lo, int w, int h, int D,
 // SpikeRemovalFilter::filter (src/core/SpikeRemovalFilter.cpp:18-116), float-abs semantics; out of place.
 __global__ void k_spike(const float *__restrict__ col, const float *__restrict__ ns, const float *__restrict__ hist,
                         const float *__restrict__ cov, int W, int H, int D, float factor,
-                        float *__restrict__ ocol, float *__restrict__ ons, float *__restrict__ ohist, float *__restrict__ ocov, int row_begin)
+                        float *__restrict__ ocol, float *__restrict__ ons, float *__restrict__ ohist, float *__restrict__ ocov, int row_begin, int vec16 /* hist / ohist are 16-byte aligned */)
 {
     // (round 4) the decision is per pixel, the copies are per workgroup: the 64 source indices go through LDS and the 64 lanes then move the 64
     // pixels' values as contiguous runs (16 bytes per lane for the histograms).  One lane copying the 60 bins of its own pixel was 4 bytes per lane
@@ -201,7 +201,7 @@ __global__ void k_spike(const float *__restrict__ col, const float *__restrict__
     for (int e = threadIdx.x; e < ncols * 3; e += 64) { const int px = e / 3; ocol[row_base * 3 + e] = col[(size_t)s_src[px] * 3 + (e - px * 3)]; }
     if (in_row) ons[dst] = ns[src];
     for (int e = threadIdx.x; e < ncols * 6; e += 64) { const int px = e / 6; ocov[row_base * 6 + e] = cov[(size_t)s_src[px] * 6 + (e - px * 6)]; }
-    if ((D & 3) == 0) {
+    if ((D & 3) == 0 && vec16) {
         const int Q = D >> 2;
         const float4 *h4 = reinterpret_cast<const float4 *>(hist);
         float4 *o4 = reinterpret_cast<float4 *>(ohist);
@@ -328,7 +328,9 @@ hipError_t bcd_launch_spike_rows(const float *col, const float *ns, const float 
                                  float factor, float *ocol, float *ons, float *ohist, float *ocov, int row_begin, int row_end, hipStream_t st)
 {
     if (row_end <= row_begin) return hipSuccess;
-    hipLaunchKernelGGL(k_spike, dim3((W + 63) / 64, row_end - row_begin), dim3(64), 0, st, col, ns, hist, cov, W, H, D, factor, ocol, ons, ohist, ocov, row_begin);
+    // (the public entry point takes any device pointers -- a view into a larger buffer may be 4-byte aligned only: those take the scalar copies)
+    const int vec16 = (((uintptr_t)hist | (uintptr_t)ohist) & 15) == 0 ? 1 : 0;
+    hipLaunchKernelGGL(k_spike, dim3((W + 63) / 64, row_end - row_begin), dim3(64), 0, st, col, ns, hist, cov, W, H, D, factor, ocol, ons, ohist, ocov, row_begin, vec16);
     return hipGetLastError();
 }
 

@@ -363,11 +363,11 @@ __device__ inline float plane_value(__half v) { return __half2float(v); }
 template <bool APPROX>
 __global__ __launch_bounds__(64) void k_fwd_masks_w1(const typename PlaneT<APPROX>::type *__restrict__ T, const uint8_t *__restrict__ Cn,
                                                      int W, int H, int b, float tau, int fwords, int nd,
-                                                     uint32_t *__restrict__ fwd, BcdBorderline bl)
+                                                     uint32_t *__restrict__ fwd, BcdBorderline bl, int rb0 /* first block of FWD_RB lines */, int row_end /* lines written: < row_end */)
 {
     const int lane = threadIdx.x;
     const int c = blockIdx.x * 62 + lane - 1; // lanes 1..62 produce output
-    const int rb = blockIdx.y * FWD_RB;
+    const int rb = (blockIdx.y + rb0) * FWD_RB;
     const int wi = blockIdx.z;
     const bool writer = lane >= 1 && lane <= 62 && c < W;
     const bool c_main = c >= 1 && c <= W - 2;
@@ -421,11 +421,11 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const typename PlaneT<APPRO
     }
 #pragma unroll
     for (int i = 0; i < FWD_RB; ++i)
-        if (writer && rb + i < H) fwd[((size_t)(rb + i) * W + c) * fwords + wi] = word[i];
+        if (writer && rb + i < row_end) fwd[((size_t)(rb + i) * W + c) * fwords + wi] = word[i];
     if (APPROX) {
         uint32_t pix[FWD_RB];
 #pragma unroll
-        for (int i = 0; i < FWD_RB; ++i) pix[i] = (uint32_t)((rb + i) * W + c);
+        for (int i = 0; i < FWD_RB; ++i) { pix[i] = (uint32_t)((rb + i) * W + c); if (rb + i >= row_end) bword[i] = 0; } // (lines of a later launch)
         borderline_flush<FWD_RB>(bl, bword, pix, wi, lane);
     }
 }
@@ -436,11 +436,11 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const typename PlaneT<APPRO
 template <bool APPROX>
 __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APPROX>::type *__restrict__ T, const uint8_t *__restrict__ Cn,
                                                        int W, int H, int b, float tau, int fwords, int nd,
-                                                       uint32_t *__restrict__ fwd, BcdBorderline bl)
+                                                       uint32_t *__restrict__ fwd, BcdBorderline bl, int rb0, int row_end)
 {
     const int lane = threadIdx.x;
     const int c = blockIdx.x * 248 - 4 + 4 * lane; // first of the lane's four columns
-    const int rb = blockIdx.y * FWD_RB;
+    const int rb = (blockIdx.y + rb0) * FWD_RB;
     const int wi = blockIdx.z;
     const bool writer = lane >= 1 && lane <= 62 && c < W;
     const size_t plane = (size_t)W * H;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APP
     if (writer) {
 #pragma unroll
         for (int i = 0; i < FWD_RB; ++i)
-            if (rb + i < H) {
+            if (rb + i < row_end) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) fwd[((size_t)(rb + i) * W + c + j) * fwords + wi] = word[i][j];
             }
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APP
 #pragma unroll
         for (int i = 0; i < FWD_RB; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pix[i * 4 + j] = (uint32_t)((rb + i) * W + c + j);
+            for (int j = 0; j < 4; ++j) { pix[i * 4 + j] = (uint32_t)((rb + i) * W + c + j); if (rb + i >= row_end) bword[i * 4 + j] = 0; }
         borderline_flush<FWD_RB * 4>(bl, bword, pix, wi, lane);
     }
 }
@@ -747,6 +747,54 @@ hipError_t bcd_launch_pairdist(const float *hist, const float *ns, int W, int H,
 
 hipError_t bcd_launch_verify_pairs(const float *, const float *, int, int, int, int, float, const void *, const int *, int, uint32_t *, hipStream_t);
 
+// forward bits of the lines [row_begin, row_end) (row_begin a multiple of FWD_RB; the planes of the lines row_begin - 1 .. row_end must be complete).
+// ap != nullptr: T / Cn are the approximate planes of k_pairdist_rw (T in binary16, passed as an untyped buffer); pairs within
+// tau (1 +- BCD_APPROX_DELTA) are appended to the borderline list
+hipError_t bcd_launch_fwd_masks_rows(const float *T, const uint8_t *Cn, int W, int H, int b, float tau, uint32_t *fwd_scratch, hipStream_t st,
+                                     const BcdBorderline *ap, int row_begin, int row_end)
+{
+    if (row_begin % FWD_RB != 0 || row_begin < 0 || row_end > H) return hipErrorInvalidValue;
+    if (row_begin >= row_end) return hipSuccess;
+    const int fwords = (bcd_delta_count(b) + 31) / 32;
+    BcdBorderline bl = { tau, nullptr, nullptr, 0 };
+    float tau_k = tau;
+    if (ap) { bl = *ap; bl.tau_hi = tau * (1.f + BCD_APPROX_DELTA); tau_k = tau * (1.f - BCD_APPROX_DELTA); }
+    // the wide kernel needs enough lines to fill the chip (few, fat wavefronts); small scales keep the narrow one
+    const bool wide = W % 4 == 0 && (int64_t)W * H >= 400000;
+    const int rb0 = row_begin / FWD_RB, nrb = (row_end - row_begin + FWD_RB - 1) / FWD_RB;
+    const dim3 gw((W + 247) / 248, nrb, fwords), gn((W + 61) / 62, nrb, fwords);
+    if (wide && ap)
+        hipLaunchKernelGGL(k_fwd_masks_w1v4<true>, gw, dim3(64), 0, st, reinterpret_cast<const __half *>(T), Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl, rb0, row_end);
+    else if (wide)
+        hipLaunchKernelGGL(k_fwd_masks_w1v4<false>, gw, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl, rb0, row_end);
+    else if (ap)
+        hipLaunchKernelGGL(k_fwd_masks_w1<true>, gn, dim3(64), 0, st, reinterpret_cast<const __half *>(T), Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl, rb0, row_end);
+    else
+        hipLaunchKernelGGL(k_fwd_masks_w1<false>, gn, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl, rb0, row_end);
+    return hipGetLastError();
+}
+
+// the rest of the w = 1 mask stage: exact re-evaluation of the listed borderline pairs (ap != nullptr), then the symmetric masks and |S|
+hipError_t bcd_launch_masks_finish(int W, int H, int b, float tau, uint32_t *mask, int32_t *count, uint32_t *fwd_scratch, hipStream_t st,
+                                   const BcdBorderline *ap, const float *hist, const float *ns, int D)
+{
+    const int side = 2 * b + 1, words = (side * side + 31) / 32, fwords = (bcd_delta_count(b) + 31) / 32;
+    if (ap) {
+        hipError_t e = bcd_launch_verify_pairs(hist, ns, W, H, D, b, tau, ap->list, ap->counter, ap->capacity, fwd_scratch, st);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    if (b == 6 || b == 12) {
+        const size_t lds = (size_t)(4 + b) * (64 + 2 * b) * fwords * sizeof(uint32_t);
+        if (b == 6)
+            hipLaunchKernelGGL(k_sym_masks_t<6>, grid, dim3(256), lds, st, fwd_scratch, W, H, mask, count);
+        else
+            hipLaunchKernelGGL(k_sym_masks_t<12>, grid, dim3(256), lds, st, fwd_scratch, W, H, mask, count);
+    } else
+        hipLaunchKernelGGL(k_sym_masks, grid, dim3(256), 0, st, fwd_scratch, W, H, b, fwords, words, mask, count);
+    return hipGetLastError();
+}
+
 // ap != nullptr: T / Cn are the approximate planes of k_pairdist_rw (T in binary16, passed as an untyped buffer); pairs within tau (1 +- BCD_APPROX_DELTA) are listed and
 // re-evaluated exactly from (hist, ns) before the symmetric masks are completed (w = 1 only)
 hipError_t bcd_launch_masks(const float *T, const uint8_t *Cn, int W, int H, int w, int b, float tau,
@@ -756,35 +804,9 @@ hipError_t bcd_launch_masks(const float *T, const uint8_t *Cn, int W, int H, int
     const int side = 2 * b + 1, words = (side * side + 31) / 32;
     int64_t npix = (int64_t)W * H;
     if (w == 1 && fwd_scratch) {
-        const int fwords = (bcd_delta_count(b) + 31) / 32;
-        BcdBorderline bl = { tau, nullptr, nullptr, 0 };
-        float tau_k = tau;
-        if (ap) { bl = *ap; bl.tau_hi = tau * (1.f + BCD_APPROX_DELTA); tau_k = tau * (1.f - BCD_APPROX_DELTA); }
-        // the wide kernel needs enough lines to fill the chip (few, fat wavefronts); small scales keep the narrow one
-        const bool wide = W % 4 == 0 && (int64_t)W * H >= 400000;
-        const dim3 gw((W + 247) / 248, (H + FWD_RB - 1) / FWD_RB, fwords), gn((W + 61) / 62, (H + FWD_RB - 1) / FWD_RB, fwords);
-        if (wide && ap)
-            hipLaunchKernelGGL(k_fwd_masks_w1v4<true>, gw, dim3(64), 0, st, reinterpret_cast<const __half *>(T), Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
-        else if (wide)
-            hipLaunchKernelGGL(k_fwd_masks_w1v4<false>, gw, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
-        else if (ap)
-            hipLaunchKernelGGL(k_fwd_masks_w1<true>, gn, dim3(64), 0, st, reinterpret_cast<const __half *>(T), Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
-        else
-            hipLaunchKernelGGL(k_fwd_masks_w1<false>, gn, dim3(64), 0, st, T, Cn, W, H, b, tau_k, fwords, bcd_delta_count(b), fwd_scratch, bl);
-        if (ap) {
-            hipError_t e = bcd_launch_verify_pairs(hist, ns, W, H, D, b, tau, bl.list, bl.counter, bl.capacity, fwd_scratch, st);
-            if (e != hipSuccess) return e;
-        }
-        dim3 grid((W + 63) / 64, (H + 3) / 4);
-        if (b == 6 || b == 12) {
-            const size_t lds = (size_t)(4 + b) * (64 + 2 * b) * fwords * sizeof(uint32_t);
-            if (b == 6)
-                hipLaunchKernelGGL(k_sym_masks_t<6>, grid, dim3(256), lds, st, fwd_scratch, W, H, mask, count);
-            else
-                hipLaunchKernelGGL(k_sym_masks_t<12>, grid, dim3(256), lds, st, fwd_scratch, W, H, mask, count);
-        } else
-            hipLaunchKernelGGL(k_sym_masks, grid, dim3(256), 0, st, fwd_scratch, W, H, b, fwords, words, mask, count);
-        return hipGetLastError();
+        hipError_t e = bcd_launch_fwd_masks_rows(T, Cn, W, H, b, tau, fwd_scratch, st, ap, 0, H);
+        if (e != hipSuccess) return e;
+        return bcd_launch_masks_finish(W, H, b, tau, mask, count, fwd_scratch, st, ap, hist, ns, D);
     }
     if (ap) return hipErrorInvalidValue;
     dim3 block(64, 4);

@@ -253,8 +253,8 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
                 const float Tv = fmaf(qq, A1, rho * (Sy - A2));
                 const int nc = gc + dcA, nr = gr + dlA;
                 if (nc >= 0 && nc < W && nr < H) {
-                    // (the bound of the header with the larger of its two factors on every term)
-                    const float bound = fmaf((float)(max(Ln, C1y) + 10), fmaf(qq, A1, rho * (Sy + A2)), Tv + extra);
+                    // (the bound of the header with the larger of its two factors on every term; the count-ratio term only where a bin was live)
+                    const float bound = fmaf((float)(max(Ln, C1y) + 10), fmaf(qq, A1, rho * (Sy + A2)), Tv + ((Cm > 0 || A2 > 0.f) ? extra : 0.f));
                     imprecise = imprecise || bound > margin * (float)C;
                     const unsigned int e = eA + pix * (unsigned int)t_ps;
                     T[e] = __float2half_rn(fmaxf(Tv, 0.f));
@@ -287,7 +287,8 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
                 const float Tv = fmaf(qq, A1, rho * (Sy - A2));
                 const int nc = gc + dcB, nr = gr + dlB;
                 if (lane < 63 && gc < W && nc >= 0 && nc < W && nr < H) {
-                    const float bound = fmaf((float)(max(Ln, C1y) + 10), fmaf(qq, A1, rho * (Sy + A2)), Tv + extra);
+                    // (the bound of the header with the larger of its two factors on every term; the count-ratio term only where a bin was live)
+                    const float bound = fmaf((float)(max(Ln, C1y) + 10), fmaf(qq, A1, rho * (Sy + A2)), Tv + ((Cm > 0 || A2 > 0.f) ? extra : 0.f));
                     imprecise = imprecise || bound > margin * (float)C;
                     const unsigned int e = eB + pix * (unsigned int)t_ps;
                     T[e] = __float2half_rn(fmaxf(Tv, 0.f));
@@ -312,6 +313,87 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
             atomicAdd(prof + 0, (unsigned long long)pc[0]); atomicAdd(prof + 1, (unsigned long long)pc[1]);
             atomicAdd(prof + 3, (unsigned long long)pc[3]); atomicAdd(prof + 4, (unsigned long long)pc[4]);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Forward similarity bits from PIXEL-major planes (element (pixel, displacement i) at pixel * 85 + i: what k_pairdist_nz writes with
+// t_ps = 85, t_ds = 1).  Lanes = displacements, so the 3 x 3 patch sum of a displacement stays in one lane: a wavefront walks along a
+// strip of FWD_PM_RB lines, loads per column the FWD_PM_RB + 2 plane lines of its displacement (one coalesced 128-byte + 64-byte read per
+// line), keeps the last two columns in registers, and decides a column of FWD_PM_RB pixels per step -- any summation order: these are the
+// approximate planes, pairs inside tau (1 +- delta) go to the borderline list exactly like in k_fwd_masks_w1 (k_similarity.hip).
+//   CHUNK 0: displacements 0..63 of one strip (words 0 and 1 of the pixel's three forward words come straight from the ballot);
+//   CHUNK 1: displacements 64..84 of three strips (lanes 21 j .. 21 j + 20 = strip 3 blockIdx.x + j; word 2).
+// ---------------------------------------------------------------------------------------------------
+constexpr int FWD_PM_RB = 4, FWD_PM_ND = NZ_SIDE * NZ_B + NZ_B + 1; // 85
+
+template <int CHUNK>
+__global__ __launch_bounds__(64) void k_fwd_masks_pm(const __half *__restrict__ T, const uint8_t *__restrict__ Cn, int W, int H, float tau_lo,
+                                                     BcdBorderline bl, uint32_t *__restrict__ fwd, int strip_cols, int nstrips)
+{
+    const int lane = threadIdx.x;
+    const int sub = CHUNK == 0 ? 0 : lane / 21;
+    const int idx = CHUNK == 0 ? lane : 64 + (lane - 21 * sub);
+    const int strip = CHUNK == 0 ? (int)blockIdx.x : 3 * (int)blockIdx.x + sub;
+    const bool lane_on = (CHUNK == 0 || lane < 63) && strip < nstrips;
+    const int dl = (idx + NZ_B) / NZ_SIDE, dc = idx - NZ_SIDE * dl; // (idx 0: the self pair)
+    const int rb = blockIdx.y * FWD_PM_RB;
+    const int cs = min(strip, nstrips - 1) * strip_cols, ce = min(W, cs + strip_cols);
+    const int ncols = strip_cols; // (uniform loop bound; columns beyond a strip's end are gated by c < ce)
+    unsigned int line_off[FWD_PM_RB + 2];
+#pragma unroll
+    for (int i = 0; i < FWD_PM_RB + 2; ++i) line_off[i] = (unsigned int)(min(max(rb - 1 + i, 0), H - 1) * W) * FWD_PM_ND + idx;
+    // the plane values of three consecutive columns live in registers (t0 | t1 | t2 = columns c - 1 | c | c + 1 of the step that decides column c);
+    // the loads of column c + 2 are issued before column c is evaluated, so a step never waits for the loads it has just issued
+    float t0[FWD_PM_RB + 2], t1[FWD_PM_RB + 2], t2[FWD_PM_RB + 2];
+    int n0[FWD_PM_RB + 2], n1[FWD_PM_RB + 2], n2[FWD_PM_RB + 2];
+    auto load = [&](int c, float (&t)[FWD_PM_RB + 2], int (&n)[FWD_PM_RB + 2]) __attribute__((always_inline)) {
+        const unsigned int co = (unsigned int)min(max(c, 0), W - 1) * FWD_PM_ND;
+#pragma unroll
+        for (int i = 0; i < FWD_PM_RB + 2; ++i) { t[i] = __half2float(T[line_off[i] + co]); n[i] = Cn[line_off[i] + co]; }
+    };
+    load(cs - 1, t0, n0);
+    load(cs, t1, n1);
+    load(cs + 1, t2, n2);
+    for (int step = 0; step < ncols; ++step) {
+        const int c = cs + step; // the column decided in this step
+        float t3[FWD_PM_RB + 2], h[FWD_PM_RB + 2];
+        int n3[FWD_PM_RB + 2], hn[FWD_PM_RB + 2];
+        load(c + 2, t3, n3);
+#pragma unroll
+        for (int i = 0; i < FWD_PM_RB + 2; ++i) { h[i] = (t0[i] + t1[i]) + t2[i]; hn[i] = n0[i] + n1[i] + n2[i]; }
+        const int qc = c + dc;
+        const bool cols_ok = lane_on && c < ce && c >= 1 && c <= W - 2 && qc >= 1 && qc <= W - 2;
+#pragma unroll
+        for (int i = 0; i < FWD_PM_RB; ++i) {
+            const int r = rb + i;
+            const float sT = (h[i] + h[i + 1]) + h[i + 2];
+            const int n = hn[i] + hn[i + 1] + hn[i + 2];
+            const float fn = (float)n;
+            const bool ok = cols_ok && r >= 1 && r <= H - 2 && r + dl <= H - 2 && n > 0;
+            const bool sure = ok && sT <= tau_lo * fn; // (no division: see k_fwd_masks_w1; 0 / 0 in the reference is never similar)
+            const bool border = ok && !sure && sT <= bl.tau_hi * fn;
+            const unsigned long long ms = __builtin_amdgcn_ballot_w64(sure), mb = __builtin_amdgcn_ballot_w64(border);
+            if (r < H) {
+                if (CHUNK == 0) {
+                    if (lane < 2 && c < ce) fwd[(size_t)(r * W + c) * 3 + lane] = lane ? (uint32_t)(ms >> 32) : (uint32_t)ms;
+                } else {
+                    if (lane < 63 && lane == 21 * sub && strip < nstrips && c < ce) fwd[(size_t)(r * W + c) * 3 + 2] = (uint32_t)(ms >> (21 * sub)) & 0x1fffffu;
+                }
+            }
+            if (mb != 0ull) { // (rare) append the borderline pairs of this line: one atomic per wavefront
+                const int total = __builtin_popcountll(mb);
+                int base = 0;
+                if (lane == 0) base = atomicAdd(bl.counter, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (border) {
+                    const int slot = base + __builtin_popcountll(mb & ((1ull << lane) - 1ull));
+                    if (slot < bl.capacity) bl.list[slot] = make_uint2((uint32_t)(r * W + c), (uint32_t)idx);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FWD_PM_RB + 2; ++i) { t0[i] = t1[i]; t1[i] = t2[i]; t2[i] = t3[i]; n0[i] = n1[i]; n1[i] = n2[i]; n2[i] = n3[i]; }
     }
 }
 
@@ -360,4 +442,17 @@ hipError_t bcd_launch_pairdist_nz(const float *hist, const float *ns, int W, int
 #undef BCD_NZ_LAUNCH1
 #undef BCD_NZ_LAUNCH2
     return hipErrorInvalidValue;
+}
+
+// forward bits from the pixel-major planes of bcd_launch_pairdist_nz (t_ps = 85, t_ds = 1); ap: the borderline list (tau_hi is set here)
+hipError_t bcd_launch_fwd_masks_pm(const void *T, const uint8_t *Cn, int W, int H, float tau, uint32_t *fwd, const BcdBorderline *ap, hipStream_t st)
+{
+    if (!ap) return hipErrorInvalidValue;
+    BcdBorderline bl = *ap;
+    bl.tau_hi = tau * (1.f + BCD_APPROX_DELTA);
+    const float tau_lo = tau * (1.f - BCD_APPROX_DELTA);
+    const int strip_cols = 16, nstrips = (W + strip_cols - 1) / strip_cols, nrb = (H + FWD_PM_RB - 1) / FWD_PM_RB;
+    hipLaunchKernelGGL(k_fwd_masks_pm<0>, dim3(nstrips, nrb), dim3(64), 0, st, static_cast<const __half *>(T), Cn, W, H, tau_lo, bl, fwd, strip_cols, nstrips);
+    hipLaunchKernelGGL(k_fwd_masks_pm<1>, dim3((nstrips + 2) / 3, nrb), dim3(64), 0, st, static_cast<const __half *>(T), Cn, W, H, tau_lo, bl, fwd, strip_cols, nstrips);
+    return hipGetLastError();
 }

@@ -39,10 +39,10 @@ class ScaleStats(C.Structure):
 # every symbol include/bcd_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
-    "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_set_cu_share", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
+    "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_set_strict_eigensolver", "bcd_hip_set_cu_share", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
     "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_last_upload_bytes", "bcd_hip_selftest_pack32", "bcd_hip_set_progress_callback",
     "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_set_progress_callback", "bcd_hip_multi_set_frame_timeout", "bcd_hip_multi_set_comm_trace", "bcd_hip_multi_get_comm_trace", "bcd_hip_multi_denoise_host",
-    "bcd_hip_multi_unique_id", "bcd_hip_multi_create_rank", "bcd_hip_multi_rank_configure", "bcd_hip_multi_rank_upload", "bcd_hip_multi_rank_step",
+    "bcd_hip_multi_unique_id", "bcd_hip_multi_rccl_info", "bcd_hip_multi_create_rank", "bcd_hip_multi_rank_configure", "bcd_hip_multi_rank_upload", "bcd_hip_multi_rank_step",
     "bcd_hip_multi_rank_download", "bcd_hip_multi_rank_renew_ids", "bcd_hip_multi_set_loopback", "bcd_hip_multi_selftest_transport",
     "bcd_hip_scale_begin", "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_similarity_masks_deferred", "bcd_hip_similarity_masks_verdict", "bcd_hip_similarity_masks_exact", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step",
     "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
@@ -342,7 +342,7 @@ class Context:
         H, W, D = hist.shape
         r, n, f = C.c_float(0), C.c_int64(0), C.c_int(0)
         m0, m1, m2 = C.c_float(0), C.c_float(0), C.c_float(0)
-        prof = (C.c_int64 * 7)()
+        prof = (C.c_int64 * 8)()
         self._chk(lib().bcd_hip_selftest_nz_distance(self.h, _dp(hist), _dp(ns), W, H, D, int(b), C.c_float(tau), int(variant), int(reps), C.byref(r), C.byref(n), C.byref(f),
                                                      C.byref(m0), C.byref(m1), C.byref(m2), prof))
         self.nz_prof = list(prof)
@@ -428,6 +428,28 @@ class MultiDenoiser:
 
 
 MULTI_ID_BYTES = 128
+
+
+def set_strict_eigensolver(on):
+    """process-wide: the fully converged stopping rule of the estimate chain's eigensolver (bcd_hip_set_strict_eigensolver)"""
+    lib().bcd_hip_set_strict_eigensolver(1 if on else 0)
+
+
+def rccl_info():
+    """{"native": what libbcd_hip.so's band driver is linked against at run time, "mapped": every librccl copy mapped into this process}"""
+    buf = C.create_string_buffer(512)
+    lib().bcd_hip_multi_rccl_info(buf, 512)
+    mapped = []
+    try:
+        for ln in open("/proc/self/maps"):
+            f = ln.split()
+            if len(f) >= 6 and "librccl" in f[5] and f[5] not in mapped:
+                mapped.append(f[5])
+    except OSError:
+        pass
+    native = buf.value.decode()
+    path = native.split(" from ", 1)[1] if " from " in native else "?"
+    return {"native": native, "mapped": mapped, "one_copy": len(mapped) <= 1, "native_is_mapped": os.path.realpath(path) in [os.path.realpath(m) for m in mapped]}
 
 
 def multi_unique_ids(n):

@@ -71,7 +71,7 @@ namespace
 		cout << "    -m <float in [0,1]>  Probability of skipping marked centers of denoised patches (default: " << d.m_markedPixelsSkippingProbability << ")" << endl;
 		cout << "    -s <int>             Number of Scales for Multi-Scaling (default: " << d.m_nbOfScales << ")" << endl;
 		cout << "    --ncores <n>         the loop runs on the HIP device; n > 1 with -r 0 selects the reference's strip visiting order" << endl;
-		cout << "    --use-cuda <0/1>     1 (default): run on the HIP device; 0 asks for the CPU path, which this build does not have: the run is refused" << endl;
+		cout << "    --use-cuda <0/1>     1 (default): run on the HIP device; 0 asks for the CPU path, which this build does not have: declined with a note, the device runs (BCD_STRICT_CPU_REQUEST=1: refused)" << endl;
 		cout << "    -e <float>           Minimum eigen value for matrix inversion (default: " << d.m_minEigenValue << ")" << endl;
 		cout << "    --seed <int>         Seed of the random pixel order (default: " << d.m_orderSeed << ")" << endl;
 		cout << "    --device <int>       HIP device index (default: 0)" << endl;
@@ -228,15 +228,19 @@ namespace
 
 	int launchBayesianCollaborativeDenoising(int argc, const char** argv)
 	{
-		// --use-cuda 0 asks for the reference's CPU/OpenMP loop, which this build does not have (one product path: the HIP device).  Said
-		// before the input files are read, not after minutes of EXR decoding (the library refuses the same request with `false`)
-		for(int i = 1; i + 1 < argc; ++i)
-			if(string(argv[i]) == "--use-cuda" && atoi(argv[i + 1]) != 1)
-			{
-				cerr << "bcd_cli: --use-cuda 0 requests the CPU/OpenMP path, which this build does not have; nothing was read or written. "
-						"Run without the flag (or --use-cuda 1) to denoise on the HIP device" << endl;
-				return 2;
-			}
+		// --use-cuda 0 asks for the reference's CPU/OpenMP loop, which this build does not have (one product path: the HIP device).  The library
+		// declines the request with a note and runs on the device (Denoiser.cpp); under BCD_STRICT_CPU_REQUEST=1 it refuses instead, and that is
+		// said here, before the input files are read, not after minutes of EXR decoding
+		{
+			const char* pStrict = getenv("BCD_STRICT_CPU_REQUEST");
+			for(int i = 1; i + 1 < argc; ++i)
+				if(string(argv[i]) == "--use-cuda" && atoi(argv[i + 1]) != 1 && pStrict != nullptr && pStrict[0] == '1')
+				{
+					cerr << "bcd_cli: --use-cuda 0 requests the CPU/OpenMP path, which this build does not have, and BCD_STRICT_CPU_REQUEST=1 forbids "
+							"answering it with the HIP device; nothing was read or written" << endl;
+					return 2;
+				}
+		}
 		ProgramArguments args;
 		if(!parseProgramArguments(argc, argv, args))
 			return 1;

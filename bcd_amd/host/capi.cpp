@@ -182,6 +182,16 @@ int bcdcore_spike_filter(float* col, float* ns, float* hist, float* cov, int W, 
 	return 0;
 }
 
+// the host loops of the prefilter on their own (what filter() runs without a usable device): tests pin them against the reference's fixture on any box
+int bcdcore_spike_filter_host(float* col, float* ns, float* hist, float* cov, int W, int H, int D, float factor)
+{
+	Deepimf c(W, H, 3), n(W, H, 1), h(W, H, D), v(W, H, 6);
+	c.copyDataFrom(col); n.copyDataFrom(ns); h.copyDataFrom(hist); v.copyDataFrom(cov);
+	SpikeRemovalFilter::filterOnHost(c, n, h, v, factor);
+	c.copyDataTo(col); n.copyDataTo(ns); h.copyDataTo(hist); v.copyDataTo(cov);
+	return 0;
+}
+
 int bcdcore_merge_hist_ns(const float* hist, const float* ns, int W, int H, int D, float* out)
 {
 	Deepimf h(W, H, D), n(W, H, 1);

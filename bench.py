@@ -108,7 +108,7 @@ def per_scale_stats(ctx, S):
                        "processed_frac": round(st.processed / max(1, st.main_pixels), 4),
                        "fallback_frac": round(st.fallback / max(1, st.processed), 4),
                        "mean_similar": round(st.similar_total / max(1, st.processed), 2), "rounds": st.active_rounds,
-                       "borderline_pairs": st.borderline_pairs if st.similarity_path == 1 else None, "cu_share_pct": st.cu_share, "spectral_inverses": st.spectral_inverses})
+                       "borderline_pairs": st.borderline_pairs if st.similarity_path >= 1 else None, "similarity_path": st.similarity_path, "cu_share_pct": st.cu_share, "spectral_inverses": st.spectral_inverses})
     return scales
 
 
@@ -188,6 +188,9 @@ def predicted_8gpu(args, frame_ms):
 
 def main():
     args = parse()
+    # multi-process GPU work on these hosts needs dmabuf IPC (the host driver does not support the legacy IPC mode: without it RCCL's
+    # hipIpcGetMemHandle fails); the variable is read when the HSA runtime starts, i.e. before torch is imported
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.predict_band_child:
         return predict_band_child(args)
     import torch
@@ -285,6 +288,34 @@ def main():
                 ms4 = float(t4.item()) * 1e3 / 3
                 extras["frame_4k"] = {"value": round(w4 * h4 / 1e6 / (ms4 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms4, 4), "steps": 3,
                                       "workload": "3840x2160 frame of the same generator and flags (BASELINE configs[3]) over the same %d row bands, inputs resident" % world}
+                # BASELINE configs[4] over the same row bands: -b 12 -r 1 with the spike prefilter.  The prefilter (a 3 x 3
+                # per-pixel kernel: 0.8 ms of the 46 ms frame at N = 1, where it is inside the timed step) runs once per rank on its band's input
+                # lines before the upload -- with one extra line on either interior side, dropped afterwards, so that every kept line sees the
+                # neighbourhood it has in the whole frame -- and is NOT in the timed region here.
+                prm12 = bh.default_params(b=12, w=w, m=args.skip_prob, random_order=1, seed=1234)
+                l0, nl, _, _ = rd.configure(w4, h4, 60, S, prm12)
+                g0, g1 = max(0, l0 - 1), min(h4, l0 + nl + 1)
+                part = [torch.from_numpy(a).cuda() for a in core.synthetic_scene(w4, h4, args.spp, 1234, args.sigma, args.spikes, g0, g1 - g0)]
+                filt = ctx.spike_filter(*part, 2.0)
+                rd.upload(*[np.ascontiguousarray(t.cpu().numpy()[l0 - g0:l0 - g0 + nl]) for t in filt])
+                del part, filt
+                rd.step()
+                rd.step()
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    rd.step()
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t12 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+                if world > 1:
+                    dist.all_reduce(t12, op=dist.ReduceOp.MAX)
+                ms12 = float(t12.item()) * 1e3 / 2
+                extras["frame_4k_b12_prefilter"] = {"value": round(w4 * h4 / 1e6 / (ms12 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms12, 4), "steps": 2,
+                                                    "workload": "3840x2160, -b 12 -r 1, prefiltered inputs (BASELINE configs[4]) over the same %d row bands; the prefilter itself is outside the timed region at N > 1" % world}
             load(W, H)
             rd.step()   # (workspaces and the size of the first marking batch settle in two steps at a new frame size; untimed,
             rd.step()   # before the warm-up steps the caller asked for)
@@ -350,13 +381,7 @@ def main():
                     "wave_issued_bins_x64": wave_bins * 64, "wave_issued_frac": round(wave_bins * 64 / slots, 4), "wave_groups_entered": wave_groups,
                     "flop": flop, "kernel_ms": round(k_ms, 4), "achieved_tflops": round(flop / (k_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(flop / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
-                    "issued_tflops": round((2 * slots + 6 * 64 * wave_bins) / (k_ms * 1e-3) / 1e12, 3),
-                    "flop_model": "per (pixel pair, bin) slot of the 85 half-plane displacements: the skip test b1 + b2 > 1 = 2 (add, compare); per EVALUATED term "
-                                  "(DenoisingUnit.cpp:379-383): subtract, square, reciprocal, fused multiply-add, count = 6.  evaluated_bins is counted on the device by a "
-                                  "counting instantiation of the kernel (bcd_hip_selftest_bin_work), kernel_ms is the production instantiation on the same input, alone on the chip. "
-                                  "issued_tflops prices every lane of a wavefront that issues a bin (a bin is issued when any of its 64 pairs needs it). "
-                                  "The 157.3 TFLOP/s peak counts packed fp32 at full rate; v_pk_fma_f32 was measured at half rate on this chip (tools/ubench/pk_rate.hip), "
-                                  "so a kernel of plain fp32 instructions tops out at half the peak"}
+                    "issued_tflops": round((2 * slots + 6 * 64 * wave_bins) / (k_ms * 1e-3) / 1e12, 3)}
         except Exception as e:   # (reported, never fatal for the headline)
             valu = {"error": "%s: %s" % (type(e).__name__, e)}
     if single and not args.no_extras:
@@ -418,6 +443,18 @@ def main():
         extras["textured_low_noise"] = dict(tex_low, workload="the textured frame with sigma 0.10, no spikes")
         extras["m0"] = dict(leg((col, ns, hist, cov), bh.default_params(b=b, w=w, m=0.0, random_order=args.random_order, seed=1234), 2),
                             workload="the default frame with -m 0 (no marking: every main pixel is processed)")
+        # General sample counts (src/core/DenoisingUnit.cpp:371-383 takes any n1, n2): the headline frame at a uniform 24 spp (not
+        # a power of two: the count products do not drop out) and with per-pixel counts drawn from {16, 24, 32, 48} (48-spp statistics thinned per
+        # pixel: histogram and count scaled by 1/3, 1/2, 2/3 or 1 -- what an adaptive sampler's early exit leaves).  Both take the own-list distance
+        # kernel (similarity_path 2 in per_scale).
+        f24 = core.synthetic_scene(W, H, 24, 1234, args.sigma, args.spikes)
+        extras["nonuniform_counts"] = {"uniform_24spp": leg(f24, prm, 3)}
+        col48, ns48, hist48, cov48 = core.synthetic_scene(W, H, 48, 1234, args.sigma, args.spikes)
+        keep = np.random.default_rng(5).choice(np.array([1.0 / 3.0, 0.5, 2.0 / 3.0, 1.0], np.float32), size=(H, W, 1)).astype(np.float32)
+        ns_mix = np.ascontiguousarray(np.rint(ns48 * keep).astype(np.float32))
+        hist_mix = np.ascontiguousarray(hist48 * (ns_mix / ns48))
+        extras["nonuniform_counts"]["mixed_16_24_32_48"] = leg((col48, ns_mix, hist_mix, cov48), prm, 3)
+        del col48, ns48, hist48, cov48, hist_mix, ns_mix, f24
         # BASELINE configs[3]'s frame on this one GPU: the N = 1 point of the 4K strong-scaling curve (north_star), untimed leg
         if not args.no_4k:
             w4, h4 = 3840, 2160
@@ -456,11 +493,10 @@ def main():
                 "launches": pd_launches,
                 "avg_launch_ms": round(pd_ms / max(1, pd_launches), 4),
                 "whole_process": {"launches": all_launches, "avg_launch_ms": round(all_ms / max(1, all_launches), 4),
-                                  "note": "all launches of this command incl. warm-up and the untimed legs: what `rocprofv3 --kernel-trace --stats` of the same command averages (profiles/)"},
+                                  },
                 "algorithmic_bytes_per_launch_avg": int(algo_bytes_per_step / S),
                 "isolated_avg_launch_ms": None if iso_ms is None else round(iso_ms, 4),
-                "isolated_frac": None if not iso_ms else round((algo_bytes_per_step / S) / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "VALU-bound kernel (85 displacements x 60 bins of chi-square per pixel); the 3 scales run concurrently on separate streams, so launch durations in the timed region include overlap -- isolated_* = the same kernel with the scales serialised; see DESIGN.md"}
+                "isolated_frac": None if not iso_ms else round((algo_bytes_per_step / S) / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     roofline["valu"] = valu
     # numbers taken offline (rocprofv3 --pmc passes) are only quoted while the kernel source they were taken on is the one that runs
     src_hash = source_hash(PAIRDIST_SOURCE)
@@ -498,6 +534,25 @@ def main():
         pass
 
     if rank == 0:
+        # The line ends with what a reader of its last 2 000 characters must find: `roofline` (compact), `cpu_baseline` (compact) and `legs` (bare
+        # [Mpix/s, ms per frame] pairs of every untimed leg).  Everything wordy -- per-scale counters of the legs, the distance kernel's counters, the
+        # band prediction's message sizes -- sits in `details` before them; what the fields mean is written down in DESIGN.md 8 ("The bench line").
+        details = {"roofline": roofline}
+        legs = {}
+
+        def pair(o):
+            return [o.get("value"), o.get("ms_per_step", o.get("ms_per_frame"))]
+        for name, o in extras.items():
+            if name == "nonuniform_counts":
+                for sub, oo in o.items():
+                    legs["nonuniform_" + sub] = pair(oo)
+            else:
+                legs[name] = pair(o)
+        details["legs"] = extras
+        rccl = bh.rccl_info()
+        if world > 1:
+            # the band driver must talk to the RCCL copy this process already holds (torch is imported first: same SONAME, one mapping -- DESIGN.md 7)
+            assert rccl["one_copy"] and rccl["native_is_mapped"], "two RCCL copies in one process: %r" % (rccl,)
         res = {
             "metric": "Mpixels/sec denoised (3-scale, b=6, w=1)", "value": round(W * H / 1e6 / (ms_step * 1e-3), 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
@@ -506,19 +561,33 @@ def main():
             "config": {"workload": "%dx%d synthetic frame (%s%d spp, sigma %.2f, spikes %.2f), %d-scale, b=%d w=1 d=1 e=1e-8, -m %g -r %d (seeded), no prefilter"
                                    % (W, H, "texture pattern, " if args.pattern else "", args.spp, args.sigma, args.spikes, S, b, args.skip_prob, args.random_order),
                        "parallelism": parallelism, "per_scale": scales},
-            "roofline": roofline,
+            "details": details,
         }
-        res.update(extras)
         if not single:
-            res["roofline"].update({"achieved": None, "frac": None, "launches": None, "avg_launch_ms": None,
-                                    "note": "kernel timing is reported by the single-GPU run (N = 1); the band drivers keep their engine contexts inside"})
-            res["roofline"].pop("whole_process", None)
+            roofline.update({"achieved": None, "frac": None, "launches": None, "avg_launch_ms": None})
+            roofline.pop("whole_process", None)
             if band_check is not None:
-                res["band_check"] = band_check
+                details["band_check"] = band_check
         if single and not (args.no_extras or args.no_predict):
-            res["predicted_8gpu"] = predicted_8gpu(args, frame4k_ms)
+            pred = predicted_8gpu(args, frame4k_ms)
+            details["predicted_8gpu"] = pred
+            legs["predicted_8gpu"] = [pred.get("speedup_before_waiting"), pred.get("band_ms")] if "error" not in pred else ["error", None]
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args)
+            cpu = cpu_baseline(args)
+            details["cpu_baseline"] = cpu
+        v = roofline.get("valu") or {}
+        busy = roofline.get("vector_pipe_busy_profiled") or {}
+        res["rccl"] = {"native": rccl["native"], "one_copy": rccl["one_copy"]}
+        res["roofline"] = {"bound": "hbm", "achieved": roofline["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roofline["frac"], "traffic": roofline["traffic"],
+                           "kernel": "k_pairdist_rw<60>" if fast else "k_pairdist<60>", "avg_launch_ms": roofline["avg_launch_ms"],
+                           "isolated_avg_launch_ms": roofline["isolated_avg_launch_ms"], "isolated_frac": roofline["isolated_frac"],
+                           "valu": {"achieved": v.get("achieved_tflops"), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": v.get("frac"), "pipe_busy": busy.get("frac")},
+                           "kernel_source_sha256_16": roofline["kernel_source_sha256_16"]}
+        if cpu is not None:
+            res["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                   "sample": "%s, %d-scale, best of 3 on all cores" % (cpu["sample"].split(" synthetic")[0], S), "one_core": cpu["one_core"]["value"]}
+        res["legs"] = legs
         # native libraries (RCCL's version banner) write to the C stdio buffer: flush it first so that the JSON line is the last line
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)

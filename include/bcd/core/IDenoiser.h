@@ -35,8 +35,8 @@ namespace bcd
 		float m_minEigenValue; ///< eigenvalue floor used when inverting covariance matrices
 		bool m_useRandomPixelOrder; ///< visit main pixels in a (seeded, reproducible) pseudo-random order
 		float m_markedPixelsSkippingProbability; ///< 1: skip centres of already denoised patches; 0: process every pixel
-		int m_nbOfCores; ///< kept for source compatibility; the GPU engine ignores it
-		bool m_useCuda; ///< kept for source compatibility; this build always runs on the HIP device
+		int m_nbOfCores; ///< <= 0: OpenMP's default; the thread count the reference would run with is written back by denoise() and, without m_useRandomPixelOrder, selects the visiting order (> 1: strip list, 1: scanline) -- the loop itself runs on the HIP device
+		bool m_useCuda; ///< a request, as in the reference: true (default) = the HIP device; false = the CPU/OpenMP path, which this build does not have -- declined with a note on cout and served by the device (refused with `false` under BCD_STRICT_CPU_REQUEST=1)
 	};
 
 	/// Non-owning pointers to the four input images (must outlive denoise())

@@ -1,5 +1,5 @@
 // SpikeRemovalFilter.h -- optional outlier prefilter (bcd_cli -p); API of the reference's
-// include/bcd/core/SpikeRemovalFilter.h.  Runs as a HIP kernel (bcd_hip_spike_filter).
+// include/bcd/core/SpikeRemovalFilter.h.  Runs as a HIP kernel (bcd_hip_spike_filter); without a usable device, as host loops.
 #ifndef SPIKE_REMOVAL_FILTER_H
 #define SPIKE_REMOVAL_FILTER_H
 
@@ -21,9 +21,19 @@ namespace bcd
 				float i_thresholdStDevFactor = 2.f);
 
 		/// the same on a chosen HIP device, with a result: false = no usable device or a device error (the images are then
-		/// unchanged or partially filtered, and a message is on cerr).  filter() is this on device 0 with the reference's void signature
+		/// unchanged or partially filtered, and a message is on cerr unless i_quiet).  filter() is this on device 0 with the reference's void
+		/// signature, falling back to filterOnHost() when there is no usable device
 		static bool filterOnDevice(
 				int i_device,
+				DeepImage<float>& io_rInputColorImage,
+				DeepImage<float>& io_rInputNbOfSamplesImage,
+				DeepImage<float>& io_rInputHistogramImage,
+				DeepImage<float>& io_rInputCovImage,
+				float i_thresholdStDevFactor = 2.f,
+				bool i_quiet = false);
+
+		/// the same as host loops (OpenMP over the lines): what filter() runs when no HIP device is usable
+		static void filterOnHost(
 				DeepImage<float>& io_rInputColorImage,
 				DeepImage<float>& io_rInputNbOfSamplesImage,
 				DeepImage<float>& io_rInputHistogramImage,

@@ -68,8 +68,9 @@ typedef struct bcd_hip_scale_stats {
     float   ms_active;
     float   ms_bayes;
     float   ms_total;
-    int32_t similarity_path;  /* 1 = approximate planes + exact verification at the threshold, 0 = exact planes */
-    int32_t borderline_pairs; /* pairs re-evaluated exactly (similarity_path == 1)  */
+    int32_t similarity_path;  /* 1 = approximate planes + exact verification at the threshold, 2 = the same with the own-list distance kernel
+                               * (general sample counts, search radius 6), 0 = exact planes */
+    int32_t borderline_pairs; /* pairs re-evaluated exactly (similarity_path >= 1)  */
     int32_t cu_share;         /* share (%) of the CU slots this scale's persistent estimate kernels took (100: all)  */
     int32_t spectral_inverses; /* full estimates (3x3 patches, default search radius) whose matrix inverse failed the sweep's checks and took
                                   the spectral branch of inverseSymmetricMatrix in the LDS kernel (normally 0)        */
@@ -91,6 +92,10 @@ int  bcd_hip_set_concurrent_scales(bcd_hip_ctx *ctx, int enabled);
  * Default on for w = 1, D in {24, 36, 60} and tau in [2^-6, 64] -- other settings take the exact kernels; also disabled by
  * BCD_HIP_EXACT_SIMILARITY=1.  The masks are bit-identical either way; 0 forces the exact kernels. */
 int  bcd_hip_set_fast_similarity(bcd_hip_ctx *ctx, int enabled);
+/* process-wide: 1 = the eigensolver of the Bayesian steps (Eigen::SelfAdjointEigenSolver of DenoisingUnit.cpp:589,617) runs to off^2 <= 1e-12 diag^2
+ * instead of the production rule (2e-9 + first-order correction of the positive part): ~1.5 % of a step for a 3x smaller deviation on
+ * ill-conditioned low-sample frames (4K at 8 spp: 2.9e-6 instead of 9.8e-6 from the CPU path).  Default: the environment's BCD_HIP_STRICT_EIGEN (0). */
+int  bcd_hip_set_strict_eigensolver(int enabled);
 /* share (1..100 %, default 100) of the device's CU slots the persistent estimate kernels of this context occupy.  A caller that
  * runs several contexts on one device at once lowers it for the contexts that have slack, so that the short kernels of the one on
  * the critical path find room beside them (bcd_hip_denoise does this itself for its coarse scales; the multi-GPU driver uses
@@ -174,6 +179,9 @@ int  bcd_hip_multi_denoise_host(bcd_hip_multi *m, const float *h_colors, const f
  * the band stay in HBM.  bcd_hip_multi_rank_download copies the owned lines [first_owned_line, +nb_owned_lines) of the result. */
 #define BCD_HIP_MULTI_ID_BYTES 128
 int  bcd_hip_multi_unique_id(char *out /* BCD_HIP_MULTI_ID_BYTES */);
+/* which RCCL library this build talks to: "rccl version <code> from <path of the shared object ncclCommInitRank resolved to>" (a process that also
+ * maps a second copy -- an ML framework's bundled one -- can tell which of the two serves the band driver; BCD_HIP_MULTI_VERBOSE=1 prints the same at communicator creation) */
+int  bcd_hip_multi_rccl_info(char *out, int capacity);
 int  bcd_hip_multi_create_rank(bcd_hip_multi **m, int rank, int n_ranks, int device, const char *ids, int n_ids);
 int  bcd_hip_multi_rank_configure(bcd_hip_multi *m, int W, int H, int D, int nb_scales, const bcd_hip_params *prm, int *first_input_line,
                                   int *nb_input_lines, int *first_owned_line, int *nb_owned_lines);
@@ -325,10 +333,10 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
  * b1 = 0 enter by the closed form the rule of src/core/DenoisingUnit.cpp:379-383 allows; search radius 6 only): *max_rel_dev /
  * *count_mismatches as above (against the exact planes), *flags = the kernel's range (1) / absolute-error (4) flag bits; best-of-reps kernel times:
  * *ms_nz (pixel-major planes), *ms_nz_plane_major, *ms_dense (k_pairdist_rw on the same input).  variant: bit 0 = own bins by v_readlane instead of scalar loads, bit 1 = straight-line bin body;
- * prof7 (may be NULL): shader-clock sums of a counting launch -- staging, S pass, wavefronts inside the item loop, item phase x 16, whole workgroups --, the bin slots
- * issued and that launch's duration in microseconds */
+ * prof8 (may be NULL): shader-clock sums of a counting launch -- staging, S pass, wavefronts inside the item loop, item phase x 16, whole workgroups --, the bin slots
+ * issued, that launch's duration in microseconds, and the dense kernel's with the general (non-uniform) formula */
 int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius, float tau, int variant,
-                                 int reps, float *max_rel_dev, int64_t *count_mismatches, int *flags, float *ms_nz, float *ms_nz_plane_major, float *ms_dense, int64_t *prof7);
+                                 int reps, float *max_rel_dev, int64_t *count_mismatches, int *flags, float *ms_nz, float *ms_nz_plane_major, float *ms_dense, int64_t *prof8);
 
 /* the eigensolver of the Bayesian steps on its own (Eigen::SelfAdjointEigenSolver of DenoisingUnit.cpp:589,617 for 27 x 27 matrices):
  * d_A = n symmetric matrices, 28 x 28 floats each, row-major, row / column 27 zero; d_eig[n][28] = eigenvalues (unordered, entry 27 = 0),

@@ -11,6 +11,10 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4  # relative L-inf on in-memory fp32 buffers (north_star)
+# The full-size frames have a budget of their own (round 5): they measure 1e-6 ... 1e-5 against the oracle (9.8e-6 on the 4K 8-spp frame since the
+# eigensolver stops at 2e-9 with a first-order correction), so a further loosening of a solver or an accumulation order is a red test here long
+# before it reaches the north-star bar.
+TOL_FULL_SIZE = 3e-5
 
 
 def rel_linf(a, b):
@@ -622,7 +626,7 @@ def test_720p_three_scale_frame_against_the_oracle(hipctx):
     want = ol.denoise_multiscale(col, ns, hist, cov, 3, ol.params(m=0.0, threads=threads))
     ok = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), ok)
-    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL_FULL_SIZE
 
 
 @pytest.mark.gpu
@@ -641,7 +645,7 @@ def test_1080p_headline_frame_against_the_oracle(hipctx):
     want = ol.denoise_multiscale(col, ns, hist, cov, 3, ol.params(m=0.0, threads=threads))
     ok = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), ok)
-    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL_FULL_SIZE
 
 
 @pytest.mark.gpu
@@ -661,7 +665,7 @@ def test_1080p_bench_workload_against_the_oracle(hipctx):
     want = ol.denoise_multiscale(col, ns, hist, cov, S, ol.params(m=1.0, skip_seed=1234, threads=threads), orders=_orders(W, H, 1, 1, 1234, S))
     ok = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), ok)
-    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL_FULL_SIZE
 
 
 @pytest.mark.gpu
@@ -680,7 +684,7 @@ def test_4k_config3_frame_against_the_oracle(hipctx):
     want = ol.denoise_multiscale(col, ns, hist, cov, S, ol.params(m=1.0, skip_seed=17, threads=threads), orders=_orders(W, H, 1, 1, 17, S))
     ok = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), ok)
-    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL_FULL_SIZE
 
 
 @pytest.mark.gpu
@@ -699,7 +703,7 @@ def test_4k_config4_frame_against_the_oracle(hipctx):
     want = ol.denoise_multiscale(fc, fn, fh, fv, S, ol.params(b=b, m=1.0, skip_seed=23, threads=threads), orders=_orders(W, H, 1, 1, 23, S))
     ok = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), ok)
-    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL_FULL_SIZE
 
 
 @pytest.mark.gpu
@@ -866,10 +870,84 @@ def test_fast_similarity_path_is_the_default_and_reports_its_borderline_pairs(hi
     import bcd_amd.hip as bh
     col, ns, hist, cov = core.synthetic_scene(320, 200, 32, 1234, 0.35, 0.01)
     prm = bh.default_params(b=6, w=1, m=1.0, random_order=1, seed=1234)
-    out = hipctx.denoise(*dev(col, ns, hist, cov), 1, prm)
-    st = hipctx.stats(0)
+    fresh = bh.Context(0)  # (a workspace that remembers frames with mixed sample counts would start with the general formula: path 2)
+    out = fresh.denoise(*dev(col, ns, hist, cov), 1, prm)
+    st = fresh.stats(0)
     assert st.similarity_path == 1 and 0 <= st.borderline_pairs < 320 * 200
     assert np.isfinite(out.cpu().numpy()[1:-1, 1:-1]).all()
+
+
+def _drop_samples(W, H, spp, seed, keep_frac, sigma=0.3):
+    """a frame whose pixels carry different sample counts (adaptive sampling): a random subset of a uniform sample stream"""
+    rng = np.random.default_rng(seed)
+    samples, _ = ol.synth_samples(W, H, spp, seed=seed, sigma=sigma, spike_prob=0.01)
+    keep = rng.random(samples.shape[0]) < keep_frac
+    keep[::spp] = True
+    ns, mean, cov, hist = ol.oracle_ops()["accumulate"](np.ascontiguousarray(samples[keep]), W, H)
+    return mean, ns, hist, cov
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,S", [(0.0, 1), (1.0, 2)])
+def test_frames_with_mixed_sample_counts_take_the_own_list_kernel_and_match_the_oracle(hipctx, m, S):
+    """general sample counts (src/core/DenoisingUnit.cpp:371-383 takes any n1, n2): the production path is the own-list distance kernel + the
+    pixel-major mask kernel (similarity_path 2); the frame is the oracle's"""
+    import bcd_amd.hip as bh
+    W, H = 96, 72
+    col, ns, hist, cov = _drop_samples(W, H, 16, 9, 0.7)
+    assert len(np.unique(ns)) > 3
+    prm = bh.default_params(m=m, random_order=0, seed=5)
+    got = hipctx.denoise(*dev(col, ns, hist, cov), S, prm).cpu().numpy()
+    assert hipctx.stats(0).similarity_path == 2
+    if S == 1:
+        want = ol.denoise_mono(col, ns, hist, cov, ol.params(m=m), order=_orders(W, H, 1, 0, 5, 1)[0] if m != 0.0 else None)
+    else:
+        want = ol.denoise_multiscale(col, ns, hist, cov, S, ol.params(m=m), orders=_orders(W, H, 1, 0, 5, S) if m != 0.0 else None)
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
+
+
+@pytest.mark.gpu
+def test_own_list_kernel_declines_when_its_error_bound_fails_and_the_dense_kernel_takes_over(hipctx):
+    """hundreds of samples per pixel (a coarse pyramid level): the own-list kernel's absolute-error check fails (flag bit 2), the pass is repeated with the
+    dense kernel's general formula, and the masks are the exact kernels' either way"""
+    W, H = 64, 40
+    col, ns, hist, cov = _drop_samples(W, H, 16, 4, 0.8)
+    hist, ns = np.ascontiguousarray(hist * 40.0), np.ascontiguousarray(ns * 40.0)   # ~ 500 samples per pixel, counts still mixed
+    d_hist, d_ns = dev(hist, ns)
+    rel, count_mismatches, flags, *_ = hipctx.selftest_nz_distance(d_hist, d_ns, 6, 1.0, 3, 1)
+    assert count_mismatches == 0 and (flags & 4) != 0
+    import bcd_amd.hip as bh
+    fresh = bh.Context(0)                       # (a workspace that has not met such a frame yet)
+    m1, c1 = fresh.similarity_masks(d_hist, d_ns, 1, 6, 1.0)
+    wmask, wcnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
+    assert np.array_equal(m1.cpu().numpy().view(np.uint32), wmask) and np.array_equal(c1.cpu().numpy(), wcnt)
+    m2, c2 = fresh.similarity_masks(d_hist, d_ns, 1, 6, 1.0)      # second call: the workspace goes to the dense kernel directly
+    assert np.array_equal(m2.cpu().numpy().view(np.uint32), wmask)
+
+
+@pytest.mark.gpu
+def test_low_sample_frame_stays_inside_its_budget_and_strict_eigensolver_tightens_it(hipctx):
+    """an ill-conditioned low-sample frame at reduced size (8 spp, -m 0: every pixel takes the full estimate): the production stopping rule of the
+    eigensolver (2e-9 + first-order correction) stays within 2e-5 of the oracle, the strict rule (bcd_hip_set_strict_eigensolver) is not worse"""
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H = 160, 120
+    col, ns, hist, cov = core.synthetic_scene(W, H, 8, 77, 0.15, 0.0)
+    prm = bh.default_params(m=0.0)
+    want = ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0))
+    ok = np.isfinite(want)
+    d = dev(col, ns, hist, cov)
+    got = hipctx.denoise(*d, 1, prm).cpu().numpy()
+    e_prod = rel_linf(np.where(ok, got, 0), np.where(ok, want, 0))
+    try:
+        bh.set_strict_eigensolver(True)
+        got_s = hipctx.denoise(*d, 1, prm).cpu().numpy()
+    finally:
+        bh.set_strict_eigensolver(False)
+    e_strict = rel_linf(np.where(ok, got_s, 0), np.where(ok, want, 0))
+    assert e_prod < 2e-5 and e_strict < 2e-5 and e_strict <= e_prod * 1.5 + 1e-7, (e_prod, e_strict)
 
 
 @pytest.mark.gpu
@@ -1196,10 +1274,21 @@ def test_one_process_per_gpu_rank_api_with_one_rank(hipctx):
 
 
 @pytest.mark.gpu
+def test_cpu_request_is_declined_with_a_note_and_served_by_the_device(hipctx, capfd):
+    """m_useCuda = false through the C++ API (bcd::Denoiser / MultiscaleDenoiser): a note on cout, the device result (identical to m_useCuda = true)"""
+    import bcd_amd.core as core
+    col, ns, hist, cov = core.synthetic_scene(48, 40, 8, 3, 0.2, 0.0)
+    ok1, out1, _ = core.denoise(col, ns, hist, cov, 2, use_cuda=True, random_order=False)
+    ok0, out0, _ = core.denoise(col, ns, hist, cov, 2, use_cuda=False, random_order=False)
+    assert ok1 and ok0 and rel_linf(out0, out1) < 1e-6      # (two device runs: the accumulation order of the float atomics differs)
+    assert "running on the HIP device" in capfd.readouterr().out
+
+
+@pytest.mark.gpu
 def test_bcd_cli_baseline_config0_plumbing(hipctx, tmp_path):
     """BASELINE configs[0] as far as this build goes: `bcd_cli -s 1 -b 6 -w 1 --ncores 1 -r 0` on a 128 x 96 scene (the reference
-    bundles none: data/inputs holds a .gitignore only).  There is no CPU path: `--use-cuda 0` is REFUSED (exit code 2, message), never
-    silently answered by the device; without it the HIP device runs and the RESULT is the CPU path's -- the oracle's single-thread
+    bundles none: data/inputs holds a .gitignore only).  There is no CPU path: `--use-cuda 0` is declined with a note and served by the HIP device
+    (under BCD_STRICT_CPU_REQUEST=1: refused, exit code 2, before any file is read); the RESULT is the CPU path's -- the oracle's single-thread
     scanline run on the same (half-precision) colours"""
     import subprocess
     import bcd_amd.core as core
@@ -1213,11 +1302,15 @@ def test_bcd_cli_baseline_config0_plumbing(hipctx, tmp_path):
     out_path = str(tmp_path / "out.exr")
     flags = [exe, "-i", stem + ".exr", "-h", stem + "_hist.exr", "-c", stem + "_cov.exr", "-o", out_path, "-s", "1", "-b", "6", "-w", "1",
              "-r", "0", "-p", "0", "-m", "1", "--ncores", "1"]
+    r = subprocess.run(flags + ["--use-cuda", "0"], capture_output=True, text=True, env=dict(_os.environ, BCD_STRICT_CPU_REQUEST="1"))
+    assert r.returncode == 2 and "does not have" in r.stderr and not _os.path.exists(out_path)   # strict mode: the CPU request is refused, loudly
     r = subprocess.run(flags + ["--use-cuda", "0"], capture_output=True, text=True)
-    assert r.returncode == 2 and "does not have" in r.stderr and not _os.path.exists(out_path)   # the CPU request is refused, loudly
+    assert r.returncode == 0 and "running on the HIP device" in r.stdout, r.stdout + r.stderr     # default: declined with a note, served by the device
+    got_cpu_request = core.read_exr(out_path, False)
     r = subprocess.run(flags + ["--use-cuda", "1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     got = core.read_exr(out_path, False)
+    assert np.max(np.abs(got - got_cpu_request)) <= 1e-3 * np.max(got)     # (two device runs, written as half)
     col_h = core.read_exr(stem + ".exr", False)                           # colours as the CLI saw them (half on disk)
     want = ol.denoise_mono(col_h, ns, hist, cov, ol.params(b=6, m=1.0, threads=1))   # 1 thread, -r 0: plain scanline order
     want = np.where(np.isfinite(want) & (want >= 0), want, 0.0).astype(np.float32)
@@ -1526,8 +1619,10 @@ def test_streamed_host_upload_equals_the_resident_path(hipctx, spike_factor):
         assert rel_linf(got, want) < 1e-5
         # both paths stay on the approximate-planes kernels: a single odd pixel that the host's sample (streamed path) or the speculative
         # launch on the first pixel's count (resident path) misses is caught by the kernel's per-pixel check, and the pass is repeated with
-        # the general (non-uniform) formula
-        assert (path, hipctx.stats(0).similarity_path) == (1, 1)
+        # the general (non-uniform) formula -- since round 5 by the own-list distance kernel (similarity_path 2)
+        # (with the prefilter the odd pixel may itself be replaced by a neighbour, which makes the counts uniform again)
+        both = (path, hipctx.stats(0).similarity_path)
+        assert both == (1, 1) if (variant == "uniform" or spike_factor > 0 and both == (1, 1)) else both == (2, 2)
 
 
 @pytest.mark.gpu

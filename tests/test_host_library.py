@@ -32,6 +32,23 @@ def test_samples_accumulator_other_histogram_parameters():
         assert np.allclose(a[3].sum(-1), 3 * a[0][..., 0])       # each sample adds weight 1 to each channel's histogram
 
 
+def test_spike_filter_host_loops_match_the_reference_fixture_bit_for_bit():
+    """SpikeRemovalFilter::filterOnHost -- what filter() runs when no HIP device is usable -- against tests/golden/ref_spike.npz, the outputs of the
+    reference's own SpikeRemovalFilter.cpp (float-abs semantics); product code, nothing of oracle/ in it.  On a box without a device filter()
+    itself takes this path: the images must never come back untouched (the reference's filter is a host function)"""
+    f = np.load(os.path.join(G, "ref_spike.npz"))
+    got = core.spike_filter_host(f["mean"], f["ns"], f["hist"], f["cov"], float(f["factor"]))
+    for g, k in zip(got, ("o_mean", "o_ns", "o_hist", "o_cov")):
+        assert same(g, f[k]), k
+    assert not same(f["mean"], f["o_mean"])          # (the fixture does contain spikes)
+    via_filter = core.spike_filter(f["mean"], f["ns"], f["hist"], f["cov"], float(f["factor"]))   # device if there is one, else the host loops
+    for g, k in zip(via_filter, ("o_mean", "o_ns", "o_hist", "o_cov")):
+        assert same(g, f[k]), k
+    # a frame too small for a 3 x 3 neighbourhood is left alone
+    tiny = [np.ascontiguousarray(f[k][:2, :5]) for k in ("mean", "ns", "hist", "cov")]
+    assert all(same(a, b) for a, b in zip(core.spike_filter_host(*tiny), tiny))
+
+
 def test_histogram_packing_roundtrip():
     f = np.load(os.path.join(G, "ref_pyramid.npz"))
     m = core.merge_hist_ns(f["hist"], f["ns"])
@@ -58,10 +75,12 @@ def test_denoiser_rejects_bad_inputs_like_the_reference():
     assert core.denoise(col[:0], ns[:0], hist[:0], cov[:0])[0] is False  # empty (:294-320)
 
 
-def test_explicit_cpu_request_is_refused_not_substituted(capfd):
-    """DenoiserParameters::m_useCuda = false selects the CPU/OpenMP loop in the reference (src/core/Denoiser.cpp:99-110,241-265).  This
-    library has one path, the HIP device: the request is answered with `false` and a message on cerr -- on any host, with or without a
-    GPU, and before any device work -- never by silently running something else (error table)"""
+def test_explicit_cpu_request_is_refused_in_strict_mode(capfd, monkeypatch):
+    """DenoiserParameters::m_useCuda = false asks for the CPU/OpenMP loop of the reference (src/core/Denoiser.cpp:99-110,241-265), which this library
+    does not have.  Default (round 5): the request is declined with a note and the HIP device serves the call (GPU test
+    test_cpu_request_is_declined_with_a_note_and_served_by_the_device); under BCD_STRICT_CPU_REQUEST=1 it is refused -- `false` and a message on
+    cerr, on any host, with or without a GPU, before any device work"""
+    monkeypatch.setenv("BCD_STRICT_CPU_REQUEST", "1")
     col, ns, hist, cov = core.synthetic_scene(16, 12, 2)
     for nscales in (1, 2):
         ok, out, _ = core.denoise(col, ns, hist, cov, nscales, use_cuda=False)
