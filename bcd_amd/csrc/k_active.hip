@@ -119,12 +119,18 @@ __global__ __launch_bounds__(256) void k_mark_deps(const uint32_t *__restrict__ 
 {
     constexpr int side = 2 * B + 1, WORDS = (side * side + 31) / 32, tw = 16 + 2 * B;
     static_assert(tw <= 64 && side <= 32, "row bitmaps are 64-bit");
+    // (round 5) "visited earlier" is a comparison of order keys, one per similar neighbour -- ~100 of them per pixel in a flat region, and the
+    // wavefront walks the longest of its 64 lists: that loop was the kernel (0.13 ms at 1080p, vector pipe saturated).  The keys' top LV_BITS bits
+    // sort the cells of the tile into 32 levels; per level l two row bitmaps of the tile + halo -- cells of a level BELOW l (certainly earlier
+    // than a pixel of level l) and cells OF level l (to be compared key by key: 1 in 32) -- turn the test into the same word-parallel window
+    // extraction as the strong flags, plus a short loop over the few same-level neighbours.
+    constexpr int LV_BITS = 5, NLV = 1 << LV_BITS;
     __shared__ uint32_t s_hash[tw * tw];
-    __shared__ unsigned long long s_rowbits[tw];
+    __shared__ unsigned long long s_eq[NLV][tw], s_lt[NLV][tw];
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + lx, r = blockIdx.y * 16 + ly;
     const int r0 = blockIdx.y * 16 - B, c0 = blockIdx.x * 16 - B;
-    if (threadIdx.x < tw) s_rowbits[threadIdx.x] = 0ull;
+    for (int i = threadIdx.x; i < NLV * tw; i += 256) (&s_eq[0][0])[i] = 0ull;
     __syncthreads();
     for (int i = threadIdx.x; i < tw * tw; i += 256) {
         int lr = i / tw, lc = i - lr * tw, gr = r0 + lr, gc = c0 + lc;
@@ -132,33 +138,51 @@ __global__ __launch_bounds__(256) void k_mark_deps(const uint32_t *__restrict__ 
         if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
             size_t q = (size_t)gr * W + gc;
             h = (uint32_t)(bcd_order_key((uint32_t)(q + (size_t)row_offset * W), random_order, seed) >> 32);
-            if (nsim[q] >= min_strong) atomicOr(&s_rowbits[lr], 1ull << lc);
+            if (nsim[q] >= min_strong) {
+                atomicOr(&s_eq[h >> (32 - LV_BITS)][lr], 1ull << lc); // (only strong cells can be dependencies: the level bitmaps hold those)
+            }
         }
         s_hash[i] = h;
+    }
+    __syncthreads();
+    if (threadIdx.x < tw) { // strictly-lower-level bitmaps: a running OR over the levels, per tile row
+        unsigned long long run = 0ull;
+#pragma unroll 8
+        for (int l = 0; l < NLV; ++l) { s_lt[l][threadIdx.x] = run; run |= s_eq[l][threadIdx.x]; }
     }
     __syncthreads();
     const bool inside = c < W && r < H;
     const size_t p = inside ? (size_t)r * W + c : 0;
     bool pending = inside && r >= row_begin && r < row_end && state[p] == BCD_ST_UNDECIDED;
     if (pending) {
-        uint32_t sw[WORDS];
-        window_bits<B>(sw, s_rowbits, lx, ly);
         const int lp = (ly + B) * tw + lx + B;
         const uint32_t hp = s_hash[lp];
+        const int lv = (int)(hp >> (32 - LV_BITS));
+        uint32_t lower[WORDS], same[WORDS];
+        window_bits<B>(lower, s_lt[lv], lx, ly); // strong cells of a lower level: earlier whatever the rest of the key says
+        window_bits<B>(same, s_eq[lv], lx, ly);  // strong cells of the pixel's own level: compared key by key below
         uint32_t d[WORDS];
         bool none = true;
+        // window cell k = (dl + B) side + (dc + B) lies at lp0 + k + (tw - side) (k / side) of the hash tile; visited earlier: key = (hash, index),
+        // and the index order is the order of k (k < KC = the window's centre)
+        constexpr int KC = (side * side - 1) / 2;
+        const int lp0 = lp - B * tw - B;
+        auto earlier_bit = [&](int k, int bit) __attribute__((always_inline)) -> uint32_t {
+            const int rw = side == 13 ? (k * 79) >> 10 : k / side; // k / side
+            const uint32_t hq = s_hash[lp0 + k + (tw - side) * rw];
+            const uint32_t e = (uint32_t)(hq < hp) | ((uint32_t)(hq == hp) & (uint32_t)(k < KC));
+            return e << bit;
+        };
 #pragma unroll
         for (int j = 0; j < WORDS; ++j) {
-            uint32_t m = mask[p * WORDS + j] & sw[j], keep = 0;
+            const uint32_t sim = mask[p * WORDS + j];
+            uint32_t m = sim & same[j], keep = sim & lower[j];
             while (m) {
-                int bit = __ffs(m) - 1;
+                const int b0 = __ffs(m) - 1;
                 m &= m - 1;
-                int k = j * 32 + bit;
-                int dl = k / side - B, dc = k - (k / side) * side - B;
-                uint32_t hq = s_hash[lp + dl * tw + dc];
-                // visited earlier: key = (hash, index), index order == (dl, dc) lexicographic order
-                bool earlier = hq < hp || (hq == hp && (dl < 0 || (dl == 0 && dc < 0)));
-                if (earlier) keep |= 1u << bit;
+                const int b1 = m ? __ffs(m) - 1 : b0; // (a second bit, or the first one again: its result is OR-ed in twice)
+                m &= m - 1;                            // (0 & anything == 0)
+                keep |= earlier_bit(j * 32 + b0, b0) | earlier_bit(j * 32 + b1, b1);
             }
             d[j] = keep;
             none = none && keep == 0;
@@ -188,44 +212,74 @@ __global__ __launch_bounds__(256) void k_mark_round(const uint32_t *__restrict__
     const size_t p = inside ? (size_t)r * W + c : 0;
     bool pending = inside && r >= row_begin && r < row_end && state[p] == BCD_ST_UNDECIDED;
     if (!__syncthreads_or(pending)) return; // nothing left to decide in this tile
-    if (threadIdx.x < tw) { s_in_[threadIdx.x] = 0ull; s_und_[threadIdx.x] = 0ull; }
-    __syncthreads();
+    // (round 5) the two row bitmaps come from ballots, not from LDS atomics: a wavefront takes every fourth tile row, lane c loads the state of
+    // column c of that row, and the two ballots ARE the row's bitmaps (the 28 lanes of a row used to hit one 64-bit word with an atomic each)
     const int r0 = blockIdx.y * 16 - B, c0 = blockIdx.x * 16 - B;
-    for (int i = threadIdx.x; i < tw * tw; i += 256) {
-        int lr = i / tw, lc = i - lr * tw, gr = r0 + lr, gc = c0 + lc;
-        if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
-            uint8_t v = state[(size_t)gr * W + gc];
-            if (v == BCD_ST_IN) atomicOr(&s_in_[lr], 1ull << lc);
-            else if (v == BCD_ST_UNDECIDED) atomicOr(&s_und_[lr], 1ull << lc);
+    // every load of the tile is issued before the first one is used (the halo lines and the dependency words: one round trip to memory, not one per line)
+    uint32_t dword[WORDS];
+#pragma unroll
+    for (int j = 0; j < WORDS; ++j) dword[j] = pending ? dep[p * WORDS + j] : 0u;
+    {
+        constexpr int NL = (tw + 3) / 4;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        uint8_t hv[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int lr = wave + 4 * u, gr = r0 + lr, gc = c0 + lane;
+            hv[u] = BCD_ST_NONE;
+            if (lr < tw && lane < tw && gr >= 0 && gr < H && gc >= 0 && gc < W) hv[u] = state[(size_t)gr * W + gc];
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int lr = wave + 4 * u;
+            const unsigned long long bin = __ballot(hv[u] == BCD_ST_IN), bund = __ballot(hv[u] == BCD_ST_UNDECIDED);
+            if (lane == 0 && lr < tw) { s_in_[lr] = bin; s_und_[lr] = bund; }
         }
     }
-    uint32_t d[WORDS];
+    // the pixel's dependency bits, one window line per register (bit dc + B of drow[j] = window cell (j - B, dc)): a probe is then, per window line,
+    // one shifted row bitmap AND-ed with that register -- no 169-bit window is assembled per iteration any more (round 5: half the instructions)
+    uint32_t drow[side];
+    {
+        uint32_t d[WORDS + 1];
 #pragma unroll
-    for (int j = 0; j < WORDS; ++j) d[j] = pending ? dep[p * WORDS + j] : 0u;
+        for (int j = 0; j < WORDS; ++j) d[j] = dword[j];
+        d[WORDS] = 0u;
+#pragma unroll
+        for (int j = 0; j < side; ++j) {
+            const int pos = j * side, word = pos >> 5, sh = pos & 31;
+            const unsigned long long two = ((unsigned long long)d[word + 1] << 32) | d[word];
+            drow[j] = (uint32_t)(two >> sh) & ((1u << side) - 1u);
+        }
+    }
     __syncthreads();
     // decisions made inside the tile are visible to the tile at once (LDS), the halo is as of the launch: one launch resolves
-    // the chains that stay inside a tile, the next one sees the neighbours' results.  Word-parallel probe: p is marked iff
-    // dep & IN-window != 0, and waits iff dep & undecided-window != 0.
+    // the chains that stay inside a tile, the next one sees the neighbours' results.  p is marked iff a dependency is IN, and waits iff one
+    // is still undecided.
     for (int it = 0; it < iters; ++it) {
         uint8_t v = BCD_ST_UNDECIDED;
         if (pending) {
-            uint32_t win[WORDS];
-            bool any_in = false, wait = false;
-            window_bits<B>(win, s_in, lx, ly);
+            uint32_t hit_in = 0u, hit_und = 0u;
 #pragma unroll
-            for (int j = 0; j < WORDS; ++j) any_in = any_in || (d[j] & win[j]) != 0;
-            window_bits<B>(win, s_und, lx, ly);
-#pragma unroll
-            for (int j = 0; j < WORDS; ++j) wait = wait || (d[j] & win[j]) != 0;
-            v = any_in ? BCD_ST_OUT : (wait ? BCD_ST_UNDECIDED : BCD_ST_IN);
+            for (int j = 0; j < side; ++j) {
+                hit_in |= (uint32_t)(s_in[ly + j] >> lx) & drow[j];
+                hit_und |= (uint32_t)(s_und[ly + j] >> lx) & drow[j];
+            }
+            v = hit_in != 0u ? BCD_ST_OUT : (hit_und != 0u ? BCD_ST_UNDECIDED : BCD_ST_IN);
         }
         __syncthreads(); // every probe of this iteration has read the bitmaps
         const bool changed = pending && v != BCD_ST_UNDECIDED;
-        if (changed) {
-            state[p] = v;
-            atomicAnd(&s_und_[ly + B], ~(1ull << (lx + B)));
-            if (v == BCD_ST_IN) atomicOr(&s_in_[ly + B], 1ull << (lx + B));
-            pending = false;
+        if (changed) { state[p] = v; pending = false; }
+        {
+            // a wavefront owns four tile rows (16 lanes each): the decisions of a row go into its two bitmap words with one plain update by one lane
+            // (nobody else writes these words; the halo bits of a row stay as loaded)
+            const unsigned long long bch = __ballot(changed), bin = __ballot(changed && v == BCD_ST_IN);
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            if (lane < 4 && ((bch >> (16 * lane)) & 0xffffull) != 0ull) {
+                const int row = 4 * wave + lane + B;
+                const unsigned long long ch = ((bch >> (16 * lane)) & 0xffffull) << B, in = ((bin >> (16 * lane)) & 0xffffull) << B;
+                s_und_[row] &= ~ch;
+                s_in_[row] |= in;
+            }
         }
         if (!__syncthreads_or(changed)) break;
     }

@@ -869,6 +869,7 @@ __device__ __attribute__((noinline)) void mfma27(float *out, int ldo, const floa
 // A per-pair stopping rule (every opposite-sign pair decoupled, loose bound on the rest) was built and measured out: in fp32 it needs the
 // sixth sweep as often as the plain rule does, and its test costs 5 % of a sweep.
 constexpr float JACOBI_CONV2_CORRECTED = 2e-9f; // off / diag <= 4.5e-5
+constexpr bool FOLD_MAIN_TERM = true;             // k_finish27w: V (diag f + E o Phi) V^T as two products instead of three (round 5)
 constexpr float JACOBI_CONV2_STRICT = 1e-12f;   // the round-3 rule: one sweep more, the correction then has nothing left to do
 
 
@@ -1682,12 +1683,23 @@ __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ c
             v16f U;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[e] = Nop[e]; U[e] = 0.f; }
-            // the main term as ever (positive multiples of v v^T on top of N, bitwise symmetric) and U = (E o Phi) V^T: two independent chains,
-            // interleaved so that each covers the other's latency
+            if (FOLD_MAIN_TERM) {
+                // (round 5) main term and correction in ONE pair of products: M = diag(f(D)) + E o Phi (the correction matrix has a zero diagonal, so f(d_idx)
+                // simply takes the diagonal place of row idx), U = M V^T, P = N + V U -- 30 matrix-core steps instead of 45.  P is then symmetric up to
+                // round-off only (the separate main term was bitwise symmetric); the sweep inverse and the acceptance test below do not rely on it
+                // (measured: the same deviation from the oracle as the three-product form, .notes of round 4)
 #pragma unroll
-            for (int s_ = 0; s_ < 15; ++s_) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vB[s_] * fmaxf(0.f, dK[s_]), vB[s_], acc, 0, 0, 0);
-                U = __builtin_amdgcn_mfma_f32_32x32x2f32(aK[s_], vB[s_], U, 0, 0, 0);
+                for (int e = 0; e < 16; ++e) aK[e] += ((e & 3) + 8 * (e >> 2) + 4 * h == idx) ? fmaxf(0.f, dK[e]) : 0.f;
+#pragma unroll
+                for (int s_ = 0; s_ < 15; ++s_) U = __builtin_amdgcn_mfma_f32_32x32x2f32(aK[s_], vB[s_], U, 0, 0, 0);
+            } else {
+                // the main term (positive multiples of v v^T on top of N, bitwise symmetric) and U = (E o Phi) V^T: two independent chains,
+                // interleaved so that each covers the other's latency
+#pragma unroll
+                for (int s_ = 0; s_ < 15; ++s_) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vB[s_] * fmaxf(0.f, dK[s_]), vB[s_], acc, 0, 0, 0);
+                    U = __builtin_amdgcn_mfma_f32_32x32x2f32(aK[s_], vB[s_], U, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int s_ = 0; s_ < 15; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vB[s_], U[s_], acc, 0, 0, 0);   // + V U
