@@ -115,6 +115,7 @@ struct Work {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_pixcov = nullptr; // the per-pixel covariances (side stream, beside the distance kernel) are complete
     std::vector<hipEvent_t> ev_chunk;  // head pipeline (round 5): the distance planes of a chunk of tile rows are complete
+    hipStream_t prio = nullptr;        // ... and the high-priority stream of its experiment variant
     // approximate distance planes computed ahead of similarity() by a caller that streams the frame in (bcd_hip_denoise_host_ex): valid for
     // exactly this problem; similarity() consumes the note
     struct { bool ready = false; const float *hist = nullptr, *ns = nullptr; int W = 0, H = 0, D = 0, b = 0; float tau = 0.f, uni_n = 0.f; } planes;
@@ -411,11 +412,25 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
                 wk.ev_chunk.push_back(ev);
             }
             if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
+            // (experiment, BCD_HIP_HEAD_PRIO=1) the chunks have no order among themselves: every chunk but the last goes to a stream of higher priority
+            // forked off here, so that the dispatcher hands out the earlier chunk's workgroups first and fills the chip with the next chunk's as they
+            // retire -- no drained chip at the chunk boundary
+            static const bool head_prio = [] { const char *e = getenv("BCD_HIP_HEAD_PRIO"); return e && e[0] == '1'; }();
+            if (head_prio && !wk.prio) {
+                int lo = 0, hi = 0;
+                HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(ctx, hipStreamCreateWithPriority(&wk.prio, hipStreamNonBlocking, hi));
+            }
+            if (head_prio) {
+                HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
+                HIPCHK(ctx, hipStreamWaitEvent(wk.prio, wk.ev_fork, 0));
+            }
             int line0 = 0;
             for (int i = 0; i < chunks; ++i) {
                 const int t0 = (int)((int64_t)tile_rows * i / chunks), t1 = (int)((int64_t)tile_rows * (i + 1) / chunks);
-                HIPCHK(ctx, bcd_launch_pairdist_rw_rows(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, t0, t1, wk.stream));
-                HIPCHK(ctx, hipEventRecord(wk.ev_chunk[i], wk.stream));
+                hipStream_t cs = (head_prio && i + 1 < chunks) ? wk.prio : wk.stream;
+                HIPCHK(ctx, bcd_launch_pairdist_rw_rows(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, t0, t1, cs));
+                HIPCHK(ctx, hipEventRecord(wk.ev_chunk[i], cs));
                 // forward bits of the lines whose three plane lines are complete: up to the chunk's last line but three (the last chunk: to the end)
                 const int line1 = i + 1 == chunks ? H : t1 * tile_lines - 4;
                 HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_chunk[i], 0));
@@ -797,6 +812,7 @@ void work_destroy(Work &w)
     if (w.ev_done) (void)hipEventDestroy(w.ev_done);
     if (w.ev_built) (void)hipEventDestroy(w.ev_built);
     for (hipEvent_t ev : w.ev_chunk) (void)hipEventDestroy(ev);
+    if (w.prio) { (void)hipStreamDestroy(w.prio); w.prio = nullptr; }
     w.ev_chunk.clear();
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
     if (w.ev_join) (void)hipEventDestroy(w.ev_join);

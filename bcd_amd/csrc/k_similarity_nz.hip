@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) void k_fwd_masks_pm(const __half *__restrict__ 
 #pragma unroll
     for (int i = 0; i < FWD_PM_RB + 2; ++i) line_off[i] = (unsigned int)(min(max(rb - 1 + i, 0), H - 1) * W) * FWD_PM_ND + idx;
     // the plane values of three consecutive columns live in registers (t0 | t1 | t2 = columns c - 1 | c | c + 1 of the step that decides column c);
-    // the loads of column c + 2 are issued before column c is evaluated, so a step never waits for the loads it has just issued
+    // the loads of columns c + 2 and c + 3 are in flight meanwhile, so a step never waits for loads it has just issued
     float t0[FWD_PM_RB + 2], t1[FWD_PM_RB + 2], t2[FWD_PM_RB + 2];
     int n0[FWD_PM_RB + 2], n1[FWD_PM_RB + 2], n2[FWD_PM_RB + 2];
     auto load = [&](int c, float (&t)[FWD_PM_RB + 2], int (&n)[FWD_PM_RB + 2]) __attribute__((always_inline)) {
@@ -352,14 +352,17 @@ __global__ __launch_bounds__(64) void k_fwd_masks_pm(const __half *__restrict__ 
 #pragma unroll
         for (int i = 0; i < FWD_PM_RB + 2; ++i) { t[i] = __half2float(T[line_off[i] + co]); n[i] = Cn[line_off[i] + co]; }
     };
+    float t3[FWD_PM_RB + 2];
+    int n3[FWD_PM_RB + 2];
     load(cs - 1, t0, n0);
     load(cs, t1, n1);
     load(cs + 1, t2, n2);
+    load(cs + 2, t3, n3);
     for (int step = 0; step < ncols; ++step) {
         const int c = cs + step; // the column decided in this step
-        float t3[FWD_PM_RB + 2], h[FWD_PM_RB + 2];
-        int n3[FWD_PM_RB + 2], hn[FWD_PM_RB + 2];
-        load(c + 2, t3, n3);
+        float t4[FWD_PM_RB + 2], h[FWD_PM_RB + 2];
+        int n4[FWD_PM_RB + 2], hn[FWD_PM_RB + 2];
+        load(c + 3, t4, n4); // (two columns ahead of the last one this step reads: 24 loads in flight per lane)
 #pragma unroll
         for (int i = 0; i < FWD_PM_RB + 2; ++i) { h[i] = (t0[i] + t1[i]) + t2[i]; hn[i] = n0[i] + n1[i] + n2[i]; }
         const int qc = c + dc;
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(64) void k_fwd_masks_pm(const __half *__restrict__ 
             }
         }
 #pragma unroll
-        for (int i = 0; i < FWD_PM_RB + 2; ++i) { t0[i] = t1[i]; t1[i] = t2[i]; t2[i] = t3[i]; n0[i] = n1[i]; n1[i] = n2[i]; n2[i] = n3[i]; }
+        for (int i = 0; i < FWD_PM_RB + 2; ++i) { t0[i] = t1[i]; t1[i] = t2[i]; t2[i] = t3[i]; t3[i] = t4[i]; n0[i] = n1[i]; n1[i] = n2[i]; n2[i] = n3[i]; n3[i] = n4[i]; }
     }
 }
 
