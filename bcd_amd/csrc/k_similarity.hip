@@ -478,16 +478,28 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APP
             const int nl = lane_up(n3), nr = lane_down(n0);
             nh[i][0] = nl + n0 + n1; nh[i][1] = n0 + n1 + n2; nh[i][2] = n1 + n2 + n3; nh[i][3] = n2 + n3 + nr;
         }
+        // (round 5) the approximate planes may be added in any order (k_similarity_fast.hip): line sums first, 80 additions per 16 outputs instead of 128
+        float hs[FWD_RB + 2][4];
+        if (APPROX) {
+#pragma unroll
+            for (int i = 0; i < FWD_RB + 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hs[i][j] = (t[i][j] + t[i][j + 1]) + t[i][j + 2];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cj = c + j, qc = cj + dc;
             const bool cols_ok = cj >= 1 && cj <= W - 2 && qc >= 1 && qc <= W - 2;
 #pragma unroll
             for (int i = 0; i < FWD_RB; ++i) {
-                float s = t[i][j];
-                s += t[i][j + 1]; s += t[i][j + 2];
-                s += t[i + 1][j]; s += t[i + 1][j + 1]; s += t[i + 1][j + 2];
-                s += t[i + 2][j]; s += t[i + 2][j + 1]; s += t[i + 2][j + 2];
+                float s;
+                if (APPROX) s = (hs[i][j] + hs[i + 1][j]) + hs[i + 2][j];
+                else {
+                    s = t[i][j];
+                    s += t[i][j + 1]; s += t[i][j + 2];
+                    s += t[i + 1][j]; s += t[i + 1][j + 1]; s += t[i + 1][j + 2];
+                    s += t[i + 2][j]; s += t[i + 2][j + 1]; s += t[i + 2][j + 2];
+                }
                 const int n = nh[i][j] + nh[i + 1][j] + nh[i + 2][j];
                 const int r = rb + i;
                 if (cols_ok && r >= 1 && r <= H - 2 && r + dl <= H - 2) {
