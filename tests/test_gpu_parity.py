@@ -566,6 +566,25 @@ def test_other_histogram_depths(hipctx, nbins):
     assert rel_linf(got, ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0))) < TOL
 
 
+@pytest.mark.parametrize("nbins", [12, 8])
+def test_own_list_kernel_other_histogram_depths_and_mixed_counts(hipctx, nbins):
+    """the own-list distance kernel has instantiations for D = 36 and 24 too (pixel stride D + 1 dwords: odd, conflict-free): mixed sample counts
+    at those depths go through it (masks and counts against the oracle), and its planes agree with the exact ones"""
+    W, H = 90, 50
+    rng = np.random.default_rng(nbins)
+    samples, _ = ol.synth_samples(W, H, 16, seed=7, sigma=0.3, spike_prob=0.01)
+    keep = rng.random(samples.shape[0]) < 0.7
+    keep[::16] = True
+    ns, mean, cov, hist = ol.oracle_ops()["accumulate"](np.ascontiguousarray(samples[keep]), W, H, nbins)
+    assert hist.shape[-1] == 3 * nbins and len(np.unique(ns)) > 3
+    d_hist, d_ns = dev(hist, ns)
+    rel, count_mismatches, flags, *_ = hipctx.selftest_nz_distance(d_hist, d_ns, 6, 1.0, 3, 1)
+    assert count_mismatches == 0 and flags == 0 and rel < 2.0 ** -10 / 1.9
+    mask, cnt = hipctx.similarity_masks(d_hist, d_ns, 1, 6, 1.0)
+    wmask, wcnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask) and np.array_equal(cnt.cpu().numpy(), wcnt)
+
+
 @pytest.mark.parametrize("w,b,m", [(2, 3, 0.0), (2, 3, 1.0), (0, 4, 1.0), (2, 6, 1.0)])
 def test_other_patch_radii(hipctx, w, b, m):
     """-w != 1 runs the generic mask / marking / Bayes kernels (K = 3(2w+1)^2 = 75 or 3)"""
