@@ -15,7 +15,8 @@
 //           the loop runs over the union of the three lists (24.8 bins), b1 is a second ds_read_b32.
 // A workgroup (16 wavefronts, one per CU: 157 KB of LDS) stages the histograms of a 24 x 11 tile of own pixels and of the 6 lines
 // below / 6 columns either side once, derives S and C1 of every staged pixel, and its wavefronts then draw items from an LDS counter
-// (B items first: they are the longer ones).  No rolling window and no barrier between items.
+// (B items first: they are the longer ones).  No rolling window and no barrier between items.  One workgroup per tile (a persistent form
+// with the next tile prefetched into registers exists behind BCD_HIP_NZ_PERSIST=1: no faster alone, and it shuts every other kernel out).
 //
 // T is still the approximate plane of k_similarity_fast.hip (rcp + fma, any summation order, binary16 store), consumed by the same
 // mask / verify kernels; C is exact.  The subtraction S - A2 adds an ABSOLUTE error to that file's relative bound.  With u = 2^-24,
@@ -33,6 +34,7 @@
 #include <hip/hip_fp16.h>
 #include <atomic>
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -115,7 +117,7 @@ __device__ inline void nz_pair_loop(unsigned long long m, const float *__restric
     A1_ = A1; A2_ = A2; Cm_ = Cm;
 }
 
-template <int D, bool READLANE, int BODY, bool PROF>
+template <int D, bool READLANE, int BODY, bool PROF, bool PERSIST>
 __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H,
                                                                __half *__restrict__ T, uint8_t *__restrict__ Cn, long long t_ps, long long t_ds,
                                                                int *range_flag, float tau, int tiles_x, int ntiles, unsigned long long *prof)
@@ -131,9 +133,8 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
     int *s_counter = s_C1 + NPIX;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    // Persistent workgroup (one per CU).  The tiles are dealt in row-major order, a contiguous share per XCD (workgroup w runs on XCD w & 7), and
-    // the workgroups of an XCD take consecutive tiles of that share: the ~32 tiles in flight on an XCD are neighbours in a tile row and find the
-    // columns they share in that XCD's L2.
+    // (PERSIST only) the tiles are dealt in row-major order, a contiguous share per XCD (workgroup w runs on XCD w & 7), and the workgroups of
+    // an XCD take consecutive tiles of that share
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3; // (gridDim.x is a multiple of 8)
     const int tq = ntiles / 8, trem = ntiles - 8 * tq;
     const int share_begin = xcd * tq + min(xcd, trem), share_end = share_begin + tq + (xcd < trem ? 1 : 0);
@@ -160,9 +161,15 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
     };
     long long pc[5] = { 0, 0, 0, 0, 0 }, slots = 0;
     bool imprecise = false, tile_uni = false;
-    int tile = share_begin + slot;
-    if (tile < share_end) prefetch(tile);
-    for (; tile < share_end; tile += per_xcd) {
+    // PERSIST: one workgroup per CU walks its share of the tiles, the next tile's histograms in flight during the current one (127 registers, every
+    // wavefront slot of the chip taken for the whole launch: nothing else runs beside it).  !PERSIST (the production form, round 5): one workgroup per
+    // tile, no prefetch (68 registers) -- the same speed alone (staging is 4 % either way once several workgroups queue per CU), and the kernels of the
+    // other scales get CUs as tiles retire: measured at 24 spp, the step went from 5.6 to the figure in DESIGN 3.
+    // (!PERSIST: tiles in launch order -- a contiguous share per XCD, tried, was 5 % slower: 2.03 against 1.93 ms at 1080p)
+    int tile = PERSIST ? share_begin + slot : (int)blockIdx.x;
+    const int tile_end = PERSIST ? share_end : (tile < ntiles ? tile + 1 : tile), tile_step = PERSIST ? per_xcd : 1;
+    if (tile < tile_end) prefetch(tile);
+    for (; tile < tile_end; tile += tile_step) {
     const int c0 = (tile % tiles_x) * NZ_TC, r0 = (tile / tiles_x) * NZ_TR;
     const long long t0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
     // ---- the prefetched tile -> LDS: lines r0 .. r0 + TR + 5, columns c0 - 6 .. c0 + TC + 5 (zeros outside the image) ----
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
     }
     __syncthreads();
     // the next tile's histograms travel while this one is evaluated
-    if (tile + per_xcd < share_end) prefetch(tile + per_xcd);
+    if (PERSIST && tile + per_xcd < share_end) prefetch(tile + per_xcd);
     const long long t2 = PROF ? (long long)__builtin_readcyclecounter() : 0;
     // ---- per-lane displacement tables ----
     // A: lane l <-> 13 dl + dc = l + 1
@@ -421,18 +428,22 @@ hipError_t bcd_launch_pairdist_nz(const float *hist, const float *ns, int W, int
         if (dev >= 0 && dev < 64) cus_of[dev].store(cus);
     }
     const int nwg = std::max(8, std::min((cus / 8) * 8, ((tx * ty + 7) / 8) * 8));
-#define BCD_NZ_LAUNCH2(DD, RL, BD, PF)                                                                                             \
+    static const bool persist_env = [] { const char *e = getenv("BCD_HIP_NZ_PERSIST"); return e && e[0] == '1'; }();
+    const bool persist = persist_env || (variant & 4) != 0; // (variant bit 2: the persistent form, for A/B measurements)
+    variant &= 3;
+#define BCD_NZ_LAUNCH3(DD, RL, BD, PF, PS)                                                                                             \
     {                                                                                                                      \
         const size_t lds = (size_t)NzLayout<DD>::LDS_DWORDS * 4;                                                           \
         static std::atomic<int> granted[64];                                                                               \
         if (dev < 0 || dev >= 64 || granted[dev].load() == 0) {                                                            \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist_nz<DD, RL, BD, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist_nz<DD, RL, BD, PF, PS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                                 \
             if (dev >= 0 && dev < 64) granted[dev].store(1);                                                               \
         }                                                                                                                  \
-        hipLaunchKernelGGL((k_pairdist_nz<DD, RL, BD, PF>), dim3(nwg), dim3(NZ_THREADS), lds, st, hist, ns, W, H, static_cast<__half *>(T), Cn, t_ps, t_ds, d_range_flag, tau, tx, tx * ty, prof); \
+        hipLaunchKernelGGL((k_pairdist_nz<DD, RL, BD, PF, PS>), dim3(PS ? nwg : tx * ty), dim3(NZ_THREADS), lds, st, hist, ns, W, H, static_cast<__half *>(T), Cn, t_ps, t_ds, d_range_flag, tau, tx, tx * ty, prof); \
         return hipGetLastError();                                                                                          \
     }
+#define BCD_NZ_LAUNCH2(DD, RL, BD, PF) { if (persist) BCD_NZ_LAUNCH3(DD, RL, BD, PF, true) else BCD_NZ_LAUNCH3(DD, RL, BD, PF, false) }
 #define BCD_NZ_LAUNCH1(DD, RL, BD) { if (prof) BCD_NZ_LAUNCH2(DD, RL, BD, true) else BCD_NZ_LAUNCH2(DD, RL, BD, false) }
 #define BCD_NZ_LAUNCH(DD) case DD: if (variant == 1) BCD_NZ_LAUNCH1(DD, true, 0) else if (variant == 2) BCD_NZ_LAUNCH1(DD, false, 1) else if (variant == 3) BCD_NZ_LAUNCH1(DD, true, 1) else BCD_NZ_LAUNCH1(DD, false, 0)
     switch (D) {
@@ -444,6 +455,7 @@ hipError_t bcd_launch_pairdist_nz(const float *hist, const float *ns, int W, int
 #undef BCD_NZ_LAUNCH
 #undef BCD_NZ_LAUNCH1
 #undef BCD_NZ_LAUNCH2
+#undef BCD_NZ_LAUNCH3
     return hipErrorInvalidValue;
 }
 
