@@ -381,9 +381,10 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1(const typename PlaneT<APPRO
 #pragma unroll
     for (int i = 0; i < FWD_RB; ++i) { word[i] = 0; bword[i] = 0; }
     const int d_end = min(nd, 32 * wi + 32);
-    for (int didx = 32 * wi; didx < d_end; ++didx) {
-        int dl = 0, dc = didx;
-        if (didx > b) { int e = didx - (b + 1); dl = 1 + e / side; dc = e - (dl - 1) * side - b; }
+    // (the displacement of the first plane by one division, the following ones by stepping: dc + 1, wrapping into the next displacement line)
+    int dl = 0, dc = 32 * wi;
+    if (dc > b) { int e = dc - (b + 1); dl = 1 + e / side; dc = e - (dl - 1) * side - b; }
+    for (int didx = 32 * wi; didx < d_end; ++didx, dc = (dc == b ? -b : dc + 1), dl += (dc == -b ? 1 : 0)) {
         const typename PlaneT<APPROX>::type *Tp = T + (size_t)didx * plane;
         const uint8_t *Cp = Cn + (size_t)didx * plane;
         float tc[FWD_RB + 2], tl[FWD_RB + 2], tr[FWD_RB + 2];
@@ -454,9 +455,10 @@ __global__ __launch_bounds__(64) void k_fwd_masks_w1v4(const typename PlaneT<APP
 #pragma unroll
         for (int j = 0; j < 4; ++j) { word[i][j] = 0; bword[i * 4 + j] = 0; }
     const int d_end = min(nd, 32 * wi + 32);
-    for (int didx = 32 * wi; didx < d_end; ++didx) {
-        int dl = 0, dc = didx;
-        if (didx > b) { int e = didx - (b + 1); dl = 1 + e / side; dc = e - (dl - 1) * side - b; }
+    // (the displacement of the first plane by one division, the following ones by stepping: dc + 1, wrapping into the next displacement line)
+    int dl = 0, dc = 32 * wi;
+    if (dc > b) { int e = dc - (b + 1); dl = 1 + e / side; dc = e - (dl - 1) * side - b; }
+    for (int didx = 32 * wi; didx < d_end; ++didx, dc = (dc == b ? -b : dc + 1), dl += (dc == -b ? 1 : 0)) {
         const typename PlaneT<APPROX>::type *Tp = T + (size_t)didx * plane;
         const uint8_t *Cp = Cn + (size_t)didx * plane;
         float t[FWD_RB + 2][6]; // left neighbour, the lane's four columns, right neighbour

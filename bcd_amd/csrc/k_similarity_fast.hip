@@ -367,6 +367,91 @@ __global__ __launch_bounds__(64) void k_verify_pairs(const float *__restrict__ h
     }
 }
 
+// The same through LDS (round 5).  k_verify_pairs reads a pixel's 240-byte histogram row as fifteen separate 16-byte loads of ONE lane, spread over time:
+// with 63 rows per instruction the L1 keeps nothing, every 64-byte line is fetched up to four times, and at 2e5 .. 1e6 borderline pairs (textured frames,
+// b = 12) the kernel was bound by that traffic (0.5 .. 1.9 ms).  Here the 126 rows of a wavefront's 63 pixel pairs are loaded in pieces of five 16-byte
+// groups by FIVE CONSECUTIVE lanes each (80 contiguous bytes), parked in LDS, and every pair lane then reads its own two rows back -- the arithmetic and
+// its order are exactly those of k_verify_pairs.
+constexpr int VP_PIECE = 5;                       // 16-byte groups per piece (20 bins)
+constexpr int VP_ROWS = 126;                      // rows per wavefront: 63 pixel pairs x 2
+constexpr int VP_STRIDE = VP_PIECE * 4 + 1;       // floats per parked row piece (odd: conflict-free column reads)
+__global__ __launch_bounds__(64) void k_verify_pairs_lds(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H, int Q /* D / 4 */, int b,
+                                                         float tau, const uint2 *__restrict__ list, const int *__restrict__ d_count, int capacity,
+                                                         int fwords, uint32_t *__restrict__ fwd)
+{
+    __shared__ float s_piece[VP_ROWS * VP_STRIDE];
+    __shared__ unsigned int s_row[VP_ROWS + 2];   // pixel index of every row (x of pair 0, y of pair 0, x of pair 1, ...)
+    const int lane = threadIdx.x, slot = lane / 9, o = lane - slot * 9; // 7 entries per wavefront, lane 63 idle
+    const int n = min(*d_count, capacity);
+    const int side = 2 * b + 1;
+    for (int base = blockIdx.x * 7; base < n; base += gridDim.x * 7) {
+        const int e = base + slot;
+        const bool live = slot < 7 && e < n;
+        uint2 ent = make_uint2(0u, 0u);
+        unsigned int x = 0u, y = 0u;
+        if (live) {
+            ent = list[e];
+            const int p = (int)ent.x, didx = (int)ent.y;
+            int dl = 0, dc = didx;
+            if (didx > b) { const int t = didx - (b + 1); dl = 1 + t / side; dc = t - (dl - 1) * side - b; }
+            const int pr = p / W, pc = p - pr * W;
+            const int xr = pr + o / 3 - 1, xc = pc + o % 3 - 1; // patch pixel o (row-major), and its partner
+            x = (unsigned int)(xr * W + xc); y = (unsigned int)((xr + dl) * W + (xc + dc));
+        }
+        __syncthreads(); // (the previous trip's readers are done with the tables)
+        if (lane < 63) { s_row[2 * lane] = x; s_row[2 * lane + 1] = y; } // (dead pairs: pixel 0 -- loaded, never used)
+        __syncthreads();
+        const float n1 = live ? ns[x] : 1.f, n2 = live ? ns[y] : 1.f, n12 = n1 * n2;
+        float sum = 0.f;
+        int cnt = 0;
+        // one bin of DenoisingUnit.cpp:379-383, in the reference's order
+        auto bin = [&](float b1, float b2) __attribute__((always_inline)) {
+            const float s = b1 + b2;
+            if (s <= 1.f) return;
+            ++cnt;
+            const float diff = n2 * b1 - n1 * b2;
+            sum += diff * diff / (n12 * s);
+        };
+        for (int q0 = 0; q0 < Q; q0 += VP_PIECE) {
+            const int np = min(VP_PIECE, Q - q0); // groups of this piece
+            // VP_ROWS rows x VP_PIECE groups, a run of consecutive lanes per row
+            float4 v[(VP_ROWS * VP_PIECE + 63) / 64];
+#pragma unroll
+            for (int u = 0; u < (VP_ROWS * VP_PIECE + 63) / 64; ++u) {
+                const int i = lane + 64 * u, row = i / VP_PIECE, g = i - row * VP_PIECE; // (a short last piece leaves the lanes g >= np idle)
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < VP_ROWS && g < np) v[u] = reinterpret_cast<const float4 *>(hist)[(size_t)s_row[row] * Q + q0 + g];
+            }
+            __syncthreads(); // (the previous piece has been consumed)
+#pragma unroll
+            for (int u = 0; u < (VP_ROWS * VP_PIECE + 63) / 64; ++u) {
+                const int i = lane + 64 * u, row = i / VP_PIECE, g = i - row * VP_PIECE;
+                if (row < VP_ROWS) { float *d = s_piece + row * VP_STRIDE + 4 * g; d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w; }
+            }
+            __syncthreads();
+            if (live) {
+                const float *r1 = s_piece + (2 * lane) * VP_STRIDE, *r2 = r1 + VP_STRIDE;
+                for (int k = 0; k < 4 * np; ++k) bin(r1[k], r2[k]);
+            }
+        }
+        // patch order: ((((t0 + t1) + t2) + ...) + t8), counts as integers
+        float tot = 0.f;
+        int ctot = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int srcl = min(slot * 9 + i, 63);
+            const float ti = __shfl(sum, srcl);
+            const int ci = __shfl(cnt, srcl);
+            tot = (i == 0) ? ti : tot + ti; // the reference starts from 0.f: 0 + t0 == t0 bit for bit (t0 >= +0)
+            ctot += ci;
+        }
+        if (live && o == 0) {
+            const float d = tot / (float)ctot; // 0/0 = NaN -> not similar
+            if (d <= tau) atomicOr(fwd + (size_t)ent.x * fwords + (ent.y >> 5), 1u << (ent.y & 31));
+        }
+    }
+}
+
 // self-test: largest relative deviation between the patch distances from two sets of planes (approximate vs exact), over all
 // pairs of main pixels; bits of (max rel, as uint) via atomicMax -- valid because the values are non-negative floats
 __global__ __launch_bounds__(256) void k_max_rel_dev(const __half *__restrict__ Ta, const float *__restrict__ Tb, const uint8_t *__restrict__ Ca,
@@ -468,7 +553,11 @@ hipError_t bcd_launch_verify_pairs(const float *hist, const float *ns, int W, in
 {
     const int fwords = (bcd_delta_count(b) + 31) / 32;
     // (the number of pairs is on the device: a fixed grid of 16 wavefronts per CU; with nothing listed every wavefront leaves at once)
-    hipLaunchKernelGGL(k_verify_pairs, dim3(4096), dim3(64), 0, st, hist, ns, W, H, D, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
+    static const bool plain = [] { const char *e = getenv("BCD_HIP_VERIFY_PLAIN"); return e && e[0] == '1'; }(); // (A/B: the per-lane loads of rounds 2-4)
+    if ((D & 3) == 0 && !plain)
+        hipLaunchKernelGGL(k_verify_pairs_lds, dim3(4096), dim3(64), 0, st, hist, ns, W, H, D >> 2, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
+    else
+        hipLaunchKernelGGL(k_verify_pairs, dim3(4096), dim3(64), 0, st, hist, ns, W, H, D, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
     return hipGetLastError();
 }
 
