@@ -3,7 +3,7 @@
 // Real defaults are -r 1 and -p 1 (main.cpp:52-53) although the reference's README says 0.  Missing -h / -c are
 // inferred as <input>_hist.exr / <input>_cov.exr (:344-370).  Extra flags of this build: --seed <n> (visiting
 // order), --device <n>.  --ncores only selects the visiting order (n > 1 with -r 0: the reference's strip list; the loop runs on the HIP device); --use-cuda 0 (a request for the CPU path this
-// build does not have) is refused with an error, never answered by silently running something else.
+// build does not have) is declined with a note and served by the device; under BCD_STRICT_CPU_REQUEST=1 it is refused with an error before any file is read.
 // -a <file.bcd.json> (advertised but never parsed by the reference, main.cpp:107) loads a preset; later flags override it.
 #include "Chronometer.h"
 #include "DeepImage.h"
