@@ -1221,13 +1221,24 @@ template <int B> struct WinT {
 };
 static_assert(WinT<WB>::AW == WAW && WinT<WB>::PIX == WPIX && WinT<WB>::MEM == WMEM && WinT<WB>::G == 36 && WinT<WB>::CSLICES == 1, "b = 6 is the geometry the r3 kernels were written for");
 // LDS layout of PHASE 1 (floats): colour window | covariance window | noise | mean | members (16-byte aligned)
-constexpr int W1_NWIN = (WPIX * 3 + 3) / 4 * 4, W1_NOISE = W1_NWIN + (WPIX * 6 + 3) / 4 * 4, W1_MEM = W1_NOISE + 56 + 28;
+// (b = 12: no covariance window -- 17.5 KB more per wavefront left 5 wavefronts per CU and a kernel slower than the gather form, measured; the
+// per-pixel covariances of the members are gathered from memory there and the area only holds the 28 x 29 result tile)
+template <int B> struct W1L {
+    static constexpr bool COV_WINDOW = B == WB;
+    static constexpr int NWIN = (WinT<B>::PIX * 3 + 3) / 4 * 4, NOISE = NWIN + ((COV_WINDOW ? WinT<B>::PIX * 6 : 28 * 29) + 3) / 4 * 4, MEM = NOISE + 56 + 28;
+    static constexpr int NSLICES = (WinT<B>::PIX * 6 + 64 * WIN_SLICE - 1) / (64 * WIN_SLICE);   // slices of the covariance window
+    static constexpr int MEM_SLOTS = WinT<B>::MEM + 16;  // (the covariance loop reads two groups of 8 ahead)
+    static constexpr size_t BYTES = (size_t)MEM * sizeof(float) + MEM_SLOTS * sizeof(uint16_t);
+};
+constexpr int W1_NWIN = W1L<WB>::NWIN, W1_NOISE = W1L<WB>::NOISE, W1_MEM = W1L<WB>::MEM;
 constexpr int W2_MEM = 4 * 784 + 56 + 56 + 28 + 28;                              // PHASE 2: four matrix buffers | cs | noise | mean | fl | members
 static_assert(W1_MEM % 4 == 0 && W2_MEM % 4 == 0 && 28 * 29 <= WPIX * 6, "aligned member lists; the covariance tile fits the covariance window");
+static_assert(W1L<12>::MEM % 4 == 0 && W1L<12>::BYTES <= 14 * 1024, "b = 12: a 27 x 27 pixel colour window, eleven wavefronts per CU");
 
 // similar set of p in window order -> mem[i] = window pixel index of member i; returns |S|.  The mask words of p are wave-uniform
 // (scalar loads); lane l looks at the bits l, l + 64, l + 128 and places its members by prefix population counts.
-template <int B = WB>
+// (SCALE: the codes are stored multiplied by it -- the prepare kernel keeps float offsets into the colour window, 3 per pixel)
+template <int B = WB, int SCALE = 1>
 __device__ inline int decode_members_win(const uint32_t *__restrict__ mask, int p, int words, uint16_t *mem, int lane)
 {
     using G_ = WinT<B>;
@@ -1249,7 +1260,7 @@ __device__ inline int decode_members_win(const uint32_t *__restrict__ mask, int 
         if ((w >> bit) & 1u) {
             const int k = lane + 64 * j;
             const int kl = k / G_::SIDE, kc = k - kl * G_::SIDE;          // (division by a constant: a multiply and a shift)
-            mem[base + __popc(w & below)] = (uint16_t)((kl + 1) * G_::AW + kc + 1);
+            mem[base + __popc(w & below)] = (uint16_t)(((kl + 1) * G_::AW + kc + 1) * SCALE);
         }
     }
     __syncthreads();
@@ -1286,50 +1297,122 @@ __device__ inline void win_commit(float *win, const float (&v)[WIN_SLICE], int f
 static_assert(WIN_SLICE * 64 >= WPIX * 3 && 2 * WIN_SLICE * 64 >= WPIX * 6, "one slice holds the colour window, two the covariance window");
 
 // offset (floats, D per pixel) of component k of a patch vector relative to the member's centre pixel in a window image
-template <int D> __device__ inline int patch_off(int o) { return ((o / 3 - 1) * WAW + (o % 3 - 1)) * D; }
+template <int D, int B = WB> __device__ inline int patch_off(int o) { return ((o / 3 - 1) * WinT<B>::AW + (o % 3 - 1)) * D; }
 
 // ---- PHASE 1 of the windowed kernel, in out-of-line steps (each gets the register file to itself) ----
 // the colour window travels while the members are decoded, then the covariance window in two slices; returns |S|
+// (round 5: any search radius B -- b = 12 stages 4 + 7 slices, 121 loads per lane in flight; with 28 KB of LDS per wavefront at most two share a SIMD,
+// so the registers are there)
+template <int B>
 __device__ __attribute__((noinline)) int win_stage_phase1(float *cwin, float *nwin, uint16_t *mem, const float *__restrict__ colors,
                                                           const float *__restrict__ pixcov, const uint32_t *__restrict__ mask, int p, int pr, int pc,
                                                           int W, int H, int words, int lane)
 {
     LDS_POINTER(cwin); LDS_POINTER(nwin); LDS_POINTER(mem);
     // all 33 loads of the lane are in flight at once (one exposed round trip to memory per item instead of three)
-    float wv[WIN_SLICE], wn0[WIN_SLICE], wn1[WIN_SLICE];
-    win_issue<3>(wv, colors, 0, pr, pc, W, H, lane);
-    win_issue<6>(wn0, pixcov, 0, pr, pc, W, H, lane);
-    win_issue<6>(wn1, pixcov, WIN_SLICE, pr, pc, W, H, lane);
-    const int n = decode_members_win(mask, p, words, mem, lane);
-    win_commit<3>(cwin, wv, 0, lane);
-    win_commit<6>(nwin, wn0, 0, lane);
-    win_commit<6>(nwin, wn1, WIN_SLICE, lane);
+    constexpr int CS = WinT<B>::CSLICES, NS = W1L<B>::COV_WINDOW ? W1L<B>::NSLICES : 0;
+    float wv[CS][WIN_SLICE], wn[NS > 0 ? NS : 1][WIN_SLICE];
+#pragma unroll
+    for (int sl = 0; sl < CS; ++sl) win_issue<3, B>(wv[sl], colors, sl * WIN_SLICE, pr, pc, W, H, lane);
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) win_issue<6, B>(wn[sl], pixcov, sl * WIN_SLICE, pr, pc, W, H, lane);
+    const int n = decode_members_win<B, 3>(mask, p, words, mem, lane);
+#pragma unroll
+    for (int sl = 0; sl < CS; ++sl) win_commit<3, B>(cwin, wv[sl], sl * WIN_SLICE, lane);
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) win_commit<6, B>(nwin, wn[sl], sl * WIN_SLICE, lane);
     __syncthreads();
     return n;
 }
 
 // computeNoiseCovPatchesMean (:400-419) and empiricalMean (:500-509): lanes 0..53 own one noise component, lanes 0..26 also one
-// colour component; sums in member order
-__device__ __attribute__((noinline)) void win_noise_mean(float *noise, float *mean, const float *cwin, const float *nwin, const uint16_t *mem, int n, int lane)
+// colour component; sums in member order.
+// (round 5) The member codes are the same for every lane: they are moved to scalar registers (v_readfirstlane), so that unpacking them and
+// the window offsets they stand for are scalar-unit work and a member costs the vector unit an address add, a read and an add per sum; whole
+// groups of 8 need no "is this slot a member" selects, only the last, partial group does.  (Before: ~75 vector-unit cycles per member --
+// 64-bit multiply-adds for the offsets, a compare and two selects per slot -- in a kernel that is bound by instruction issue.)
+template <int B>
+__device__ __attribute__((noinline)) void win_noise_mean(float *noise, float *mean, const float *cwin, const float *nwin, const uint16_t *mem, int n_, int lane,
+                                                         const float *__restrict__ pixcov = nullptr, int win_origin = 0, int W = 0)
 {
     LDS_POINTER(noise); LDS_POINTER(mean); LDS_POINTER(cwin); LDS_POINTER(nwin); LDS_POINTER(mem);
+    const int n = __builtin_amdgcn_readfirstlane(n_);
+    W = __builtin_amdgcn_readfirstlane(W);
+    win_origin = __builtin_amdgcn_readfirstlane(win_origin);
+    // (arguments of an out-of-line function travel in vector registers: the image pointer is made scalar again)
+    const unsigned long long pixcov_bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)((unsigned long long)pixcov >> 32)) << 32)
+                                           | (uint32_t)__builtin_amdgcn_readfirstlane((int)(unsigned long long)pixcov);
     const float n_inv = 1.f / (float)n;
     const int ln = min(lane, P * 6 - 1), lc = min(lane, K - 1);
-    const int noff = patch_off<6>(ln / 6) + ln % 6, coff = patch_off<3>(lc / 3) + lc % 3;
+    const float *nlane = nwin + (patch_off<6, B>(ln / 6) + ln % 6), *clane = cwin + (patch_off<3, B>(lc / 3) + lc % 3);
+    // without a covariance window: the lane's component of the 3 x 3 patch whose TOP-LEFT pixel is pixel 0 (a non-negative byte offset)
+    const uint32_t glane = (uint32_t)((((ln / 6) / 3) * W + (ln / 6) % 3) * 6 + ln % 6) * 4u;
+    constexpr int AW = WinT<B>::AW, CENTRE = (B + 1) * AW + B + 1;
     float accn = 0.f, accm = 0.f;
-    for (int i = 0; i < n; i += 8) {
+    const int nfull = n & ~7;
+    if (!W1L<B>::COV_WINDOW) {
+        // the per-pixel covariances of the members come from memory, NG members per round trip, sums in member order.  Slots past |S| hold stale
+        // codes of earlier items, which may lie outside the image for this one: they read the centre pixel instead.
+        constexpr int NG = 32;
+        for (int i = 0; i < n; i += NG) {
+            float vn[NG];
+#pragma unroll
+            for (int j = 0; j < NG / 8; ++j)
+                if (i + 8 * j < n) {
+                    const uint4 c8 = *reinterpret_cast<const uint4 *>(mem + i + 8 * j);
+                    const uint32_t cw[4] = { (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.y),
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.w) };
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int wp = (int)((cw[u >> 1] >> (16 * (u & 1))) & 0xffffu) / 3;
+                        const int wq = (i + 8 * j + u < n) ? wp : CENTRE, wy = wq / AW, wx = wq - wy * AW;
+                        // (a scalar base in the global address space + the lane's 32-bit offset: global_load_dword v, v, s[..])
+                        typedef const __attribute__((address_space(1))) char *GlobalBytes;
+                        typedef const __attribute__((address_space(1))) float *GlobalFloat;
+                        GlobalBytes patch = (GlobalBytes)pixcov_bits + (long long)(win_origin + (wy - 1) * W + wx - 1) * 24;
+                        vn[8 * j + u] = *(GlobalFloat)(patch + glane);
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < NG / 8; ++j)
+                if (i + 8 * j < n) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) accn += (i + 8 * j + u < n) ? vn[8 * j + u] : 0.f;
+                }
+        }
+    }
+    for (int i = 0; i < nfull; i += 8) {
         const uint4 c8 = *reinterpret_cast<const uint4 *>(mem + i);
-        const uint32_t cw[4] = { c8.x, c8.y, c8.z, c8.w };
+        const uint32_t cw[4] = { (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.y),
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.w) };
         float vn[8], vm[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int wp = (int)((cw[u >> 1] >> (16 * (u & 1))) & 0xffffu);
-            vn[u] = nwin[wp * 6 + noff];
-            vm[u] = cwin[wp * 3 + coff];
+            const int w3 = (int)((cw[u >> 1] >> (16 * (u & 1))) & 0xffffu); // 3 x the window pixel
+            if (W1L<B>::COV_WINDOW) vn[u] = nlane[w3 * 2];
+            vm[u] = clane[w3];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { // (x + 0.f == x: the padding slots of the last group leave the sums untouched)
-            accn += (i + u < n) ? vn[u] : 0.f;
+        for (int u = 0; u < 8; ++u) {
+            if (W1L<B>::COV_WINDOW) accn += vn[u];
+            accm += vm[u];
+        }
+    }
+    if (nfull < n) { // the last, partial group (slots past |S| hold codes inside the window: read, not added; x + 0.f == x)
+        const int i = nfull;
+        const uint4 c8 = *reinterpret_cast<const uint4 *>(mem + i);
+        const uint32_t cw[4] = { (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.y),
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)c8.w) };
+        float vn[8], vm[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w3 = (int)((cw[u >> 1] >> (16 * (u & 1))) & 0xffffu); // 3 x the window pixel
+            if (W1L<B>::COV_WINDOW) vn[u] = nlane[w3 * 2];
+            vm[u] = clane[w3];
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            if (W1L<B>::COV_WINDOW) accn += (i + u < n) ? vn[u] : 0.f;
             accm += (i + u < n) ? vm[u] : 0.f;
         }
     }
@@ -1343,30 +1426,47 @@ __device__ __attribute__((noinline)) void win_noise_mean(float *noise, float *me
 // element i = l & 31 of member 2 s + (l >> 5) (rows / columns 27..31 zero); a chain of fma in member order, i.e. the reference's
 // sequential sum with the product fused; A and B operands are the same centred value, so the result is bitwise symmetric.
 // The product (x 1 / (n - 1)) leaves the accumulators for a 28 x 29 tile in LDS (row / column 27 exactly zero).
-__device__ __attribute__((noinline)) void win_covariance(float *tile, const float *cwin, const float *mean, const uint16_t *mem, int n, int lane)
+// (round 5: |S| in a scalar register -- the loop's tests are scalar branches, whole groups of 8 members run without them -- and the operands of
+// the next group are read while the matrix core works on the current one; before, every product waited for its own LDS read)
+template <int B>
+__device__ __attribute__((noinline)) void win_covariance(float *tile, const float *cwin, const float *mean, const uint16_t *mem, int n_, int lane)
 {
     LDS_POINTER(tile); LDS_POINTER(cwin); LDS_POINTER(mean); LDS_POINTER(mem);
+    const int n = __builtin_amdgcn_readfirstlane(n_);
     const int mi = lane & 31, mk = lane >> 5, mic = min(mi, K - 1);
+    const bool real = mi < K;
     const float my_mean = mean[mic];
-    const int aoff = patch_off<3>(mic / 3) + mic % 3;
+    const float *alane = cwin + (patch_off<3, B>(mic / 3) + mic % 3);
     v16f acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int s8 = 0; s8 < n; s8 += 8) {
-        const uint4 c8 = *reinterpret_cast<const uint4 *>(mem + s8);
+    // operands of the group of 8 members at s8: member s8 + 2 t + mk for t = 0..3 (slots past |S| hold codes inside the window: read, not used)
+    auto fetch = [&](float (&av)[4], const uint4 c8) {
         const uint32_t cw[4] = { c8.x, c8.y, c8.z, c8.w };
-        float av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) av[t] = alane[(cw[t] >> (16 * mk)) & 0xffffu];   // (the codes are float offsets: 3 x the window pixel)
+    };
+    float av[4], nx[4];
+    fetch(av, *reinterpret_cast<const uint4 *>(mem));
+    uint4 codes = *reinterpret_cast<const uint4 *>(mem + 8);
+    int s8 = 0;
+    for (; s8 + 8 <= n; s8 += 8) {          // whole groups (the list has 16 slots of slack past its last group: W1L::MEM_SLOTS)
+        fetch(nx, codes);                                               // operands one group ahead,
+        codes = *reinterpret_cast<const uint4 *>(mem + s8 + 16);        // codes two groups ahead
+        __builtin_amdgcn_sched_barrier(0);                              // (the reads stay in front of the products)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int wp = (int)((cw[t] >> (16 * mk)) & 0xffffu);       // member s8 + 2 t + mk
-            av[t] = cwin[wp * 3 + aoff];
+            const float a = real ? av[t] - my_mean : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (s8 + 2 * t < n) {                                       // (wave-uniform)
-                const float a = (s8 + 2 * t + mk < n && mi < K) ? av[t] - my_mean : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
-            }
+        for (int t = 0; t < 4; ++t) av[t] = nx[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {           // the last, partial group
+        if (s8 + 2 * t < n) {                                           // (scalar)
+            const float a = (s8 + 2 * t + mk < n && real) ? av[t] - my_mean : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
         }
     }
     const float inv = 1.f / (float)(n - 1);
@@ -1396,7 +1496,7 @@ __device__ __attribute__((noinline)) void win_write_records(float *__restrict__ 
     if (lane < K) recX[P * 6 + lane] = mean[lane];
 }
 
-template <int PHASE>
+template <int PHASE, int B = WB>
 __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                  const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
                                                  int first_item, int nb_items, int *work, Geom27 g, float min_eig, Records27 rec, float *sum,
@@ -1411,14 +1511,15 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float
     // PHASE 2: Cm | A | V | Bm (matrix scratch, then the colour window) | cs | noise | mean | fl | members   (as the gather kernel)
     float *Cm = lds, *A = Cm + MSZ, *V = A + MSZ, *Bm = V + MSZ;
     float *cwin = PHASE == 1 ? lds : Bm;
-    float *nwin = cwin + W1_NWIN;                  // PHASE 1 only (later the 28 x 29 covariance tile)
+    static_assert(PHASE == 1 || B == WB, "the LDS finish (PHASE 2) exists for the default search radius only");
+    float *nwin = cwin + W1L<B>::NWIN;             // PHASE 1 only (later the 28 x 29 covariance tile)
     float *cs = Bm + MSZ;                          // PHASE 2 only
-    float *noise = PHASE == 1 ? lds + W1_NOISE : cs + 2 * KP;
+    float *noise = PHASE == 1 ? lds + W1L<B>::NOISE : cs + 2 * KP;
     float *mean = noise + 56;                      // (54 noise components; offsets stay multiples of 16 bytes)
     float *fl = mean + KP;                         // PHASE 2 only
-    uint16_t *mem = reinterpret_cast<uint16_t *>(PHASE == 1 ? lds + W1_MEM : fl + KP);
+    uint16_t *mem = reinterpret_cast<uint16_t *>(PHASE == 1 ? lds + W1L<B>::MEM : fl + KP);
     static_assert(WPIX * 3 <= MSZ, "the colour window fits a matrix buffer");
-    for (int e = lane; e < WMEM; e += 64) mem[e] = (uint16_t)(WAW + 1); // (entries past |S| are read, never used: keep them inside the window)
+    for (int e = lane; e < (PHASE == 1 ? W1L<B>::MEM_SLOTS : WinT<B>::MEM); e += 64) mem[e] = (uint16_t)((WinT<B>::AW + 1) * (PHASE == 1 ? 3 : 1)); // (PHASE 1 keeps codes x 3; entries past |S| are read, never used: keep them inside the window)
     if (lane == 0) mean[K] = 0.f;
     __syncthreads();
     const int W = g.W, H = g.H;
@@ -1433,13 +1534,13 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float
     float *recA = rec.A + (size_t)slot * MSZ, *recC = rec.C + (size_t)slot * MSZ, *recX = rec.aux + (size_t)slot * AUX27;
 
   if (PHASE == 1) {
-    const int n = win_stage_phase1(cwin, nwin, mem, colors, pixcov, mask, p, pr, pc, W, H, g.words, lane);
-    win_noise_mean(noise, mean, cwin, nwin, mem, n, lane);
-    win_covariance(nwin /* tile: the covariance window is dead by then */, cwin, mean, mem, n, lane);
+    const int n = win_stage_phase1<B>(cwin, nwin, mem, colors, pixcov, mask, p, pr, pc, W, H, g.words, lane);
+    win_noise_mean<B>(noise, mean, cwin, nwin, mem, n, lane, pixcov, (pr - (B + 1)) * W + pc - (B + 1), W);
+    win_covariance<B>(nwin /* tile: the covariance window (if there is one) is dead by then */, cwin, mean, mem, n, lane);
     win_write_records(recA, recC, recX, nwin, noise, mean, lane);
     __syncthreads(); // the next item reuses the LDS
   } else {
-    const int n = decode_members_win(mask, p, g.words, mem, lane);
+    const int n = decode_members_win<WB>(mask, p, g.words, mem, lane);
     {
         const float *recV = rec.V + (size_t)slot * MSZ;
         for (int e = lane; e < MSZ / 4; e += 64) {
@@ -1875,7 +1976,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     static const bool gather_only = [] { const char *e = getenv("BCD_HIP_BAYES_GATHER"); return e && e[0] == '1'; }();
     if (b == WB && !gather_only) {
         // default search radius: the windowed kernels (members read from LDS windows)
-        const size_t wl1 = (size_t)W1_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
+        const size_t wl1 = W1L<WB>::BYTES;
         const size_t wl2 = (size_t)W2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
         const int w_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / wl1), w_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / wl2);
         static const bool lds_algebra = [] { const char *e = getenv("BCD_HIP_FINISH_LDS"); return e && e[0] == '1'; }();
@@ -1905,12 +2006,22 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     static const bool finish_lds_b12 = [] { const char *e = getenv("BCD_HIP_FINISH_LDS"); return e && e[0] == '1'; }();
     const bool finish_regs = b == WB2 && !gather_only && !finish_lds_b12;
     int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP);
-    hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
-                       d_work, g, min_eig, rec, sum, cnt, (const int *)nullptr);
+    // (round 5) b = 12 prepares from LDS windows too: the gather kernel read 105 KB per item (325 members x 81 floats, scattered) where the
+    // 27 x 27 window is 26 KB of whole rows; BCD_HIP_PREPARE_GATHER=1 keeps the gather form (A/B; the records are bit-identical)
+    static const bool prepare_gather = [] { const char *e = getenv("BCD_HIP_PREPARE_GATHER"); return e && e[0] == '1'; }();
+    const bool prepare_win = finish_regs && !prepare_gather;
+    if (prepare_win) {
+        const size_t wl1 = W1L<WB2>::BYTES;
+        const int w_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / wl1);
+        hipLaunchKernelGGL((k_bayes27w<1, WB2>), dim3(std::min(nb_items, num_cus * w_cu1)), dim3(64), wl1, st, colors, pixcov, mask, list, first_item, nb_items,
+                           d_work, g, min_eig, rec, sum, cnt, (const int *)redo);
+    } else
+        hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
+                           d_work, g, min_eig, rec, sum, cnt, (const int *)nullptr);
     { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st, jacobi_conv2(), rec.A); if (e != hipSuccess) return e; }
     if (finish_regs) {
-        // the prepare kernel of this path does not know the redo list: its counter is cleared here (one fill per chunk)
-        { hipError_t e = hipMemsetAsync(redo, 0, sizeof(int), st); if (e != hipSuccess) return e; }
+        // the gather prepare kernel does not know the redo list: its counter is cleared here (one fill per chunk)
+        if (!prepare_win) { hipError_t e = hipMemsetAsync(redo, 0, sizeof(int), st); if (e != hipSuccess) return e; }
         const size_t wl3 = WinT<WB2>::F2_BYTES;
         static std::atomic<int> granted[64];
         int dev = -1;
