@@ -1281,7 +1281,9 @@ __device__ inline void win_issue(float (&v)[WIN_SLICE], const float *__restrict_
         const int e = min(lane + 64 * (first + u), N - 1);
         const int wy = e / ROW, r = e - wy * ROW, px = r / D, ch = r - px * D;
         const int gy = min(max(row0 + wy, 0), H - 1), gx = min(max(col0 + px, 0), W - 1);
-        v[u] = img[(gy * W + gx) * D + ch]; // (32-bit index: DeepImage indices are ints, checked by the host)
+        // (32-bit index: DeepImage indices are ints, checked by the host; image sides are below 2^24, so the line offset is a full-rate 24-bit
+        // multiply; and the image is in the global address space -- inside an out-of-line step the pointer would otherwise be a flat one)
+        v[u] = ((const __attribute__((address_space(1))) float *)img)[(__mul24(gy, W) + gx) * D + ch];
     }
 }
 template <int D, int B = WB>

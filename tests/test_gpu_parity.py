@@ -1024,6 +1024,31 @@ def test_comparison_kernels_stay_correct(switch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["0", "1"])
+def test_large_window_prepare_kernels_agree_with_the_oracle(gather):
+    """-b 12 (BASELINE configs[4]'s window): the prepare kernel with the colour window in LDS (round 5, default) and the gather kernel it replaced
+    (BCD_HIP_PREPARE_GATHER=1, read once per process: run in a child) both reproduce the oracle, on a frame whose border pixels have windows
+    that leave the image (the window kernel reads stale member slots as the centre pixel there) and with |S| up to the full 625"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch, oracle_lib as ol, bcd_amd.core as core, bcd_amd.hip as bh\n"
+            "col, ns, hist, cov = core.synthetic_scene(60, 44, 32, 5, 0.08, 0.0)\n"
+            "ctx = bh.Context(0)\n"
+            "got = ctx.denoise(*[torch.from_numpy(a).cuda() for a in (col, ns, hist, cov)], 1, bh.default_params(m=0.0, b=12)).cpu().numpy()\n"
+            "want = ol.denoise_mono(col, ns, hist, cov, ol.params(m=0.0, b=12))\n"
+            "st = ctx.stats(0)\n"
+            "print('ERR %%.3e FULL %%d' %% (np.max(np.abs(got - want)) / np.max(np.abs(want)), st.processed - st.fallback))\n") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["BCD_HIP_PREPARE_GATHER"] = gather
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("ERR")][-1].split()
+    assert float(line[1]) < TOL and int(line[3]) > 200, line     # (392 of the 2 436 processed pixels take the full estimate)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("W,H,S,ranks,m,random_order,b", [(256, 288, 3, 2, 1.0, 1, 6), (256, 288, 3, 4, 1.0, 1, 6), (256, 288, 3, 4, 0.0, 0, 6),
                                                           (96, 80, 3, 2, 1.0, 0, 3), (70, 66, 2, 3, 0.5, 1, 6), (64, 48, 1, 1, 1.0, 1, 6)])
 def test_native_multi_rank_driver_equals_single_gpu(hipctx, W, H, S, ranks, m, random_order, b):
