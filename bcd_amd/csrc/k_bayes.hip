@@ -488,6 +488,7 @@ __global__ __launch_bounds__(256) void k_bayes_weak_tile(const float *__restrict
     }
     __syncthreads();
     const float inv_side = 1.f / (float)g.side;
+    const int cell0 = (g.b & 15) * ((TW & 63) + 1);             // window offset (-b, -b) in cells
     for (int base = 0; base < npairs; base += 64) {
         const bool live = base + lane < npairs;
         const int code = pairs[live ? base + lane : 0];
@@ -511,8 +512,12 @@ __global__ __launch_bounds__(256) void k_bayes_weak_tile(const float *__restrict
                     while (m) {
                         const int k = (w0 + u) * 32 + __ffs(m) - 1;
                         m &= m - 1;
-                        const int kl = (int)(((float)k + 0.5f) * inv_side), kc = k - kl * g.side; // k / side, see k_bayes_weak
-                        const float *q = src + ((kl - g.b) * TW + (kc - g.b)) * 3;
+                        // k / side, see k_bayes_weak; the window cell as ONE multiply: kl (TW - side) + k - (b, b).  (The masks change nothing -- kl < 25,
+                        // side <= 25, TW <= 42 -- they let the compiler see small factors and fold the two products; 32-bit integer multiplies are
+                        // not slow on gfx950, tools/ubench/int_rate.hip: 4.6-5.4 cycles per wavefront instruction against 3.6 for v_add_f32.)
+                        const int kl = (int)(((float)k + 0.5f) * inv_side) & 31, kc = k - kl * (g.side & 31);
+                        const int cell = kl * (TW & 63) + kc - cell0;
+                        const float *q = src + cell * 3;
 #pragma unroll
                         for (int e = 0; e < 9; ++e) a[e] += q[e];
                         ++n;

@@ -1281,9 +1281,9 @@ __device__ inline void win_issue(float (&v)[WIN_SLICE], const float *__restrict_
         const int e = min(lane + 64 * (first + u), N - 1);
         const int wy = e / ROW, r = e - wy * ROW, px = r / D, ch = r - px * D;
         const int gy = min(max(row0 + wy, 0), H - 1), gx = min(max(col0 + px, 0), W - 1);
-        // (32-bit index: DeepImage indices are ints, checked by the host; image sides are below 2^24, so the line offset is a full-rate 24-bit
-        // multiply; and the image is in the global address space -- inside an out-of-line step the pointer would otherwise be a flat one)
-        v[u] = ((const __attribute__((address_space(1))) float *)img)[(__mul24(gy, W) + gx) * D + ch];
+        // (32-bit index: DeepImage indices are ints, checked by the host; the image is in the global address space -- inside an out-of-line step
+        // the pointer would otherwise be a flat one)
+        v[u] = ((const __attribute__((address_space(1))) float *)img)[(gy * W + gx) * D + ch];
     }
 }
 template <int D, int B = WB>
@@ -1332,7 +1332,7 @@ __device__ __attribute__((noinline)) int win_stage_phase1(float *cwin, float *nw
 // (round 5) The member codes are the same for every lane: they are moved to scalar registers (v_readfirstlane), so that unpacking them and
 // the window offsets they stand for are scalar-unit work and a member costs the vector unit an address add, a read and an add per sum; whole
 // groups of 8 need no "is this slot a member" selects, only the last, partial group does.  (Before: ~75 vector-unit cycles per member --
-// 64-bit multiply-adds for the offsets, a compare and two selects per slot -- in a kernel that is bound by instruction issue.)
+// unpacking, offsets, a compare and two selects per slot -- in a kernel that is bound by instruction issue.)
 template <int B>
 __device__ __attribute__((noinline)) void win_noise_mean(float *noise, float *mean, const float *cwin, const float *nwin, const uint16_t *mem, int n_, int lane,
                                                          const float *__restrict__ pixcov = nullptr, int win_origin = 0, int W = 0)
