@@ -641,17 +641,6 @@ __global__ __launch_bounds__(64, 3) void k_jacobi27_quads(const float *Ain, int 
     }
 }
 
-// JLD-layout copy of the lower triangle of M (LD layout), mirrored, padding row/column zeroed (what Eigen's
-// SelfAdjointEigenSolver reads)
-__device__ void to_jacobi_layout(float *J, const float *M, int lane)
-{
-    for (int e = lane; e < KP * JLD; e += 64) {
-        int r = e / JLD, c = e - r * JLD;
-        J[e] = (r < K && c < K) ? M[(r >= c ? r : c) * LD + (r >= c ? c : r)] : 0.f;
-    }
-    __syncthreads();
-}
-
 __device__ void add_noise27(float *M, const float *noise, int lane, float sign)
 {
     for (int t = lane; t < P * 9; t += 64) {
@@ -1230,7 +1219,7 @@ template <int B> struct W1L {
     static constexpr int MEM_SLOTS = WinT<B>::MEM + 16;  // (the covariance loop reads two groups of 8 ahead)
     static constexpr size_t BYTES = (size_t)MEM * sizeof(float) + MEM_SLOTS * sizeof(uint16_t);
 };
-constexpr int W1_NWIN = W1L<WB>::NWIN, W1_NOISE = W1L<WB>::NOISE, W1_MEM = W1L<WB>::MEM;
+constexpr int W1_MEM = W1L<WB>::MEM;
 constexpr int W2_MEM = 4 * 784 + 56 + 56 + 28 + 28;                              // PHASE 2: four matrix buffers | cs | noise | mean | fl | members
 static_assert(W1_MEM % 4 == 0 && W2_MEM % 4 == 0 && 28 * 29 <= WPIX * 6, "aligned member lists; the covariance tile fits the covariance window");
 static_assert(W1L<12>::MEM % 4 == 0 && W1L<12>::BYTES <= 14 * 1024, "b = 12: a 27 x 27 pixel colour window, eleven wavefronts per CU");
