@@ -1263,6 +1263,20 @@ __device__ inline void win_issue(float (&v)[WIN_SLICE], const float *__restrict_
 {
     constexpr int AW = WinT<B>::AW, ROW = AW * D, N = AW * ROW;
     const int row0 = pr - (B + 1), col0 = pc - (B + 1);
+    // (round 5) a window inside the image -- all but the pixels within b + 1 of the frame's edge -- needs no clamps and no pixel / channel split:
+    // element e of the window is float wy * (W * D) + r of the image, counted from the window's first float (5 vector instructions per load
+    // instead of ~22; pr and pc are wave-uniform, the branch is a scalar one)
+    if (row0 >= 0 && col0 >= 0 && row0 + AW <= H && col0 + AW <= W) {
+        const __attribute__((address_space(1))) float *origin = (const __attribute__((address_space(1))) float *)img + (row0 * W + col0) * D;
+        const int line = W * D;
+#pragma unroll
+        for (int u = 0; u < WIN_SLICE; ++u) {
+            const int e = min(lane + 64 * (first + u), N - 1);
+            const int wy = e / ROW, r = e - wy * ROW;
+            v[u] = origin[wy * line + r];
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < WIN_SLICE; ++u) {
         // (cells outside the image are never part of a member's patch: their content is irrelevant, so the address is clamped
@@ -1300,6 +1314,9 @@ __device__ __attribute__((noinline)) int win_stage_phase1(float *cwin, float *nw
                                                           int W, int H, int words, int lane)
 {
     LDS_POINTER(cwin); LDS_POINTER(nwin); LDS_POINTER(mem);
+    // (arguments of an out-of-line function travel in vector registers: the wave-uniform ones are made scalar again)
+    pr = __builtin_amdgcn_readfirstlane(pr); pc = __builtin_amdgcn_readfirstlane(pc);
+    W = __builtin_amdgcn_readfirstlane(W); H = __builtin_amdgcn_readfirstlane(H);
     // all 33 loads of the lane are in flight at once (one exposed round trip to memory per item instead of three)
     constexpr int CS = WinT<B>::CSLICES, NS = W1L<B>::COV_WINDOW ? W1L<B>::NSLICES : 0;
     float wv[CS][WIN_SLICE], wn[NS > 0 ? NS : 1][WIN_SLICE];
