@@ -27,7 +27,6 @@ hipError_t bcd_launch_compare_planes(const float *, const uint8_t *, const float
 hipError_t bcd_launch_selftest_div(uint32_t, int, int, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_masks(const float *, const uint8_t *, int, int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t,
                             const BcdBorderline *, const float *, const float *, int);
-hipError_t bcd_launch_fwd_masks_rows(const float *, const uint8_t *, int, int, int, float, uint32_t *, hipStream_t, const BcdBorderline *, int, int);
 hipError_t bcd_launch_masks_finish(int, int, int, float, uint32_t *, int32_t *, uint32_t *, hipStream_t, const BcdBorderline *, const float *, const float *, int);
 int bcd_pairdist_rw_supported(int D);
 hipError_t bcd_launch_pairdist_rw(const float *, const float *, int, int, int, int, void * /* binary16 T planes */, uint8_t *, int *, float, hipStream_t);
@@ -114,8 +113,6 @@ struct Work {
     hipStream_t aux = nullptr;     // side stream: the fallback-pixel kernel runs beside the (latency-bound) full estimate kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_pixcov = nullptr; // the per-pixel covariances (side stream, beside the distance kernel) are complete
-    std::vector<hipEvent_t> ev_chunk;  // head pipeline (round 5): the distance planes of a chunk of tile rows are complete
-    hipStream_t prio = nullptr;        // ... and the high-priority stream of its experiment variant
     // approximate distance planes computed ahead of similarity() by a caller that streams the frame in (bcd_hip_denoise_host_ex): valid for
     // exactly this problem; similarity() consumes the note
     struct { bool ready = false; const float *hist = nullptr, *ns = nullptr; int W = 0, H = 0, D = 0, b = 0; float tau = 0.f, uni_n = 0.f; } planes;
@@ -146,7 +143,6 @@ struct bcd_hip_ctx {
     // share of the CU slots the coarse scales' persistent estimate kernels take inside bcd_hip_denoise (bayes()); adjusted from call to
     // call on the same geometry so that the coarse scales end shortly before the finest one (see bcd_hip_denoise)
     int coarse_share = 25;
-    bool coarse_share_fixed = false; // BCD_HIP_COARSE_PCT given
     int64_t share_key = 0;          // geometry the current value was tuned on
     std::mutex err_mutex;
     std::string err;
@@ -381,76 +377,31 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         const int capacity = (int)std::min<size_t>(std::max<size_t>(npix, 1u << 16), 1u << 28);
         RCCHK(ensure(ctx, wk.border, (size_t)capacity * sizeof(uint2)));
         wk.border_capacity = capacity;
-        // (round 5, experiment hook, off by default) Head pipeline: BCD_HIP_HEAD_CHUNKS=n launches the distance kernel of a large scale in n chunks of
-        // tile rows and the forward-mask kernel of a chunk on the side stream while the next chunk's distance planes are being computed.  Measured
-        // at 1080p: 4.80 ms per step with one launch, 4.79 with 2 chunks, 4.94 with 4, 5.28 with 8 -- every chunk boundary drains the chip (the last
-        // workgroups of a chunk run alone), which costs what hiding the 0.2 ms mask kernel saves.
-        static const int head_chunks = [] { const char *e = getenv("BCD_HIP_HEAD_CHUNKS"); const int v = e ? atoi(e) : 1; return std::max(1, std::min(v, 16)); }();
-        const int tile_lines = bcd_pairdist_rw_tile_lines(), tile_rows = (H + tile_lines - 1) / tile_lines;
-        const int chunks = (!pre && head_chunks > 1 && npix >= 400000 && tile_rows >= 8 * head_chunks && uni_n != 0.f) ? head_chunks : 1;
         BcdBorderline bl = { 0.f, (uint2 *)wk.border.p, d_flag + 3, capacity };
         // (round 5) General sample counts (adaptive sampling, 24 spp, ...; src/core/DenoisingUnit.cpp:371-383 handles any n1, n2): the own-list kernel
         // evaluates them at the cost of uniform ones (1.9 - 2.0 ms at 1080p against 2.9 - 3.0 ms for the dense kernel's general formula).
         // Its planes are pixel-major and have a mask kernel of their own.  It raises flag bit 2 when its absolute-error check fails (coarse scales of
         // frames with hundreds of samples per pixel): the pass is then repeated with the dense kernel, and the workspace remembers.
-        static const bool nz_off = [] { const char *e = getenv("BCD_HIP_NO_OWN_LIST"); return e && e[0] == '1'; }();
-        const bool use_nz = !pre && uni_n == 0.f && !nz_off && !(wk.nz_imprecise && wk.nz_imprecise_W == W && wk.nz_imprecise_H == H) && bcd_pairdist_nz_supported(D, b) && npix * (size_t)nd < ((size_t)1 << 31);
+        const bool use_nz = !pre && uni_n == 0.f && !(wk.nz_imprecise && wk.nz_imprecise_W == W && wk.nz_imprecise_H == H) && bcd_pairdist_nz_supported(D, b) && npix * (size_t)nd < ((size_t)1 << 31);
         wk.nz_used = use_nz;
         if (pre) { if (e0) --wk.ev_used; } // (nothing to time: the planes are there)
         else if (use_nz) {
             if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
             HIPCHK(ctx, bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, (long long)nd, 1, d_flag, tau, 3, wk.stream));
             if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
-        } else if (chunks == 1) {
+        } else {
             if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
             HIPCHK(ctx, bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream));
             if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
-        } else {
-            while ((int)wk.ev_chunk.size() < chunks) {
-                hipEvent_t ev;
-                HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                wk.ev_chunk.push_back(ev);
-            }
-            if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
-            // (experiment, BCD_HIP_HEAD_PRIO=1) the chunks have no order among themselves: every chunk but the last goes to a stream of higher priority
-            // forked off here, so that the dispatcher hands out the earlier chunk's workgroups first and fills the chip with the next chunk's as they
-            // retire -- no drained chip at the chunk boundary
-            static const bool head_prio = [] { const char *e = getenv("BCD_HIP_HEAD_PRIO"); return e && e[0] == '1'; }();
-            if (head_prio && !wk.prio) {
-                int lo = 0, hi = 0;
-                HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                HIPCHK(ctx, hipStreamCreateWithPriority(&wk.prio, hipStreamNonBlocking, hi));
-            }
-            if (head_prio) {
-                HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
-                HIPCHK(ctx, hipStreamWaitEvent(wk.prio, wk.ev_fork, 0));
-            }
-            int line0 = 0;
-            for (int i = 0; i < chunks; ++i) {
-                const int t0 = (int)((int64_t)tile_rows * i / chunks), t1 = (int)((int64_t)tile_rows * (i + 1) / chunks);
-                hipStream_t cs = (head_prio && i + 1 < chunks) ? wk.prio : wk.stream;
-                HIPCHK(ctx, bcd_launch_pairdist_rw_rows(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, t0, t1, cs));
-                HIPCHK(ctx, hipEventRecord(wk.ev_chunk[i], cs));
-                // forward bits of the lines whose three plane lines are complete: up to the chunk's last line but three (the last chunk: to the end)
-                const int line1 = i + 1 == chunks ? H : t1 * tile_lines - 4;
-                HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_chunk[i], 0));
-                HIPCHK(ctx, bcd_launch_fwd_masks_rows((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, b, tau, (uint32_t *)wk.fwd.p, wk.aux, &bl, line0, line1));
-                line0 = line1;
-            }
-            if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
-            HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
-            HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_join, 0));
         }
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 42, d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, wk.stream)); // "another sample count" (plain-store flag)
         if (use_nz) {
             HIPCHK(ctx, bcd_launch_fwd_masks_pm(wk.T.p, (const uint8_t *)wk.Cn.p, W, H, tau, (uint32_t *)wk.fwd.p, &bl, wk.stream));
             HIPCHK(ctx, bcd_launch_masks_finish(W, H, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream, &bl, d_hist, d_ns, D));
-        } else if (chunks == 1)
+        } else
             HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream,
                                          &bl, d_hist, d_ns, D));
-        else
-            HIPCHK(ctx, bcd_launch_masks_finish(W, H, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream, &bl, d_hist, d_ns, D));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 43, d_flag + 3, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         if (exact_mode == 0) {
             HIPCHK(ctx, hipStreamSynchronize(wk.stream));
@@ -583,13 +534,11 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     RCCHK(ensure(ctx, wk.weak, npix * sizeof(int32_t)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int32_t *d_c = (int32_t *)wk.counters.p + 16; // [0] strong, [1] weak, [2..3] sum |S|, [4..6] work counters of the generic estimate kernel, [7] spectral inverses
-    static const bool weak_lists = [] { const char *e = getenv("BCD_HIP_WEAK_LISTS"); return e && e[0] == '1'; }();
-    const bool weak_tiles = w == 1 && !weak_lists;
+    const bool weak_tiles = w == 1; // (other patch radii: the list kernel below)
     wk.h_counters[23] = 0;
     // the two paths only meet in the atomic accumulators: the fallback pixels run on a side stream.  The tiled fallback kernel needs no
     // list (it reads states and |S| itself), so it starts at once -- beside the list compaction and the host round trip for the number of
     // full estimates, during which this scale would otherwise leave the chip idle -- and is out of the way when the prepare kernel arrives
-    static const bool weak_first = [] { const char *e = getenv("BCD_HIP_WEAK_FIRST"); return e && e[0] == '1'; }(); // (experiment hook: the round-4 order)
     auto fork_weak_tiles = [&]() -> int {
         HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
         HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
@@ -597,14 +546,13 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
         HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
         return BCD_HIP_OK;
     };
-    if (weak_tiles && weak_first) RCCHK(fork_weak_tiles());
     if (wk.clean_dc) wk.clean_dc = false; // (k_scale_begin)
     else HIPCHK(ctx, hipMemsetAsync(d_c, 0, 8 * sizeof(int32_t), wk.stream));
     HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)wk.strong.p, (int32_t *)wk.weak.p, d_c, wk.stream));
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream));
     // (round 5) the list compaction is 253 workgroups of 1024 threads: 18 us alone, 150 us when the fallback kernel's 8 160 tiles were launched
     // first and every CU had to drain before one of them fitted.  The fallback kernel starts BEHIND it (it still overlaps the host round trip).
-    if (weak_tiles && !weak_first) RCCHK(fork_weak_tiles());
+    if (weak_tiles) RCCHK(fork_weak_tiles());
     const int64_t cap = std::max<int64_t>(1, npix);
     // The estimate kernels are persistent (a wavefront per CU slot, items from a counter), so whatever they occupy stays
     // occupied until they end.  In a multiscale call the finest scale is the critical path and the coarse scales have slack: they
@@ -811,9 +759,6 @@ void work_destroy(Work &w)
     for (int i = 0; i < 4; ++i) if (w.ev_stage[i]) (void)hipEventDestroy(w.ev_stage[i]);
     if (w.ev_done) (void)hipEventDestroy(w.ev_done);
     if (w.ev_built) (void)hipEventDestroy(w.ev_built);
-    for (hipEvent_t ev : w.ev_chunk) (void)hipEventDestroy(ev);
-    if (w.prio) { (void)hipStreamDestroy(w.prio); w.prio = nullptr; }
-    w.ev_chunk.clear();
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
     if (w.ev_join) (void)hipEventDestroy(w.ev_join);
     if (w.ev_pixcov) (void)hipEventDestroy(w.ev_pixcov);
@@ -869,10 +814,6 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) ctx->num_cus = cus;
-    }
-    if (const char *pct = getenv("BCD_HIP_COARSE_PCT")) {
-        ctx->coarse_share = std::min(100, std::max(1, atoi(pct)));
-        ctx->coarse_share_fixed = true;
     }
     const char *env = getenv("BCD_HIP_SERIAL_SCALES");
     ctx->concurrent_scales = !(env && env[0] == '1');
@@ -1025,7 +966,7 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
         // the finest scale is at 80 - 92 % of its chain -- earlier means their persistent kernels took more room than they needed next to
         // the finest scale's short kernels, later means they have become the critical path.  Small steps down, larger ones up.
         const int64_t key = ((int64_t)W << 40) ^ ((int64_t)H << 20) ^ ((int64_t)nb_scales << 12) ^ ((int64_t)prm->search_radius << 4) ^ (prm->marked_skip_probability > 0.f);
-        if (!ctx->coarse_share_fixed && key != ctx->share_key) { ctx->coarse_share = 25; ctx->share_key = key; }
+        if (key != ctx->share_key) { ctx->coarse_share = 25; ctx->share_key = key; }
         const auto t_start = std::chrono::steady_clock::now();
         double t_done[MAX_SCALES] = { 0 };
         HIPCHK(ctx, hipEventRecord(ctx->ev_pyramid, ctx->stream)); // the caller's inputs are ready
@@ -1076,7 +1017,7 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
         }
         for (int s = 1; s < nb_scales; ++s) threads[s].join();
         for (int s = 0; s < nb_scales; ++s) RCCHK(rcs[s]);
-        if (!ctx->coarse_share_fixed && nb_scales > 1 && t_done[0] > 0.0) {
+        if (nb_scales > 1 && t_done[0] > 0.0) {
             double last = 0.0;
             for (int s = 1; s < nb_scales; ++s) last = std::max(last, t_done[s]);
             const double frac = last / t_done[0];
@@ -1174,11 +1115,6 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
     // Everything else needs the whole frame (pyramid, the marking order) and follows the last chunk.
     const int b = prm->search_radius, tile = bcd_pairdist_rw_tile_lines();
     const bool stream_in = ctx->stream_uploads && fast_similarity_applies(ctx, D, prm->patch_radius, prm->hist_dist_threshold) && H >= 256;
-    // BCD_HIP_HOST_TIMING=1: where the host-buffer call spends its time, on stderr (diagnostic)
-    static const bool host_timing = [] { const char *e = getenv("BCD_HIP_HOST_TIMING"); return e && e[0] == '1'; }();
-    const auto ht0 = std::chrono::steady_clock::now();
-    auto ht_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count(); };
-    double ht_enq = 0.0, ht_up = 0.0, ht_dn = 0.0;
     if (!stream_in) {
         for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipMemcpyAsync(d[i], src[i], sz[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         if (prefilter) HIPCHK(ctx, bcd_launch_spike(d[0], d[1], d[2], d[3], W, H, D, opt->spike_factor, d[5], d[6], d[7], d[8], ctx->stream));
@@ -1271,8 +1207,6 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
             }
         }
         if (sparse) bcd_sparse_frame_bytes(ctx->sparse, &ctx->upload_raw_bytes, &ctx->upload_sent_bytes);
-        ht_enq = ht_ms(); // every piece packed and enqueued
-        if (host_timing) { HIPCHK(ctx, hipStreamSynchronize(ctx->upload_stream)); ht_up = ht_ms(); } // (timing only: the last piece has arrived)
         if (side) { // colours and covariances have been enqueued by now (the helper thread is joined), the frame's kernels wait for their arrival
             side_copy.join();
             HIPCHK(ctx, side_rc);
@@ -1288,12 +1222,8 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
     }
     // checkAndPutToZeroNegativeInfNaNValues (src/cli/main.cpp:389-420, 470)
     if (opt && opt->zero_bad_values) HIPCHK(ctx, bcd_launch_zero_bad(d[4], (int64_t)np * 3, ctx->stream));
-    if (host_timing) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ht_dn = ht_ms(); }
     HIPCHK(ctx, hipMemcpyAsync(h_out, d[4], sz[4] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (host_timing)
-        fprintf(stderr, "bcd_hip_denoise_host %dx%d: pieces packed + enqueued at %.2f ms, last piece on the device at %.2f, frame denoised at %.2f, result on the host at %.2f ms\n",
-                W, H, ht_enq, ht_up, ht_dn, ht_ms());
     return BCD_HIP_OK;
 }
 

@@ -241,7 +241,7 @@ struct bcd_hip_multi {
     // never returns).  The abort therefore waits for the section only this long and then proceeds anyway: ncclCommAbort is what releases a
     // blocked call (round-4 ADVICE: with an unbounded wait the watchdog could no longer end a frame whose peer is gone).
     int abort_wait_ms = 5000;                 // BCD_HIP_MULTI_ABORT_WAIT_MS
-    bool abort_forced = false;                // the last abort did not get the section to itself (diagnostics / self-test)
+    std::atomic<bool> abort_forced{ false };  // the last abort did not get the section to itself (diagnostics / self-test; written by the aborting thread, read by others)
     bool comm_aborted = false;
     // loopback (bcd_hip_multi_set_loopback; one rank, tests on a one-GPU box): the rank is its own neighbour on both sides -- every exchange and
     // all-reduce of a frame is enqueued on real RCCL communicators (ncclCommInitRank with n = 1, grouped self send / recv), in the order and with
@@ -278,7 +278,10 @@ void abort_comms(bcd_hip_multi *m)
     if (!m->use_rccl) return;
     std::unique_lock<std::shared_timed_mutex> excl(m->comm_rw, std::defer_lock);
     // normally no rank thread is inside an RCCL call on these communicators when they are freed; a thread that is STUCK in one is released by the abort itself
-    m->abort_forced = !excl.try_lock_for(std::chrono::milliseconds(std::max(0, m->abort_wait_ms)));
+    // A forced abort (the wait ran out) frees communicators a rank thread may still be inside: right for a thread that is STUCK in an RCCL call (the abort
+    // is what releases it), a residual use-after-free risk for one that is merely slow.  ncclCommAbort cannot be split into "stop" and "free", so the
+    // bound is a knob (BCD_HIP_MULTI_ABORT_WAIT_MS, default 5 s -- three orders of magnitude above a healthy enqueue section); INTEGRATION.md says so.
+    m->abort_forced.store(!excl.try_lock_for(std::chrono::milliseconds(std::max(0, m->abort_wait_ms))));
     std::lock_guard<std::mutex> lk(m->comm_mutex);
     for (int c = 0; c <= MAX_S; ++c) {
         if (!m->comm_ready[c]) continue;
@@ -1089,7 +1092,7 @@ int bcd_hip_multi_selftest_transport(int device, long long halo_bytes, char *rep
         m->abort_wait_ms = keep;
         release.store(true);
         stuck.join();
-        if (!m->abort_forced || m->comm_ready[0] || waited_ms > 5000.0) { say("an abort behind a stuck enqueue section did not go through in bounded time"); return BCD_HIP_EDEVICE; }
+        if (!m->abort_forced.load() || m->comm_ready[0] || waited_ms > 5000.0) { say("an abort behind a stuck enqueue section did not go through in bounded time"); return BCD_HIP_EDEVICE; }
     }
     say("ok: ncclCommInitRank(n=1) x2, grouped self send/recv + int64 all-reduce on 2 channels, ncclCommAbort, rebuild from fresh ids, second exchange, "
         "abort behind a stuck enqueue section after a bounded wait; " + rccl_identity());

@@ -1981,8 +1981,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     rec.eig = rec.aux + (size_t)nb_items * AUX27;
     const size_t lds2 = bcd_bayes27_lds_bytes(b), lds1 = lds2 - 3 * MSZ * sizeof(float);
     const int per_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / lds1), per_cu2 = (int)std::min<size_t>(12, (size_t)160 * 1024 / lds2);
-    static const bool gather_only = [] { const char *e = getenv("BCD_HIP_BAYES_GATHER"); return e && e[0] == '1'; }();
-    if (b == WB && !gather_only) {
+    if (b == WB) {
         // default search radius: the windowed kernels (members read from LDS windows)
         const size_t wl1 = W1L<WB>::BYTES;
         const size_t wl2 = (size_t)W2_MEM * sizeof(float) + WMEM * sizeof(uint16_t);
@@ -2012,7 +2011,7 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
     }
     constexpr int WB2 = 12; // the large search window of BASELINE configs[4]: register-resident finish on a 27 x 27 pixel window (round 4)
     static const bool finish_lds_b12 = [] { const char *e = getenv("BCD_HIP_FINISH_LDS"); return e && e[0] == '1'; }();
-    const bool finish_regs = b == WB2 && !gather_only && !finish_lds_b12;
+    const bool finish_regs = b == WB2 && !finish_lds_b12;
     int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP);
     // (round 5) b = 12 prepares from LDS windows too: the gather kernel read 105 KB per item (325 members x 81 floats, scattered) where the
     // 27 x 27 window is 26 KB of whole rows; BCD_HIP_PREPARE_GATHER=1 keeps the gather form (A/B; the records are bit-identical)

@@ -303,75 +303,11 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
 // Exact re-evaluation of the borderline pairs: entry = (pixel index, displacement index); nine lanes evaluate the nine pixel
 // pairs of the patch with the reference's operation sequence (DenoisingUnit.cpp:360-386: sequential bins, IEEE division),
 // one lane adds them in patch order (:336-358) and sets the forward bit when d <= tau.
+// A pixel's 240-byte histogram row read as fifteen separate 16-byte loads of ONE lane (the form of rounds 2-4) keeps nothing in the L1 -- 63 rows per
+// instruction, every 64-byte line fetched up to four times -- and at 2e5 .. 1e6 borderline pairs (textured frames, b = 12) the kernel was bound by that
+// traffic (0.5 .. 1.9 ms).  Here the 126 rows of a wavefront's 63 pixel pairs are loaded in pieces of five 16-byte groups by FIVE CONSECUTIVE lanes each
+// (80 contiguous bytes), parked in LDS, and every pair lane then reads its own two rows back.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_verify_pairs(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H, int D, int b,
-                                                     float tau, const uint2 *__restrict__ list, const int *__restrict__ d_count, int capacity,
-                                                     int fwords, uint32_t *__restrict__ fwd)
-{
-    const int lane = threadIdx.x, slot = lane / 9, o = lane - slot * 9; // 7 entries per wavefront, lane 63 idle
-    const int n = min(*d_count, capacity);
-    const int side = 2 * b + 1;
-    for (int base = blockIdx.x * 7; base < n; base += gridDim.x * 7) {
-        const int e = base + slot;
-        const bool live = slot < 7 && e < n;
-        float sum = 0.f;
-        int cnt = 0;
-        uint2 ent = make_uint2(0u, 0u);
-        if (live) {
-            ent = list[e];
-            const int p = (int)ent.x, didx = (int)ent.y;
-            int dl = 0, dc = didx;
-            if (didx > b) { const int t = didx - (b + 1); dl = 1 + t / side; dc = t - (dl - 1) * side - b; }
-            const int pr = p / W, pc = p - pr * W;
-            const int xr = pr + o / 3 - 1, xc = pc + o % 3 - 1; // patch pixel o (row-major), and its partner
-            const size_t x = (size_t)xr * W + xc, y = (size_t)(xr + dl) * W + (xc + dc);
-            const float *h1 = hist + x * D, *h2 = hist + y * D;
-            const float n1 = ns[x], n2 = ns[y], n12 = n1 * n2;
-            // one bin of DenoisingUnit.cpp:379-383, in the reference's order
-            auto bin = [&](float b1, float b2) __attribute__((always_inline)) {
-                const float s = b1 + b2;
-                if (s <= 1.f) return;
-                ++cnt;
-                const float diff = n2 * b1 - n1 * b2;
-                sum += diff * diff / (n12 * s);
-            };
-            if ((D & 3) == 0) { // whole 16-byte groups (pixel strides are multiples of 16 bytes then): five groups of each histogram in flight
-                const float4 *v1 = reinterpret_cast<const float4 *>(h1), *v2 = reinterpret_cast<const float4 *>(h2);
-                const int Q = D >> 2;
-                for (int q0 = 0; q0 < Q; q0 += 5) {
-                    float4 a[5], c[5];
-#pragma unroll
-                    for (int u = 0; u < 5; ++u) { const int q = min(q0 + u, Q - 1); a[u] = v1[q]; c[u] = v2[q]; }
-#pragma unroll
-                    for (int u = 0; u < 5; ++u)
-                        if (q0 + u < Q) { bin(a[u].x, c[u].x); bin(a[u].y, c[u].y); bin(a[u].z, c[u].z); bin(a[u].w, c[u].w); }
-                }
-            } else
-                for (int k = 0; k < D; ++k) bin(h1[k], h2[k]);
-        }
-        // patch order: ((((t0 + t1) + t2) + ...) + t8), counts as integers
-        float tot = 0.f;
-        int ctot = 0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int srcl = min(slot * 9 + i, 63);
-            const float ti = __shfl(sum, srcl);
-            const int ci = __shfl(cnt, srcl);
-            tot = (i == 0) ? ti : tot + ti; // the reference starts from 0.f: 0 + t0 == t0 bit for bit (t0 >= +0)
-            ctot += ci;
-        }
-        if (live && o == 0) {
-            const float d = tot / (float)ctot; // 0/0 = NaN -> not similar
-            if (d <= tau) atomicOr(fwd + (size_t)ent.x * fwords + (ent.y >> 5), 1u << (ent.y & 31));
-        }
-    }
-}
-
-// The same through LDS (round 5).  k_verify_pairs reads a pixel's 240-byte histogram row as fifteen separate 16-byte loads of ONE lane, spread over time:
-// with 63 rows per instruction the L1 keeps nothing, every 64-byte line is fetched up to four times, and at 2e5 .. 1e6 borderline pairs (textured frames,
-// b = 12) the kernel was bound by that traffic (0.5 .. 1.9 ms).  Here the 126 rows of a wavefront's 63 pixel pairs are loaded in pieces of five 16-byte
-// groups by FIVE CONSECUTIVE lanes each (80 contiguous bytes), parked in LDS, and every pair lane then reads its own two rows back -- the arithmetic and
-// its order are exactly those of k_verify_pairs.
 constexpr int VP_PIECE = 5;                       // 16-byte groups per piece (20 bins)
 constexpr int VP_ROWS = 126;                      // rows per wavefront: 63 pixel pairs x 2
 constexpr int VP_STRIDE = VP_PIECE * 4 + 1;       // floats per parked row piece (odd: conflict-free column reads)
@@ -498,9 +434,7 @@ static hipError_t pairdist_rw_rows(const float *hist, const float *ns, int W, in
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
 #define BCD_RW_LAUNCH(DD, UU)                                                                                        \
     {                                                                                                                \
-        /* (experiment hook: BCD_HIP_RW_EXTRA_LDS=bytes pads the allocation -- the occupancy a kernel with more LDS would get) */ \
-        static const size_t extra = [] { const char *e = getenv("BCD_HIP_RW_EXTRA_LDS"); return e ? (size_t)atol(e) : (size_t)0; }(); \
-        const size_t lds = (size_t)RwLayout<DD>::LDS_DWORDS * 4 + extra;                                             \
+        const size_t lds = (size_t)RwLayout<DD>::LDS_DWORDS * 4;                                                     \
         static std::atomic<int> granted[64]; /* per instantiation and device */                                     \
         if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || granted[dev].load() == 0)) {                                 \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist_rw<DD, UU>),               \
@@ -553,11 +487,8 @@ hipError_t bcd_launch_verify_pairs(const float *hist, const float *ns, int W, in
 {
     const int fwords = (bcd_delta_count(b) + 31) / 32;
     // (the number of pairs is on the device: a fixed grid of 16 wavefronts per CU; with nothing listed every wavefront leaves at once)
-    static const bool plain = [] { const char *e = getenv("BCD_HIP_VERIFY_PLAIN"); return e && e[0] == '1'; }(); // (A/B: the per-lane loads of rounds 2-4)
-    if ((D & 3) == 0 && !plain)
-        hipLaunchKernelGGL(k_verify_pairs_lds, dim3(4096), dim3(64), 0, st, hist, ns, W, H, D >> 2, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
-    else
-        hipLaunchKernelGGL(k_verify_pairs, dim3(4096), dim3(64), 0, st, hist, ns, W, H, D, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
+    if ((D & 3) != 0) return hipErrorInvalidValue; // (every depth bcd_pairdist_rw_supported admits is a multiple of four)
+    hipLaunchKernelGGL(k_verify_pairs_lds, dim3(4096), dim3(64), 0, st, hist, ns, W, H, D >> 2, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
     return hipGetLastError();
 }
 

@@ -428,8 +428,7 @@ hipError_t bcd_launch_pairdist_nz(const float *hist, const float *ns, int W, int
         if (dev >= 0 && dev < 64) cus_of[dev].store(cus);
     }
     const int nwg = std::max(8, std::min((cus / 8) * 8, ((tx * ty + 7) / 8) * 8));
-    static const bool persist_env = [] { const char *e = getenv("BCD_HIP_NZ_PERSIST"); return e && e[0] == '1'; }();
-    const bool persist = persist_env || (variant & 4) != 0; // (variant bit 2: the persistent form, for A/B measurements)
+    const bool persist = (variant & 4) != 0; // (variant bit 2: the persistent form, for A/B measurements)
     variant &= 3;
 #define BCD_NZ_LAUNCH3(DD, RL, BD, PF, PS)                                                                                             \
     {                                                                                                                      \

@@ -8,6 +8,7 @@
 #include "bcd_hip.h"
 
 #include <hip/hip_runtime_api.h>
+#include <algorithm>
 #include <cmath>
 #include <iostream>
 #include <vector>
@@ -131,8 +132,18 @@ namespace bcd
 		if(ok)
 			ok = bcd_hip_spike_filter(pCtx, in[0], in[1], in[2], in[3], w, h, d, i_thresholdStDevFactor, out[0], out[1], out[2], out[3]) == BCD_HIP_OK;
 		bcd_hip_ctx_destroy(pCtx); // synchronises the context's stream
+		// All or nothing: the four results are downloaded into temporaries and only committed once every copy has succeeded, so a failure at
+		// any point leaves the caller's images exactly as they came in (filter() relies on this when it falls back to the host loops: they must
+		// decide spikes on unfiltered colours and copy from unfiltered images).
+		std::vector<float> filtered[4];
 		for(int i = 0; i < 4 && ok; ++i)
-			ok = hipMemcpy(images[i]->getDataPtr(), out[i], sizeof(float) * size_t(images[i]->getSize()), hipMemcpyDeviceToHost) == hipSuccess;
+		{
+			filtered[i].resize(size_t(images[i]->getSize()));
+			ok = hipMemcpy(filtered[i].data(), out[i], sizeof(float) * filtered[i].size(), hipMemcpyDeviceToHost) == hipSuccess;
+		}
+		if(ok)
+			for(int i = 0; i < 4; ++i)
+				std::copy(filtered[i].begin(), filtered[i].end(), images[i]->getDataPtr());
 		for(int i = 0; i < 4; ++i)
 		{
 			if(in[i]) (void)hipFree(in[i]);
@@ -141,7 +152,7 @@ namespace bcd
 		if(previousDevice >= 0)
 			(void)hipSetDevice(previousDevice);
 		if(!ok)
-			std::cerr << "SpikeRemovalFilter: device error, images may be partially filtered" << std::endl;
+			std::cerr << "SpikeRemovalFilter: device error, images left untouched" << std::endl;
 		return ok;
 	}
 

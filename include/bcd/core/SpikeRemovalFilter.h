@@ -21,8 +21,8 @@ namespace bcd
 				float i_thresholdStDevFactor = 2.f);
 
 		/// the same on a chosen HIP device, with a result: false = no usable device or a device error (the images are then
-		/// unchanged or partially filtered, and a message is on cerr unless i_quiet).  filter() is this on device 0 with the reference's void
-		/// signature, falling back to filterOnHost() when there is no usable device
+		/// UNCHANGED -- results are committed only after all four came back -- and a message is on cerr unless i_quiet).  filter() is this on device 0 with the reference's void
+		/// signature, falling back to filterOnHost() on the untouched images when that returns false
 		static bool filterOnDevice(
 				int i_device,
 				DeepImage<float>& io_rInputColorImage,
