@@ -119,8 +119,11 @@ struct Work {
     // uniform-sample-count speculation of the approximate distance kernel (similarity()): did the last frames on this workspace fail it?
     bool nonuniform = false;
     bool speculated = false;       // the current pass launched the uniform kernel on the first pixel's count, unchecked by the host
-    bool nz_imprecise = false;     // the own-list kernel raised its absolute-error flag on a frame of this size on this workspace: the dense kernel's general formula serves that size
-    int nz_imprecise_W = 0, nz_imprecise_H = 0;
+    // the own-list kernel raised its absolute-error flag on frames of these sizes on this workspace: the dense kernel's general formula serves them (a small
+    // set, oldest replaced: serialised scales share one workspace, a caller may alternate frame sizes)
+    struct { int W = 0, H = 0; } nz_declined[4];
+    int nz_declined_next = 0;
+    bool nz_is_declined(int W, int H) const { for (const auto &k : nz_declined) if (k.W == W && k.H == H) return true; return false; }
     bool nz_used = false;          // the current pass ran the own-list kernel (k_similarity_nz.hip)
     int nz_W = 0, nz_H = 0;        // ... on a frame of this size
     // (round 4) k_scale_begin cleared these at the head of the scale's stream: the first user takes them as they are, a repeated use (second
@@ -282,7 +285,7 @@ int similarity_redo_mode(Work &wk)
     if (fast && (wk.speculated || other_count)) wk.nonuniform = other_count;
     if (flag == 0 && !other_count && !overflow) return 0;
     if (fast && wk.nz_used && (flag & 4) != 0) { // the own-list kernel's absolute-error check: the dense kernel's general formula serves this workspace from now on
-        wk.nz_imprecise = true; wk.nz_imprecise_W = wk.nz_W; wk.nz_imprecise_H = wk.nz_H;
+        if (!wk.nz_is_declined(wk.nz_W, wk.nz_H)) { wk.nz_declined[wk.nz_declined_next] = { wk.nz_W, wk.nz_H }; wk.nz_declined_next = (wk.nz_declined_next + 1) & 3; }
         if ((flag & ~4) == 0) return 3;
     }
     return (flag == 0 && other_count) ? 3 : 1; // (a void launch has no meaningful list count: other_count alone decides)
@@ -382,7 +385,7 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         // evaluates them at the cost of uniform ones (1.9 - 2.0 ms at 1080p against 2.9 - 3.0 ms for the dense kernel's general formula).
         // Its planes are pixel-major and have a mask kernel of their own.  It raises flag bit 2 when its absolute-error check fails (coarse scales of
         // frames with hundreds of samples per pixel): the pass is then repeated with the dense kernel, and the workspace remembers.
-        const bool use_nz = !pre && uni_n == 0.f && !(wk.nz_imprecise && wk.nz_imprecise_W == W && wk.nz_imprecise_H == H) && bcd_pairdist_nz_supported(D, b) && npix * (size_t)nd < ((size_t)1 << 31);
+        const bool use_nz = !pre && uni_n == 0.f && !wk.nz_is_declined(W, H) && bcd_pairdist_nz_supported(D, b) && npix * (size_t)nd < ((size_t)1 << 31);
         wk.nz_used = use_nz;
         if (pre) { if (e0) --wk.ev_used; } // (nothing to time: the planes are there)
         else if (use_nz) {

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
 
     // per-thread share of a tile's staged histograms: NLOAD 16-byte groups (LDS offsets do not depend on the tile)
     float4 v[L::NLOAD];
-    float nv = -1.f;
+    float nv = 1.f;
+    bool nv_in = false; // the thread's staged pixel lies inside the image (an explicit flag: ANY count value of an in-image pixel goes through the range check)
     auto prefetch = [&](int tile) __attribute__((always_inline)) {
         const int c0 = (tile % tiles_x) * NZ_TC, r0 = (tile / tiles_x) * NZ_TR;
 #pragma unroll
@@ -153,10 +154,11 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (in) v[u] = reinterpret_cast<const float4 *>(hist)[((size_t)gr * W + gc) * Q + q];
         }
-        nv = -1.f; // (outside the image)
+        nv = 1.f;
+        nv_in = false;
         if (tid < NPIX) {
             const int line = tid / NZ_NCS, col = tid - line * NZ_NCS, gr = r0 + line, gc = c0 - NZ_B + col;
-            if (gr < H && gc >= 0 && gc < W) nv = ns[(size_t)gr * W + gc];
+            if (gr < H && gc >= 0 && gc < W) { nv = ns[(size_t)gr * W + gc]; nv_in = true; }
         }
     };
     long long pc[5] = { 0, 0, 0, 0, 0 }, slots = 0;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
             // (NaN: fminf / fmaxf drop it, so test the values themselves too)
             bad = bad || !(lo >= 0.f && hi <= NZ_BIN_MAX) || !(v[u].x == v[u].x && v[u].y == v[u].y && v[u].z == v[u].z && v[u].w == v[u].w);
         }
-        const bool in_image = !(nv == -1.f); // (a NaN count is inside, and bad)
+        const bool in_image = nv_in; // (a NaN or negative count is inside, and bad)
         if (tid < NPIX) { bad = bad || (in_image && !(nv >= NZ_N_MIN && nv <= NZ_N_MAX)); s_n[tid] = in_image ? nv : 1.f; }
         if (tid == 0) *s_counter = 0;
         if (__syncthreads_or(bad) && tid == 0) atomicOr(range_flag, 1);

@@ -133,14 +133,137 @@ def test_denoiser_reduces_error_and_orders_matter():
     assert np.max(np.abs(o0 - o0b)) / np.max(np.abs(o0b)) < 1e-5
 
 
+# ---- a10, second reading -------------------------------------------------------------------------------------------------------------
+# selectSimilarPatches / histogramPatchDistance / pixelSummedHistogramDistance transcribed from /root/reference/src/core/DenoisingUnit.cpp:196-219,
+# 336-358, 360-386 and the window clip of include/bcd/core/DeepImage.hpp:181-196 -- from the reference text, not from oracle/bcd_oracle.c -- in
+# np.float32 arithmetic (every NumPy float32 operation is one correctly rounded IEEE operation, never fused: the x86-64 baseline build of the
+# reference).  Two forms: a scalar one that IS the reference's loop nest (slow: used on a few main pixels), and an array one that runs the same
+# per-element operation sequence for every pixel pair of a displacement at once (bins still one after the other, the nine patch pixels still added
+# in row-major order starting from 0.f).
+
+def _np32_patch_distance_scalar(ns, hist, w, p, q):
+    """histogramPatchDistance(p, q), statement by statement (:336-358 calling :360-386)"""
+    f32 = np.float32
+    summed = f32(0.0)                                                    # float summedDistance = 0;
+    total = 0                                                            # int totalNbOfNonBoth0Bins = 0;
+    with np.errstate(all="ignore"):
+        for a in range(-w, w + 1):                                       # PixelPatch iteration: row-major (DeepImage.hpp window iterators)
+            for d in range(-w, w + 1):
+                h1, h2 = hist[p[0] + a, p[1] + d], hist[q[0] + a, q[1] + d]
+                n1, n2 = f32(ns[p[0] + a, p[1] + d, 0]), f32(ns[q[0] + a, q[1] + d, 0])
+                nb = 0                                                   # i_rNbOfNonBoth0Bins = 0;
+                acc = f32(0.0)                                           # float sum = 0.f;
+                for k in range(hist.shape[2]):
+                    b1, b2 = f32(h1[k]), f32(h2[k])
+                    if b1 + b2 <= f32(1.0):                              # :379 (the "TEMPORARY" criterion is the one compiled)
+                        continue
+                    nb += 1
+                    diff = n2 * b1 - n1 * b2                             # :382
+                    acc = acc + diff * diff / (n1 * n2 * (b1 + b2))      # :383
+                summed = summed + acc                                    # :354
+                total += nb                                              # :355
+        return summed / f32(total)                                       # :357 (int -> float, 0 / 0 -> NaN)
+
+
+def _np32_window_distances(ns, hist, w, b):
+    """(H, W, (2b+1)^2) float32: histogramPatchDistance of every main pixel to every pixel of its clipped search window (+inf outside it), the
+    array form of the transcription above"""
+    H, W, D = hist.shape
+    side = 2 * b + 1
+    out = np.full((H, W, side * side), np.inf, np.float32)
+    n = ns[..., 0]
+    with np.errstate(all="ignore"):
+        for dl in range(-b, b + 1):
+            for dc in range(-b, b + 1):
+                # pixel pairs (x, x + (dl, dc)) inside the image
+                r0, r1, c0, c1 = max(0, -dl), min(H, H - dl), max(0, -dc), min(W, W - dc)
+                if r0 >= r1 or c0 >= c1:
+                    continue
+                h1, h2 = hist[r0:r1, c0:c1], hist[r0 + dl:r1 + dl, c0 + dc:c1 + dc]
+                n1, n2 = n[r0:r1, c0:c1], n[r0 + dl:r1 + dl, c0 + dc:c1 + dc]
+                acc = np.zeros(n1.shape, np.float32)
+                nb = np.zeros(n1.shape, np.int32)
+                for k in range(D):                                       # pixelSummedHistogramDistance, bins in order
+                    b1, b2 = h1[..., k], h2[..., k]
+                    both = b1 + b2
+                    use = ~(both <= np.float32(1.0))                     # "if (b1 + b2 <= 1.f) continue;"
+                    diff = n2 * b1 - n1 * b2
+                    term = diff * diff / (n1 * n2 * both)
+                    acc = np.where(use, acc + term, acc)
+                    nb += use
+                t = np.full((H, W), np.nan, np.float32)
+                cn = np.zeros((H, W), np.int32)
+                t[r0:r1, c0:c1], cn[r0:r1, c0:c1] = acc, nb
+                # main pixels p whose partner q = p + (dl, dc) lies inside the window clipped to [w, dim - 1 - w] (DeepImage.hpp:181-196)
+                pl0, pl1, pc0, pc1 = max(w, w - dl), min(H - 1 - w, H - 1 - w - dl), max(w, w - dc), min(W - 1 - w, W - 1 - w - dc)
+                if pl0 > pl1 or pc0 > pc1:
+                    continue
+                summed = np.zeros((pl1 - pl0 + 1, pc1 - pc0 + 1), np.float32)
+                total = np.zeros(summed.shape, np.int32)
+                for a in range(-w, w + 1):                               # histogramPatchDistance: patch pixels row-major
+                    for d in range(-w, w + 1):
+                        summed = summed + t[pl0 + a:pl1 + a + 1, pc0 + d:pc1 + d + 1]
+                        total += cn[pl0 + a:pl1 + a + 1, pc0 + d:pc1 + d + 1]
+                out[pl0:pl1 + 1, pc0:pc1 + 1, (dl + b) * side + (dc + b)] = summed / total.astype(np.float32)
+    return out
+
+
+def _same_or_both_nan(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def _np32_similar_sets(ns, hist, w, b, tau):
+    """selectSimilarPatches (:196-219) for every main pixel from the transcription: (bit masks in the fixture's layout, counts)"""
+    dist = _np32_window_distances(ns, hist, w, b)
+    H, W, K = dist.shape
+    sim = dist <= np.float32(tau)                                        # :209 (NaN and the +inf outside the window: not similar)
+    sim[:w], sim[H - w:], sim[:, :w], sim[:, W - w:] = False, False, False, False
+    words = (K + 31) // 32
+    bits = np.zeros((H, W, words * 32), np.uint8)
+    bits[..., :K] = sim
+    mask = np.packbits(bits, axis=-1, bitorder="little").view(np.uint32).reshape(H, W, words)
+    return mask, sim.sum(axis=-1).astype(np.int32), dist
+
+
+@pytest.mark.parametrize("fixture,pts", [("core_regression.npz", None), ("core_lowspp.npz", [(1, 1), (7, 11), (14, 22)])])
+def test_float32_numpy_transcription_of_the_patch_distance_equals_the_oracle_bit_for_bit(fixture, pts):
+    """a10 gets a second reading: the NumPy-float32 transcription of DenoisingUnit.cpp:336-386 above against the C oracle --
+    every distance of every main pixel's window bit for bit (NaNs at the same places), the scalar loop nest on the fixture's pixels, and the
+    similar sets / counts of selectSimilarPatches against the fixture's masks.  40 x 28 at 8 spp and the 24 x 16 frame at 1 spp (0 / 0 -> NaN)."""
+    f = load(fixture)
+    ns, hist = f["ns"], f["hist"]
+    H, W, _ = hist.shape
+    w, b, side = 1, 6, 13
+    mask, cnt, dist = _np32_similar_sets(ns, hist, w, b, 1.0)
+    for l in range(w, H - w):
+        for c in range(w, W - w):
+            assert _same_or_both_nan(dist[l, c], ol.window_distances(ns, hist, w, b, l, c)), (l, c)
+    assert np.array_equal(mask, f["mask"]) and np.array_equal(cnt, f["cnt"])
+    pts = [tuple(int(v) for v in p) for p in (f["pts"] if pts is None else pts)]
+    for i, (l, c) in enumerate(pts):                                     # the literal loop nest, on a few main pixels
+        if "pts" in f.files:
+            assert _same_or_both_nan(dist[l, c], f["dist"][i])
+        for k in range(side * side):
+            ql, qc = l + k // side - b, c + k % side - b
+            if w <= ql <= H - 1 - w and w <= qc <= W - 1 - w:
+                assert _same_or_both_nan(_np32_patch_distance_scalar(ns, hist, w, (l, c), (ql, qc)), dist[l, c, k]), (l, c, k)
+            else:
+                assert np.isinf(dist[l, c, k])
+    if fixture == "core_lowspp.npz":
+        assert np.isnan(dist[np.isfinite(dist) | np.isnan(dist)]).any()   # the NaN semantics are exercised
+
+
 def test_float64_numpy_restatement_of_the_bayesian_steps_agrees_with_the_oracle():
     """Independent cross-check of the unpinned core (a11-a16): a float64 NumPy restatement written from the reference source
     (/root/reference/src/core/DenoisingUnit.cpp:400-481 and 483-693, Denoiser.cpp:357-373,434-470) -- not from oracle/bcd_oracle.c --
     with numpy.linalg.eigh in place of Eigen's solver, run on every main pixel of the 40 x 28 regression frame (-m 0) with the similar
-    sets of the fixture, must reproduce the oracle's fp32 image.  It does not pin the oracle to the reference (nothing can without
+    sets of the float32 transcription of a10 above (its own reading end to end), must reproduce the oracle's fp32 image.  It does not pin the oracle to the reference (nothing can without
     Eigen) but removes "single author, single reading" of the two Bayesian steps as a failure mode."""
     f = load("core_regression.npz")
-    col, ns, cov, mask, want = f["col"].astype(np.float64), f["ns"].astype(np.float64), f["cov"].astype(np.float64), f["mask"], f["out_m0"]
+    # (round 6) the similar sets come from the independent float32 transcription of the patch distance above, not from the oracle's masks
+    mask, _, _ = _np32_similar_sets(f["ns"], f["hist"], 1, 6, 1.0)
+    col, ns, cov, want = f["col"].astype(np.float64), f["ns"].astype(np.float64), f["cov"].astype(np.float64), f["out_m0"]
     H, W, _ = col.shape
     b, w, min_eig = 6, 1, 1e-8
     side = 2 * b + 1
