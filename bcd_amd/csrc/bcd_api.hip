@@ -64,14 +64,14 @@ hipError_t bcd_launch_active_init(const int32_t *, int, int, int, int, int, floa
 hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *, int, int, int, int, int, uint32_t, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_mark_deps(const uint32_t *, const int32_t *, uint8_t *, uint32_t *, int, int, int, int, int, uint32_t, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_mark_round(const uint32_t *, uint8_t *, int, int, int, int, int, int, int *, hipStream_t);
-hipError_t bcd_launch_sum_counter_lines(const int *, int, int *, hipStream_t);
+hipError_t bcd_launch_sum_counter_lines(const int *, int, int *, hipStream_t, long long * = nullptr, const int * = nullptr, int = 0);
 hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
-hipError_t bcd_launch_jacobi27_batch(const float *, int, int *, int, float *, float *, hipStream_t, float = 1e-12f, float * = nullptr);
+hipError_t bcd_launch_jacobi27_batch(const float *, int, int *, int, float *, float *, hipStream_t, float = 1e-12f, float * = nullptr, const int * = nullptr, int = 0);
 size_t bcd_bayes_lds_bytes(int w, int b);
 size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
 size_t bcd_bayes27_record_bytes();
 hipError_t bcd_launch_bayes27(const float *, const float *, const uint32_t *, const int32_t *, int, int, int *, int, int, int, int, float, float *, float *,
-                              int32_t *, int *, hipStream_t, int);
+                              int32_t *, int *, hipStream_t, int, const int *d_nb_items);
 hipError_t bcd_launch_bayes27_redo(const float *, const float *, const uint32_t *, const int32_t *, int, int, int *, int, int, int, int, float, float *, float *,
                                    int32_t *, hipStream_t);
 hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t *, const int32_t *, const int32_t *, int *, int, int, int, int,
@@ -101,6 +101,7 @@ struct Work {
     DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, cnt_lines, work_q, pixcov, sum, cnt, gscratch, dep, tmp_lo, border; // grow-only
     int border_capacity = 0;       // entries of `border` offered to the last fast similarity pass (0: the exact kernels ran)
     int rounds_hint = 0;           // marking launches the last problem needed
+    int last_batch = 0;            // launches of the batch active_step_enqueue left in flight
     bool dep_ready = false;        // dependency lists of the current marking problem are in `dep` (reset by active_init)
     const void *dep_mask = nullptr, *dep_state = nullptr; // ... extracted for these buffers (another problem on the same context rebuilds them)
     int32_t *h_counters = nullptr; // pinned
@@ -113,6 +114,10 @@ struct Work {
     hipStream_t aux = nullptr;     // side stream: the fallback-pixel kernel runs beside the (latency-bound) full estimate kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_pixcov = nullptr; // the per-pixel covariances (side stream, beside the distance kernel) are complete
+    hipEvent_t ev_counts = nullptr; // the list lengths of bayes() are on the host
+    // (round 6) full-estimate items of the last frame of this geometry on this workspace: the next frame's first chunk of estimate kernels is launched for
+    // that many (+ 1/8) BEFORE the host knows the new count
+    int strong_hint = 0, strong_hint_W = 0, strong_hint_H = 0;
     // approximate distance planes computed ahead of similarity() by a caller that streams the frame in (bcd_hip_denoise_host_ex): valid for
     // exactly this problem; similarity() consumes the note
     struct { bool ready = false; const float *hist = nullptr, *ns = nullptr; int W = 0, H = 0, D = 0, b = 0; float tau = 0.f, uni_n = 0.f; } planes;
@@ -438,11 +443,13 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
 }
 
 // one batch of marking launches on lines [row_begin, row_end); *undecided_out = pixels of those lines still undecided
-int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
-                int row_end, int random_order, uint32_t seed, int row_offset, bool first_pass, uint8_t *d_state, int *undecided_out,
-                int *launches_out)
+// Two halves (round 6): active_step_enqueue launches the batch and the copy of its counters WITHOUT waiting -- with `d_total` it also leaves the rank's
+// contribution to the all-reduced count on the device (k_sum_counter_lines; `with_verdict`: + 2^40 when this workspace's last similarity pass has to be
+// repeated), so that the band driver's all-reduce follows in stream order and one synchronisation serves both; active_step_collect reads the counters
+// after the caller's synchronisation.
+int active_step_enqueue(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
+                        int row_end, int random_order, uint32_t seed, int row_offset, uint8_t *d_state, long long *d_total, bool with_verdict)
 {
-    (void)first_pass; // a hint of the C ABI ("every pixel is still undecided"); the dependency-list kernels do not need it
     const int K = 3 * (2 * w + 1) * (2 * w + 1);
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int *d_cnt = (int *)wk.counters.p;
@@ -485,14 +492,31 @@ int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_
             HIPCHK(ctx, bcd_launch_active_round(d_mask, d_nsim, d_state, W, H, b, K + 1, random_order, seed, row_begin, row_end, row_offset,
                                                 d_lines + LINE_INTS * i, wk.stream));
     }
-    HIPCHK(ctx, bcd_launch_sum_counter_lines(d_lines, batch, d_cnt, wk.stream));
+    HIPCHK(ctx, bcd_launch_sum_counter_lines(d_lines, batch, d_cnt, wk.stream, d_total, with_verdict ? (const int *)wk.counters.p + 40 : nullptr, wk.border_capacity));
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters, d_cnt, ROUND_BATCH * sizeof(int), hipMemcpyDeviceToHost, wk.stream));
-    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    wk.last_batch = batch;
+    return BCD_HIP_OK;
+}
+
+void active_step_collect(Work &wk, int *undecided_out, int *launches_out)
+{
+    const int batch = wk.last_batch;
     int n = batch;
     for (int i = 0; i < batch; ++i)
         if (wk.h_counters[i] == 0) { n = i + 1; break; }
     *undecided_out = wk.h_counters[n - 1];
     if (launches_out) *launches_out = n;
+}
+
+// one batch of marking launches on lines [row_begin, row_end); *undecided_out = pixels of those lines still undecided
+int active_step(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t *d_nsim, int W, int H, int w, int b, int row_begin,
+                int row_end, int random_order, uint32_t seed, int row_offset, bool first_pass, uint8_t *d_state, int *undecided_out,
+                int *launches_out)
+{
+    (void)first_pass; // a hint of the C ABI ("every pixel is still undecided"); the dependency-list kernels do not need it
+    RCCHK(active_step_enqueue(ctx, wk, d_mask, d_nsim, W, H, w, b, row_begin, row_end, random_order, seed, row_offset, d_state, nullptr, false));
+    HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+    active_step_collect(wk, undecided_out, launches_out);
     return BCD_HIP_OK;
 }
 
@@ -572,21 +596,47 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
         HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
     }
     if (w == 1) {
-        HIPCHK(ctx, hipStreamSynchronize(wk.stream));
-        const int n_strong = wk.h_counters[16];
         const size_t rec = bcd_bayes27_record_bytes();
         const int chunk_max = 1 << 17; // 131072 pixels = 1.3 GB of records
-        if (n_strong > 0) RCCHK(ensure(ctx, wk.gscratch, rec * (size_t)std::min(n_strong, chunk_max)));
         RCCHK(ensure(ctx, wk.work_q, BCD_WORK_INTS * sizeof(int32_t)));
-        for (int first = 0; first < n_strong; first += chunk_max) {
-            const int n = std::min(chunk_max, n_strong - first);
+        auto launch_chunk = [&](int first, int n, bool defer, const int *d_n) -> int {
             if (wk.clean_wq) wk.clean_wq = false; // (k_scale_begin)
             else HIPCHK(ctx, hipMemsetAsync(wk.work_q.p, 0, BCD_WORK_INTS * sizeof(int32_t), wk.stream)); // the work queues of the three kernels
-            // one chunk (the usual case) and a caller that looks at the redo counter after its last synchronisation: the redo kernel waits for that
-            const bool defer = defer_redo && n_strong <= chunk_max;
             HIPCHK(ctx, bcd_launch_bayes27(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, first, n, (int *)wk.work_q.p, cus, W, H, b, min_eig,
-                                           (float *)wk.gscratch.p, d_sum, d_count, d_c + 7, wk.stream, defer ? 1 : 0));
-            if (defer) { wk.redo.pending = true; wk.redo.first = first; wk.redo.n = n; wk.redo.cus = cus; } // (the counter is h_counters[23], below)
+                                           (float *)wk.gscratch.p, d_sum, d_count, d_c + 7, wk.stream, defer ? 1 : 0, d_n));
+            return BCD_HIP_OK;
+        };
+        // Round 6: the first chunk does not wait for the host.  The list's length is on its way back (the copy above), the previous frame of this
+        // geometry on this workspace said how many items to expect: the three kernels are launched for that many + 1/8 with the length read on the
+        // DEVICE (records sized for the capacity; wavefronts without an item leave at once), the host waits for the COPY only -- while the prepare
+        // kernel is already running -- and launches further chunks for whatever the capacity did not cover.  A first frame, a workspace whose last
+        // frame had (next to) no full estimates, and lists beyond one chunk take the synchronous path below.
+        int ahead = 0;
+        HIPCHK(ctx, hipEventRecord(wk.ev_counts, wk.stream));
+        if (wk.strong_hint_W == W && wk.strong_hint_H == H && wk.strong_hint >= 512 && wk.strong_hint + wk.strong_hint / 8 + 1024 <= chunk_max) {
+            ahead = wk.strong_hint + wk.strong_hint / 8 + 1024;
+            RCCHK(ensure(ctx, wk.gscratch, rec * (size_t)ahead));
+            RCCHK(launch_chunk(0, ahead, defer_redo, d_c));
+        }
+        HIPCHK(ctx, hipEventSynchronize(wk.ev_counts));
+        const int n_strong = wk.h_counters[16];
+        wk.strong_hint = n_strong; wk.strong_hint_W = W; wk.strong_hint_H = H;
+        if (ahead > 0 && n_strong <= ahead) {
+            if (defer_redo) { wk.redo.pending = true; wk.redo.first = 0; wk.redo.n = ahead; wk.redo.cus = cus; } // (the counter is h_counters[23], below)
+        } else {
+            if (ahead > 0 && defer_redo) // the first chunk's records are about to be reused: its redo list (normally empty) is walked now
+                HIPCHK(ctx, bcd_launch_bayes27_redo(d_colors, d_pixcov, d_mask, (const int32_t *)wk.strong.p, 0, ahead, (int *)wk.work_q.p, cus, W, H, b, min_eig,
+                                                    (float *)wk.gscratch.p, d_sum, d_count, wk.stream));
+            const int remaining = n_strong - ahead;
+            if (remaining > 0 && ahead == 0) RCCHK(ensure(ctx, wk.gscratch, rec * (size_t)std::min(remaining, chunk_max)));
+            const int chunk = ahead > 0 ? ahead : chunk_max; // (the records of a first chunk launched ahead are laid out for `ahead` items)
+            for (int first = ahead; first < n_strong; first += chunk) {
+                const int n = std::min(chunk, n_strong - first);
+                // one chunk (the usual case) and a caller that looks at the redo counter after its last synchronisation: the redo kernel waits for that
+                const bool defer = defer_redo && ahead == 0 && n_strong <= chunk_max;
+                RCCHK(launch_chunk(first, n, defer, nullptr));
+                if (defer) { wk.redo.pending = true; wk.redo.first = first; wk.redo.n = n; wk.redo.cus = cus; }
+            }
         }
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 23, d_c + 7, sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream)); // read after the scale's last synchronisation
     } else {
@@ -749,6 +799,7 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_pixcov, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_counts, hipEventDisableTiming));
     w.initialised = true;
     return BCD_HIP_OK;
 }
@@ -765,6 +816,7 @@ void work_destroy(Work &w)
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
     if (w.ev_join) (void)hipEventDestroy(w.ev_join);
     if (w.ev_pixcov) (void)hipEventDestroy(w.ev_pixcov);
+    if (w.ev_counts) (void)hipEventDestroy(w.ev_counts);
     if (w.aux) (void)hipStreamDestroy(w.aux);
     if (w.owns_stream && w.stream) (void)hipStreamDestroy(w.stream);
 }
@@ -1366,6 +1418,26 @@ int bcd_hip_active_step(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t 
     RCCHK(active_step(ctx, ctx->main, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, random_order, seed, row_offset, first_pass != 0,
                       d_state, &u, nullptr));
     *undecided = u;
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_active_step_enqueue(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_count, int W, int H, int w, int b, int main_row_begin,
+                                int main_row_end, int random_order, uint32_t seed, int row_offset, uint8_t *d_state, int64_t *d_total, int with_verdict)
+{
+    if (!ctx || !d_mask || !d_count || !d_state) return bad(ctx, "bad argument");
+    DEVICE_GUARD(ctx);
+    static_assert(sizeof(long long) == sizeof(int64_t), "64-bit counters");
+    return active_step_enqueue(ctx, ctx->main, d_mask, d_count, W, H, w, b, main_row_begin, main_row_end, random_order, seed, row_offset, d_state,
+                               reinterpret_cast<long long *>(d_total), with_verdict != 0);
+}
+
+int bcd_hip_active_step_collect(bcd_hip_ctx *ctx, int32_t *undecided, int32_t *launches)
+{
+    if (!ctx || !undecided) return BCD_HIP_EINVAL;
+    int u = 0, n = 0;
+    active_step_collect(ctx->main, &u, &n);
+    *undecided = u;
+    if (launches) *launches = n;
     return BCD_HIP_OK;
 }
 

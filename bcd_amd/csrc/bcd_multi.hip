@@ -216,7 +216,9 @@ struct bcd_hip_multi {
     enum { IN_COL, IN_NS, IN_HIST, IN_COV, OUT, PIXCOV, MASK, NSIM, STATE, SUM, CNT, RX_UP_S, RX_UP_C, RX_DN_S, RX_DN_C, NBUF };
     DBuf buf[MAX_RANKS][MAX_S][NBUF];
     long long *d_red[MAX_RANKS][MAX_S + 1]; // all-reduce scratch (RCCL transport)
+    long long *h_red[MAX_RANKS][MAX_S + 1]; // ... and where its result lands (pinned)
     hipEvent_t ev_level[MAX_RANKS][MAX_S]; // pyramid level s of the rank is complete (recorded on the rank's tail stream)
+    hipEvent_t ev_tail[MAX_RANKS];         // the finest scale's last kernel of the frame (recorded on its stream; the merges wait for it)
     bcd_hip_multi_stats stats;
     // communication trace of the last frame (bcd_hip_multi_set_comm_trace): per rank, in the order the rank ENQUEUED its operations,
     // (channel, kind, bytes to / from the rank above, bytes to / from the rank below).  Lets a test check on one GPU what decides
@@ -482,6 +484,25 @@ bool allreduce(bcd_hip_multi *m, int rank, int ch, long long *value)
     return true;
 }
 
+// RCCL transport: the rank's contribution is already in d_red[rank][ch], produced on the channel's stream (bcd_hip_active_step_enqueue); the sum over
+// all ranks comes back with ONE synchronisation of that stream
+bool allreduce_device(bcd_hip_multi *m, int rank, int ch, long long *value)
+{
+    trace_op(m, rank, ch, 1, 0, 0);
+    hipStream_t st = m->stream[rank][ch];
+    ncclResult_t r;
+    {
+        std::shared_lock<std::shared_timed_mutex> enq(m->comm_rw);
+        if (!m->comm_ready[ch] || m->abort_flag.load()) return false;
+        r = ncclAllReduce(m->d_red[rank][ch], m->d_red[rank][ch], 1, ncclInt64, ncclSum, m->comm[ch][rank], st);
+    }
+    if (r != ncclSuccess) { fail(m, std::string("RCCL all-reduce failed: ") + ncclGetErrorString(r)); return false; }
+    MCHK(m, rank, hipMemcpyAsync(m->h_red[rank][ch], m->d_red[rank][ch], sizeof(long long), hipMemcpyDeviceToHost, st));
+    MCHK(m, rank, hipStreamSynchronize(st));
+    *value = *m->h_red[rank][ch];
+    return true;
+}
+
 struct Job {
     bcd_hip_multi *m;
     const float *h_col, *h_ns, *h_hist, *h_cov;
@@ -492,7 +513,9 @@ struct Job {
 };
 
 // ---- one scale of one rank: masks, frame-ordered marking, estimate, accumulator halos, finalisation -----------------------
-bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
+// defer_sync (the finest scale of a multiscale frame, round 6): the scale's last kernel is followed by ev_tail[rank] instead of a host synchronisation --
+// the caller enqueues the merges behind that event and waits once, at the end of the frame
+bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool defer_sync = false)
 {
     bcd_hip_multi *m = job.m;
     if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
@@ -575,18 +598,32 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
             for (;;) {
                 if (talk && !exchange(m, rank, s, state + (size_t)r0 * W, up ? state + (size_t)(r0 - b) * W : nullptr, (size_t)b * W,
                                              state + (size_t)(r1 - b) * W, down ? state + (size_t)r1 * W : nullptr, (size_t)b * W)) return false;
-                int32_t undecided = 0;
-                ECHK(m, rank, c, bcd_hip_active_step(c, mask, nsim, W, rows, w, b, r0, r1, job.prm.use_random_pixel_order, seed, row_offset,
-                                                      rounds == 0 && job.prm.marked_skip_probability >= 1.f, state, &undecided));
-                ++rounds;
-                long long total = undecided;
-                if (!verdict_known) { // the batch synchronised the stream: the flags of the masks are on the host
-                    int redo = 0;
-                    ECHK(m, rank, c, bcd_hip_similarity_masks_verdict(c, &redo));
-                    my_redo = redo != 0;
-                    if (my_redo) total += REDO;
+                // Round 6: one synchronisation per batch instead of two.  The batch leaves the rank's contribution (undecided pixels, + REDO when its
+                // masks are not valid: the same test on the device) in the all-reduce buffer, the all-reduce and the copy of its result follow in stream
+                // order, and the host waits once.
+                long long total = 0;
+                if (talk && m->use_rccl) {
+                    ECHK(m, rank, c, bcd_hip_active_step_enqueue(c, mask, nsim, W, rows, w, b, r0, r1, job.prm.use_random_pixel_order, seed, row_offset, state,
+                                                                 reinterpret_cast<int64_t *>(m->d_red[rank][s]), verdict_known ? 0 : 1));
+                    if (!allreduce_device(m, rank, s, &total)) return false; // (synchronises the scale's stream)
+                    int32_t undecided = 0;
+                    ECHK(m, rank, c, bcd_hip_active_step_collect(c, &undecided, nullptr));
+                    if (!verdict_known) { int redo = 0; ECHK(m, rank, c, bcd_hip_similarity_masks_verdict(c, &redo)); my_redo = redo != 0; }
+                    ++rounds;
+                } else {
+                    int32_t undecided = 0;
+                    ECHK(m, rank, c, bcd_hip_active_step(c, mask, nsim, W, rows, w, b, r0, r1, job.prm.use_random_pixel_order, seed, row_offset,
+                                                          rounds == 0 && job.prm.marked_skip_probability >= 1.f, state, &undecided));
+                    ++rounds;
+                    total = undecided;
+                    if (!verdict_known) { // the batch synchronised the stream: the flags of the masks are on the host
+                        int redo = 0;
+                        ECHK(m, rank, c, bcd_hip_similarity_masks_verdict(c, &redo));
+                        my_redo = redo != 0;
+                        if (my_redo) total += REDO;
+                    }
+                    if (talk && !allreduce(m, rank, s, &total)) return false;
                 }
-                if (talk && !allreduce(m, rank, s, &total)) return false;
                 if (!verdict_known) {
                     verdict_known = true;
                     if (total >= REDO) { restart = true; break; }
@@ -618,9 +655,10 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands)
     float *out = (float *)B(bcd_hip_multi::OUT).p;
     ECHK(m, rank, c, bcd_hip_finalize_band(c, sum + (size_t)r0 * W * 3, cnt + (size_t)r0 * W, W, r1 - r0, halo, up ? rx_us : nullptr, up ? rx_uc : nullptr,
                                            down ? rx_ds : nullptr, down ? rx_dc : nullptr, out + (size_t)o0 * W * 3));
+    if (rank == 0) m->stats.marking_rounds[s] = rounds;
+    if (defer_sync) { MCHK(m, rank, hipEventRecord(m->ev_tail[rank], st)); return true; } // (the caller reports the progress after its own synchronisation)
     MCHK(m, rank, hipStreamSynchronize(st));
     progress_add(m, 0.5 * (double)(r1 - r0) * W);
-    if (rank == 0) m->stats.marking_rounds[s] = rounds;
     return true;
 }
 
@@ -663,32 +701,47 @@ bool rank_compute(const Job &job, int rank)
     bcd_hip_ctx *cm = m->ctx[rank][S];
     hipStream_t sm = m->stream[rank][S];
     auto B = [&](int s, int kind) -> DBuf & { return m->buf[rank][s][kind]; };
-    // ---- local pyramid (MultiscaleDenoiser.cpp:41-53)
-    for (int s = 1; s < S; ++s) {
-        const ScaleBand &prev = bands[s - 1], &cur = bands[s];
-        const int a = 2 * cur.loc0 - prev.loc0, rows = 2 * (cur.loc1 - cur.loc0);
-        const float *pc = (const float *)B(s - 1, bcd_hip_multi::IN_COL).p + (size_t)a * prev.W * 3;
-        const float *pn = (const float *)B(s - 1, bcd_hip_multi::IN_NS).p + (size_t)a * prev.W;
-        const float *ph = (const float *)B(s - 1, bcd_hip_multi::IN_HIST).p + (size_t)a * prev.W * D;
-        const float *pv = (const float *)B(s - 1, bcd_hip_multi::IN_COV).p + (size_t)a * prev.W * 6;
-        ECHK(m, rank, cm, bcd_hip_downscale_avg(cm, pc, prev.W, rows, 3, (float *)B(s, bcd_hip_multi::IN_COL).p));
-        ECHK(m, rank, cm, bcd_hip_downscale_sum(cm, pn, prev.W, rows, 1, (float *)B(s, bcd_hip_multi::IN_NS).p));
-        ECHK(m, rank, cm, bcd_hip_downscale_sum(cm, ph, prev.W, rows, D, (float *)B(s, bcd_hip_multi::IN_HIST).p));
-        ECHK(m, rank, cm, bcd_hip_downscale_cov(cm, pv, pn, prev.W, rows, (float *)B(s, bcd_hip_multi::IN_COV).p));
-        MCHK(m, rank, hipEventRecord(m->ev_level[rank][s], sm)); // scale s starts when its level is there; the finest scale at once
-    }
-    // ---- the scales are independent until the merges: one thread, stream and context each
-    {
-        std::vector<std::thread> th;
-        std::vector<char> ok(S, 1);
-        m->gate[rank].reset();
-        for (int s = 1; s < S; ++s) th.emplace_back([&, s]() { ok[s] = scale_worker(job, rank, s, bands) ? 1 : 0; });
-        ok[0] = scale_worker(job, rank, 0, bands) ? 1 : 0;
-        for (auto &t : th) t.join();
+    // ---- the scales are independent until the merges: one thread, stream and context each.  The finest scale needs no pyramid level and is the critical
+    // path of the band: it runs in THIS thread and starts at once (round 6: it used to start behind the enqueue of the eight pyramid kernels and the
+    // creation of the other threads -- 0.1 ms of a 2.9 ms band step; the single-GPU call has always started its distance kernel beside the pyramid).  A
+    // helper thread enqueues the pyramid and starts a coarse scale's thread as soon as that scale's level is recorded.
+    std::vector<char> ok(S, 1);
+    bool pyramid_ok = true;
+    m->gate[rank].reset();
+    auto coarse = [&]() -> bool {
         if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
-        for (int s = 0; s < S; ++s)
-            if (!ok[s]) { m->abort_flag.store(true); return false; }
+        std::vector<std::thread> th;
+        struct Join { std::vector<std::thread> &th; ~Join() { for (auto &t : th) t.join(); } } join{ th };
+        // ---- local pyramid (MultiscaleDenoiser.cpp:41-53)
+        for (int s = 1; s < S; ++s) {
+            const ScaleBand &prev = bands[s - 1], &cur = bands[s];
+            const int a = 2 * cur.loc0 - prev.loc0, rows = 2 * (cur.loc1 - cur.loc0);
+            const float *pc = (const float *)B(s - 1, bcd_hip_multi::IN_COL).p + (size_t)a * prev.W * 3;
+            const float *pn = (const float *)B(s - 1, bcd_hip_multi::IN_NS).p + (size_t)a * prev.W;
+            const float *ph = (const float *)B(s - 1, bcd_hip_multi::IN_HIST).p + (size_t)a * prev.W * D;
+            const float *pv = (const float *)B(s - 1, bcd_hip_multi::IN_COV).p + (size_t)a * prev.W * 6;
+            ECHK(m, rank, cm, bcd_hip_downscale_avg(cm, pc, prev.W, rows, 3, (float *)B(s, bcd_hip_multi::IN_COL).p));
+            ECHK(m, rank, cm, bcd_hip_downscale_sum(cm, pn, prev.W, rows, 1, (float *)B(s, bcd_hip_multi::IN_NS).p));
+            ECHK(m, rank, cm, bcd_hip_downscale_sum(cm, ph, prev.W, rows, D, (float *)B(s, bcd_hip_multi::IN_HIST).p));
+            ECHK(m, rank, cm, bcd_hip_downscale_cov(cm, pv, pn, prev.W, rows, (float *)B(s, bcd_hip_multi::IN_COV).p));
+            MCHK(m, rank, hipEventRecord(m->ev_level[rank][s], sm)); // scale s starts when its level is there
+            // (the event is recorded before the scale's thread exists: its hipStreamWaitEvent sees this frame's record)
+            th.emplace_back([&, s]() { ok[s] = scale_worker(job, rank, s, bands) ? 1 : 0; });
+        }
+        return true; // (the coarse scales' threads are joined on the way out; each has synchronised its stream)
+    };
+    {
+        std::thread helper;
+        if (S > 1) helper = std::thread([&]() { pyramid_ok = coarse(); });
+        ok[0] = scale_worker(job, rank, 0, bands, S > 1) ? 1 : 0;
+        if (helper.joinable()) helper.join();
     }
+    if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
+    if (!pyramid_ok) return false; // (fail() has raised the abort flag: every scale thread came back)
+    for (int s = 0; s < S; ++s)
+        if (!ok[s]) { m->abort_flag.store(true); return false; }
+    // the merges follow the finest scale's last kernel in stream order (the coarse scales have synchronised their streams)
+    if (S > 1) MCHK(m, rank, hipStreamWaitEvent(sm, m->ev_tail[rank], 0));
     // ---- two lines of every unmerged finer output (hi - up(down(hi)) at the band edge), one line of the coarsest (up(lo))
     auto out_rows = [&](int s, int local_line) { return (float *)B(s, bcd_hip_multi::OUT).p + (size_t)local_line * bands[s].W * 3; };
     const bool talk = g.world > 1 || m->loopback;
@@ -714,6 +767,7 @@ bool rank_compute(const Job &job, int rank)
         }
     }
     MCHK(m, rank, hipStreamSynchronize(sm));
+    if (S > 1) progress_add(m, 0.5 * (double)(bands[0].own1 - bands[0].own0) * bands[0].W); // (the finest scale's estimate: its worker did not wait for it)
     return true;
 }
 
@@ -752,12 +806,13 @@ int prepare(bcd_hip_multi *m, int S)
     for (int r = 0; r < m->n; ++r) {
         if (m->local_rank >= 0 && r != m->local_rank) continue;
         if (hipSetDevice(m->devices[r]) != hipSuccess) { fail(m, "hipSetDevice failed"); return BCD_HIP_EDEVICE; }
+        if (!m->ev_tail[r] && hipEventCreateWithFlags(&m->ev_tail[r], hipEventDisableTiming) != hipSuccess) { fail(m, "hipEventCreate failed"); return BCD_HIP_EDEVICE; }
         for (int c = 0; c <= S; ++c) {
             if (c < S && !m->ev_level[r][c] && hipEventCreateWithFlags(&m->ev_level[r][c], hipEventDisableTiming) != hipSuccess) { fail(m, "hipEventCreate failed"); return BCD_HIP_EDEVICE; }
             if (m->ctx[r][c]) continue;
             if (hipStreamCreateWithFlags(&m->stream[r][c], hipStreamNonBlocking) != hipSuccess ||
                 bcd_hip_ctx_create(&m->ctx[r][c], m->devices[r], m->stream[r][c]) != BCD_HIP_OK) { fail(m, "cannot create an engine context"); return BCD_HIP_EDEVICE; }
-            if (m->use_rccl && hipMalloc((void **)&m->d_red[r][c], 64) != hipSuccess) { fail(m, "hipMalloc failed"); return BCD_HIP_ENOMEM; }
+            if (m->use_rccl && (hipMalloc((void **)&m->d_red[r][c], 64) != hipSuccess || hipHostMalloc((void **)&m->h_red[r][c], 64, hipHostMallocDefault) != hipSuccess)) { fail(m, "hipMalloc failed"); return BCD_HIP_ENOMEM; }
         }
     }
     if (m->use_rccl && (m->n > 1 || m->loopback))
@@ -837,7 +892,9 @@ int bcd_hip_multi_create(bcd_hip_multi **out, const int *devices, int n_ranks)
     memset(m->ctx, 0, sizeof(m->ctx));
     memset(m->stream, 0, sizeof(m->stream));
     memset(m->d_red, 0, sizeof(m->d_red));
+    memset(m->h_red, 0, sizeof(m->h_red));
     memset(m->ev_level, 0, sizeof(m->ev_level));
+    memset(m->ev_tail, 0, sizeof(m->ev_tail));
     memset(m->comm_ready, 0, sizeof(m->comm_ready));
     memset(&m->stats, 0, sizeof(m->stats));
     for (int c = 0; c <= MAX_S; ++c) { m->barrier[c].parties = n_ranks; m->barrier[c].abort_flag = &m->abort_flag; }
@@ -870,8 +927,10 @@ void bcd_hip_multi_destroy(bcd_hip_multi *m)
         (void)hipSetDevice(m->devices[r]);
         for (int s = 0; s < MAX_S; ++s)
             for (int k = 0; k < bcd_hip_multi::NBUF; ++k) m->buf[r][s][k].release();
+        if (m->ev_tail[r]) (void)hipEventDestroy(m->ev_tail[r]);
         for (int c = 0; c <= MAX_S; ++c) {
             if (m->d_red[r][c]) (void)hipFree(m->d_red[r][c]);
+            if (m->h_red[r][c]) (void)hipHostFree(m->h_red[r][c]);
             if (m->ctx[r][c]) bcd_hip_ctx_destroy(m->ctx[r][c]);
             if (m->stream[r][c]) (void)hipStreamDestroy(m->stream[r][c]);
             if (c < MAX_S && m->ev_level[r][c]) (void)hipEventDestroy(m->ev_level[r][c]);

@@ -19,12 +19,22 @@ constexpr int LISTS_PER_THREAD = 8;
 // a 1080p scale has 8 160 tiles: 0.13 ms for k_mark_deps alone was the counter, not the kernel (r3).
 __device__ inline int *counter_line(int *base) { return base + ((blockIdx.x + 5 * blockIdx.y) & (BCD_CNT_LINES - 1)) * BCD_CNT_STRIDE; }
 
-__global__ void k_sum_counter_lines(const int *__restrict__ lines, int rounds, int *__restrict__ out)
+// total_out (optional; round 6, the band driver): what the rank contributes to the all-reduced count of undecided pixels, left on the DEVICE for
+// ncclAllReduce -- the count after the batch's last launch, plus 2^40 when `flags` (the validity words of the similarity kernels: [0] range / count
+// flag, [2] another sample count, [3] borderline pairs against `border_capacity`; same test as similarity_redo_mode in bcd_api.hip) say that
+// this rank's masks have to be recomputed
+__global__ void k_sum_counter_lines(const int *__restrict__ lines, int rounds, int *__restrict__ out, long long *__restrict__ total_out,
+                                    const int *__restrict__ flags, int border_capacity)
 {
     const int r = blockIdx.x, t = threadIdx.x; // one wavefront per round
     int v = t < BCD_CNT_LINES ? lines[((size_t)r * BCD_CNT_LINES + t) * BCD_CNT_STRIDE] : 0;
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     if (t == 0 && r < rounds) out[r] = v;
+    if (t == 0 && r == rounds - 1 && total_out) {
+        long long tot = v;
+        if (flags && (flags[0] != 0 || (border_capacity > 0 && (flags[2] != 0 || flags[3] > border_capacity)))) tot += 1ll << 40;
+        *total_out = tot;
+    }
 }
 
 
@@ -365,10 +375,10 @@ hipError_t bcd_launch_active_lists(const uint8_t *state, const int32_t *nsim, in
     return hipGetLastError();
 }
 
-hipError_t bcd_launch_sum_counter_lines(const int *lines, int rounds, int *out, hipStream_t st)
+hipError_t bcd_launch_sum_counter_lines(const int *lines, int rounds, int *out, hipStream_t st, long long *total_out, const int *flags, int border_capacity)
 {
     if (rounds <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sum_counter_lines, dim3(rounds), dim3(64), 0, st, lines, rounds, out);
+    hipLaunchKernelGGL(k_sum_counter_lines, dim3(rounds), dim3(64), 0, st, lines, rounds, out, total_out, flags, border_capacity);
     return hipGetLastError();
 }
 

@@ -99,6 +99,13 @@ __device__ inline int work_next(int *work, int nb_items, int lane, WorkCursor &c
     return -1;
 }
 
+// Round 6: the host launches the estimate kernels of a chunk BEFORE it knows how many items the list holds (the count is still on its way back:
+// bayes() in bcd_api.hip); `d_n` then points at the list's length on the device and `nb_items` is the capacity the records were sized for.
+__device__ inline int items_on_device(const int *d_n, int first_item, int nb_items)
+{
+    return d_n ? max(0, min(nb_items, *d_n - first_item)) : nb_items;
+}
+
 __device__ inline int noise_idx(int i, int j)
 {
     // 3x3 symmetric block from xx,yy,zz,yz,xz,xy
@@ -173,8 +180,10 @@ template <bool PAD> __device__ inline int jrow_t(int r) { return (PAD && r == 8)
 template <bool PAD, bool FUSE>
 __global__ __launch_bounds__(64, 3) void k_jacobi27_batch(const float *Ain, int n, int *work,
                                                           float *__restrict__ eig, float *__restrict__ Vout,
-                                                          float conv2 /* stop at off^2 <= conv2 diag^2 */, float *Aout /* optional (may be Ain): the matrix as the sweeps left it, V^T A V */)
+                                                          float conv2 /* stop at off^2 <= conv2 diag^2 */, float *Aout /* optional (may be Ain): the matrix as the sweeps left it, V^T A V */,
+                                                          const int *d_n, int first_item)
 {
+    n = items_on_device(d_n, first_item, n);
     auto jrow = [](int r) { return jrow_t<PAD>(r); };
     __shared__ float4 lds4[(2 * JMAT + 4 * KP) / 4];
     float *Abuf = reinterpret_cast<float *>(lds4);
@@ -536,8 +545,9 @@ __device__ __forceinline__ void jacobi_super_round(float (&vrow)[JLD], float *sr
 }
 
 __global__ __launch_bounds__(64, 3) void k_jacobi27_quads(const float *Ain, int n, int *work, float *__restrict__ eig,
-                                                          float *__restrict__ Vout, float conv2, float *Aout)
+                                                          float *__restrict__ Vout, float conv2, float *Aout, const int *d_n, int first_item)
 {
+    n = items_on_device(d_n, first_item, n);
     __shared__ float4 lds4[(2 * JQ_HALF + 32) / 4];
     float *lds = reinterpret_cast<float *>(lds4);
     int *place_tab = reinterpret_cast<int *>(lds + 2 * JQ_HALF);
@@ -1060,10 +1070,12 @@ template <int PHASE>
 __global__ __launch_bounds__(64) void k_bayes27(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                 const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
                                                 int first_item, int nb_items, int *work, Geom27 g, float min_eig, Records27 rec, float *sum,
-                                                int32_t *cnt, const int *redo = nullptr /* PHASE 2, optional: [0] count, [1..] the items to process */)
+                                                int32_t *cnt, const int *redo = nullptr /* PHASE 2, optional: [0] count, [1..] the items to process */,
+                                                const int *d_n = nullptr)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
+    nb_items = items_on_device(d_n, first_item, nb_items);
     if (PHASE == 2 && redo) nb_items = redo[0];
     // PHASE 1 needs one matrix buffer only (the member chunk; its matrices go from the accumulator registers to the records) and
     // runs 20 wavefronts per CU instead of 12, which is what its member gathers want (half of its wave cycles wait for memory;
@@ -1508,10 +1520,12 @@ template <int PHASE, int B = WB>
 __global__ __launch_bounds__(64, PHASE == 1 ? 5 : 3) void k_bayes27w(const float *__restrict__ colors, const float *__restrict__ pixcov,
                                                  const uint32_t *__restrict__ mask, const int32_t *__restrict__ list,
                                                  int first_item, int nb_items, int *work, Geom27 g, float min_eig, Records27 rec, float *sum,
-                                                 int32_t *cnt, const int *redo /* PHASE 2, optional: [0] count, [1..] the items to process */)
+                                                 int32_t *cnt, const int *redo /* PHASE 2, optional: [0] count, [1..] the items to process */,
+                                                 const int *d_n = nullptr)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
+    nb_items = items_on_device(d_n, first_item, nb_items);
     if (PHASE == 2 && redo) nb_items = redo[0];
     // (PHASE 1 opens the chunk: it clears the redo list's counter for the finish kernel two launches later -- this was a fill between the kernels)
     if (PHASE == 1 && redo && blockIdx.x == 0 && lane == 0) const_cast<int *>(redo)[0] = 0;
@@ -1702,8 +1716,9 @@ template <int B>
 __global__ __launch_bounds__(64, 3) void k_finish27w(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
                                                      const int32_t *__restrict__ list, int first_item, int nb_items, int *work, Geom27 g,
                                                      float min_eig, Records27 rec, float *sum, int32_t *cnt, int *redo /* [0] count, [1..] items */,
-                                                     int *redo_total /* statistics: items handed over, all launches of the scale */)
+                                                     int *redo_total /* statistics: items handed over, all launches of the scale */, const int *d_n)
 {
+    nb_items = items_on_device(d_n, first_item, nb_items);
     using G_ = WinT<B>;
     constexpr int AW = G_::AW, PIX = G_::PIX, GAP = G_::G; // window pixels per line / in all; floats from the end of a patch line to the start of the next
     extern __shared__ float lds[];
@@ -1948,7 +1963,8 @@ size_t bcd_bayes27_lds_bytes(int b)
 // bytes of HBM one processed pixel needs between the phases (A, V, C, noise + mean, eigenvalues, its entry of the redo list)
 size_t bcd_bayes27_record_bytes() { return (size_t)(3 * MSZ + AUX27 + KP) * sizeof(float) + 2 * sizeof(int); } // (+ the redo list: 1 + items ints)
 
-hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blocks, float *eig, float *V, hipStream_t st, float conv2 = 1e-12f, float *Aout = nullptr);
+hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blocks, float *eig, float *V, hipStream_t st, float conv2 = 1e-12f, float *Aout = nullptr,
+                                     const int *d_n = nullptr, int first_item = 0);
 
 // Stopping rule of the estimate chain's eigensolver: 2e-9 + first-order correction (production), or -- strict mode, BCD_HIP_STRICT_EIGEN=1 or
 // bcd_hip_set_strict_eigensolver -- the fully converged 1e-12 (the looser rule spends accuracy on ill-conditioned low-spp frames, 9.8e-6
@@ -1967,8 +1983,11 @@ static float jacobi_conv2()
 hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const uint32_t *mask, const int32_t *list, int first_item, int nb_items,
                               int *d_work, int num_cus, int W, int H, int b, float min_eig, float *records, float *sum,
                               int32_t *cnt, int *d_spectral /* += items whose inverse took the spectral branch (windowed path) */, hipStream_t st,
-                              int defer_redo /* != 0: the caller reads *d_spectral after its next synchronisation and calls bcd_launch_bayes27_redo if it is > 0 */)
+                              int defer_redo /* != 0: the caller reads *d_spectral after its next synchronisation and calls bcd_launch_bayes27_redo if it is > 0 */,
+                              const int *d_nb_items /* optional: the list's length on the device -- the chunk is then min(nb_items, *d_nb_items - first_item) items,
+                                                       nb_items being the capacity of `records` (grids are sized for it; wavefronts without an item leave at once) */)
 {
+    const int *dn = d_nb_items;
     if (nb_items <= 0) return hipSuccess;
     Geom27 g;
     g.W = W; g.H = H; g.b = b; g.side = 2 * b + 1; g.words = (g.side * g.side + 31) / 32; g.maxS = g.side * g.side;
@@ -1989,23 +2008,23 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         static const bool lds_algebra = [] { const char *e = getenv("BCD_HIP_FINISH_LDS"); return e && e[0] == '1'; }();
         int *redo = reinterpret_cast<int *>(rec.eig + (size_t)nb_items * KP); // (the register-resident finish; cleared by the prepare kernel)
         hipLaunchKernelGGL(k_bayes27w<1>, dim3(std::min(nb_items, num_cus * w_cu1)), dim3(64), wl1, st, colors, pixcov, mask, list, first_item, nb_items,
-                           d_work, g, min_eig, rec, sum, cnt, lds_algebra ? nullptr : redo);
-        { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st, jacobi_conv2(), rec.A); if (e != hipSuccess) return e; }
+                           d_work, g, min_eig, rec, sum, cnt, lds_algebra ? nullptr : redo, dn);
+        { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st, jacobi_conv2(), rec.A, dn, first_item); if (e != hipSuccess) return e; }
         if (lds_algebra)
             hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * w_cu2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
-                               d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, nullptr);
+                               d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, nullptr, dn);
         else {
             // the register-resident finish; the items whose sweep inverse fails its checks (rare) come back on a list for the LDS kernel
             const size_t wl3 = WinT<WB>::F2_BYTES;
             hipLaunchKernelGGL(k_finish27w<WB>, dim3(std::min(nb_items, num_cus * 12)), dim3(64), wl3, st, colors, mask, list, first_item, nb_items,
-                               d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo, d_spectral);
+                               d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo, d_spectral, dn);
             // (normally an empty list: a small grid, so that its 17 KB workgroups do not queue for LDS behind the kernels of the other scales --
             // a full-size launch that only reads "0 items" was seen waiting 0.7 ms for room.  A long list is still processed, by fewer wavefronts.)
             // Round 4: a caller that looks at the counter anyway does not launch it at all on an empty list -- beside the persistent kernels of the other
             // scales even the small launch sat 170-470 us on a coarse scale's stream waiting for LDS, with nothing to do.
             if (!defer_redo)
                 hipLaunchKernelGGL(k_bayes27w<2>, dim3(std::min(nb_items, num_cus * 2)), dim3(64), wl2, st, colors, pixcov, mask, list, first_item, nb_items,
-                                   d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo);
+                                   d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo, dn);
         }
         return hipGetLastError();
     }
@@ -2021,11 +2040,11 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         const size_t wl1 = W1L<WB2>::BYTES;
         const int w_cu1 = (int)std::min<size_t>(20, (size_t)160 * 1024 / wl1);
         hipLaunchKernelGGL((k_bayes27w<1, WB2>), dim3(std::min(nb_items, num_cus * w_cu1)), dim3(64), wl1, st, colors, pixcov, mask, list, first_item, nb_items,
-                           d_work, g, min_eig, rec, sum, cnt, (const int *)redo);
+                           d_work, g, min_eig, rec, sum, cnt, (const int *)redo, dn);
     } else
         hipLaunchKernelGGL(k_bayes27<1>, dim3(std::min(nb_items, num_cus * per_cu1)), dim3(64), lds1, st, colors, pixcov, mask, list, first_item, nb_items,
-                           d_work, g, min_eig, rec, sum, cnt, (const int *)nullptr);
-    { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st, jacobi_conv2(), rec.A); if (e != hipSuccess) return e; }
+                           d_work, g, min_eig, rec, sum, cnt, (const int *)nullptr, dn);
+    { hipError_t e = bcd_launch_jacobi27_batch(rec.A, nb_items, d_work + BCD_WORK_QUEUES * BCD_WORK_STRIDE, std::min((nb_items + 1) / 2, num_cus * 12), rec.eig, rec.V, st, jacobi_conv2(), rec.A, dn, first_item); if (e != hipSuccess) return e; }
     if (finish_regs) {
         // the gather prepare kernel does not know the redo list: its counter is cleared here (one fill per chunk)
         if (!prepare_win) { hipError_t e = hipMemsetAsync(redo, 0, sizeof(int), st); if (e != hipSuccess) return e; }
@@ -2040,14 +2059,14 @@ hipError_t bcd_launch_bayes27(const float *colors, const float *pixcov, const ui
         }
         const int per_cu3 = (int)std::min<size_t>(12, (size_t)160 * 1024 / wl3);
         hipLaunchKernelGGL(k_finish27w<WB2>, dim3(std::min(nb_items, num_cus * per_cu3)), dim3(64), wl3, st, colors, mask, list, first_item, nb_items,
-                           d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo, d_spectral);
+                           d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, redo, d_spectral, dn);
         if (!defer_redo)
             hipLaunchKernelGGL(k_bayes27<2>, dim3(std::min(nb_items, num_cus * 2)), dim3(64), lds2, st, colors, pixcov, mask, list, first_item, nb_items,
-                               d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, (const int *)redo);
+                               d_work + 3 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, (const int *)redo, dn);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_bayes27<2>, dim3(std::min(nb_items, num_cus * per_cu2)), dim3(64), lds2, st, colors, pixcov, mask, list, first_item, nb_items,
-                       d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, (const int *)nullptr);
+                       d_work + 2 * BCD_WORK_QUEUES * BCD_WORK_STRIDE, g, min_eig, rec, sum, cnt, (const int *)nullptr, dn);
     return hipGetLastError();
 }
 
@@ -2077,7 +2096,8 @@ hipError_t bcd_launch_bayes27_redo(const float *colors, const float *pixcov, con
 }
 
 // eigen-decomposition of n symmetric 27 x 27 matrices (28 x 28 zero-padded, row-major): persistent wavefronts, two matrices each
-hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blocks, float *eig, float *V, hipStream_t st, float conv2, float *Aout)
+hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blocks, float *eig, float *V, hipStream_t st, float conv2, float *Aout,
+                                     const int *d_n /* optional: the number of matrices is min(n, *d_n - first_item), read on the device */, int first_item)
 {
     if (blocks <= 0) return hipSuccess;
     // <padded row placement, DPP-fused row rotation>: measured on 65 536 matrices 31.3 ns per matrix without either, 31.1 with the
@@ -2085,7 +2105,7 @@ hipError_t bcd_launch_jacobi27_batch(const float *A, int n, int *d_work, int blo
     // 29.4 with both
     static const bool pairs = [] { const char *e = getenv("BCD_HIP_JACOBI_PAIRS"); return e && e[0] == '1'; }();
     // (the comparison kernel keeps the plain rule: its residual is then far below what the correction of the finish kernels would notice)
-    if (pairs) hipLaunchKernelGGL((k_jacobi27_batch<true, true>), dim3(blocks), dim3(64), 0, st, A, n, d_work, eig, V, 1e-12f, Aout);
-    else hipLaunchKernelGGL(k_jacobi27_quads, dim3(blocks), dim3(64), 0, st, A, n, d_work, eig, V, conv2, Aout);
+    if (pairs) hipLaunchKernelGGL((k_jacobi27_batch<true, true>), dim3(blocks), dim3(64), 0, st, A, n, d_work, eig, V, 1e-12f, Aout, d_n, first_item);
+    else hipLaunchKernelGGL(k_jacobi27_quads, dim3(blocks), dim3(64), 0, st, A, n, d_work, eig, V, conv2, Aout, d_n, first_item);
     return hipGetLastError();
 }

@@ -273,6 +273,15 @@ int bcd_hip_active_init(bcd_hip_ctx *ctx, const int32_t *d_count, int W, int H, 
 int bcd_hip_active_step(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_count, int W, int H, int patch_radius, int search_radius,
                         int main_row_begin, int main_row_end, int random_order, uint32_t seed, int row_offset, int first_pass,
                         uint8_t *d_state, int32_t *undecided);
+/* bcd_hip_active_step in two halves, for a caller whose own reduction follows in stream order (the multi-GPU driver's all-reduce; round 6): _enqueue
+ * launches the batch without waiting and, if d_total is not null, leaves on the DEVICE the rank's contribution to the all-reduced count of undecided
+ * pixels -- the count after the batch, + 2^40 when with_verdict != 0 and the masks of the last bcd_hip_similarity_masks_deferred on this context are
+ * not valid (the test bcd_hip_similarity_masks_verdict makes on the host); after the caller's synchronisation of the context's stream _collect returns
+ * the local count and the number of launches the batch needed. */
+int bcd_hip_active_step_enqueue(bcd_hip_ctx *ctx, const uint32_t *d_mask, const int32_t *d_count, int W, int H, int patch_radius, int search_radius,
+                                int main_row_begin, int main_row_end, int random_order, uint32_t seed, int row_offset,
+                                uint8_t *d_state, int64_t *d_total, int with_verdict);
+int bcd_hip_active_step_collect(bcd_hip_ctx *ctx, int32_t *undecided, int32_t *launches);
 /* denoiseSelectedPatches / denoiseOnlyMainPatch + aggregateOutputPatches for every processed pixel
  * (DenoisingUnit.cpp:388-481,672-693); d_sum / d_count are accumulated into (zero them first). */
 int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixel_cov,
