@@ -65,7 +65,7 @@ hipError_t bcd_launch_active_round(const uint32_t *, const int32_t *, uint8_t *,
 hipError_t bcd_launch_mark_deps(const uint32_t *, const int32_t *, uint8_t *, uint32_t *, int, int, int, int, int, uint32_t, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_mark_round(const uint32_t *, uint8_t *, int, int, int, int, int, int, int *, hipStream_t);
 hipError_t bcd_launch_sum_counter_lines(const int *, int, int *, hipStream_t, long long * = nullptr, const int * = nullptr, int = 0);
-hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t);
+hipError_t bcd_launch_active_lists(const uint8_t *, const int32_t *, int64_t, int64_t, int, int32_t *, int32_t *, int32_t *, hipStream_t, const long long *);
 hipError_t bcd_launch_jacobi27_batch(const float *, int, int *, int, float *, float *, hipStream_t, float = 1e-12f, float * = nullptr, const int * = nullptr, int = 0);
 size_t bcd_bayes_lds_bytes(int w, int b);
 size_t bcd_bayes_scratch_bytes_per_block(int w, int b);
@@ -78,7 +78,7 @@ hipError_t bcd_launch_bayes_strong(const float *, const float *, const uint32_t 
                                    int, float, float *, int32_t *, float *, size_t, hipStream_t);
 hipError_t bcd_launch_bayes_weak(const float *, const uint32_t *, const int32_t *, const int32_t *, int, int, int, int, int, float *,
                                  int32_t *, hipStream_t);
-hipError_t bcd_launch_bayes_weak_tiles(const float *, const uint32_t *, const uint8_t *, const int32_t *, int, int, int, int, float *, int32_t *, hipStream_t);
+hipError_t bcd_launch_bayes_weak_tiles(const float *, const uint32_t *, const uint8_t *, const int32_t *, int, int, int, int, float *, int32_t *, hipStream_t, int, int, const long long *);
 
 namespace {
 
@@ -551,10 +551,21 @@ int active_set(bcd_hip_ctx *ctx, Work &wk, const uint32_t *d_mask, const int32_t
 // w = 1: the full estimate is three kernels with a per-pixel record in HBM between them (k_bayes27.hip); the host reads the
 // number of full-estimate pixels (one short round trip, the fallback kernel is already running on its side stream) to size the
 // record buffer and to cut very long lists (-m 0) into chunks.  Other patch radii: one persistent kernel, no round trip.
+// Only processed pixels of lines [row_begin, row_end) are listed / estimated (a row band's owned lines: the states of its halo lines belong to
+// the neighbours).
+// Speculative use (round 6; w = 1 only): `d_skip` points at a device word that the work enqueued ahead of this call leaves at zero when this call is
+// wanted -- the all-reduced count of undecided pixels of the marking batch that precedes it in the stream -- and `h_skip` at the host copy of that word
+// (copied on the same stream before the call).  The list and fallback kernels do nothing when the word is not zero, the estimate kernels then find empty
+// lists, and *skipped says so once the host has seen the word: the caller goes on marking and calls again.  The host waits for ONE event in here (list
+// lengths + that word), with the first chunk of estimate kernels already enqueued behind it.
 int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask, const int32_t *d_nsim,
-          const uint8_t *d_state, int W, int H, int w, int b, float min_eig, float *d_sum, int32_t *d_count, bool defer_redo = false)
+          const uint8_t *d_state, int W, int H, int w, int b, float min_eig, float *d_sum, int32_t *d_count, bool defer_redo = false,
+          int row_begin = 0, int row_end = INT_MAX, const long long *d_skip = nullptr, const long long *h_skip = nullptr, bool *skipped = nullptr)
 {
     const int64_t npix = (int64_t)W * H;
+    row_begin = std::max(0, row_begin); row_end = std::min(H, row_end);
+    if (skipped) *skipped = false;
+    if (d_skip && (w != 1 || !h_skip || !skipped)) return bad(ctx, "speculative estimate: patch radius 1 and a host copy of the word are required");
     const int K = 3 * (2 * w + 1) * (2 * w + 1);
     wk.redo.pending = false;
     RCCHK(ensure(ctx, wk.strong, npix * sizeof(int32_t)));
@@ -569,13 +580,13 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     auto fork_weak_tiles = [&]() -> int {
         HIPCHK(ctx, hipEventRecord(wk.ev_fork, wk.stream));
         HIPCHK(ctx, hipStreamWaitEvent(wk.aux, wk.ev_fork, 0));
-        HIPCHK(ctx, bcd_launch_bayes_weak_tiles(d_colors, d_mask, d_state, d_nsim, K + 1, W, H, b, d_sum, d_count, wk.aux));
+        HIPCHK(ctx, bcd_launch_bayes_weak_tiles(d_colors, d_mask, d_state, d_nsim, K + 1, W, H, b, d_sum, d_count, wk.aux, row_begin, row_end, d_skip));
         HIPCHK(ctx, hipEventRecord(wk.ev_join, wk.aux));
         return BCD_HIP_OK;
     };
     if (wk.clean_dc) wk.clean_dc = false; // (k_scale_begin)
     else HIPCHK(ctx, hipMemsetAsync(d_c, 0, 8 * sizeof(int32_t), wk.stream));
-    HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, npix, K + 1, (int32_t *)wk.strong.p, (int32_t *)wk.weak.p, d_c, wk.stream));
+    HIPCHK(ctx, bcd_launch_active_lists(d_state, d_nsim, (int64_t)row_begin * W, (int64_t)row_end * W, K + 1, (int32_t *)wk.strong.p, (int32_t *)wk.weak.p, d_c, wk.stream, d_skip));
     HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 16, d_c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream));
     // (round 5) the list compaction is 253 workgroups of 1024 threads: 18 us alone, 150 us when the fallback kernel's 8 160 tiles were launched
     // first and every CU had to drain before one of them fitted.  The fallback kernel starts BEHIND it (it still overlaps the host round trip).
@@ -619,6 +630,11 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
             RCCHK(launch_chunk(0, ahead, defer_redo, d_c));
         }
         HIPCHK(ctx, hipEventSynchronize(wk.ev_counts));
+        if (h_skip && *h_skip != 0) { // the speculation failed: nothing was listed, the kernels enqueued above found nothing to do
+            *skipped = true;
+            HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_join, 0));
+            return BCD_HIP_OK;
+        }
         const int n_strong = wk.h_counters[16];
         wk.strong_hint = n_strong; wk.strong_hint_W = W; wk.strong_hint_H = H;
         if (ahead > 0 && n_strong <= ahead) {
@@ -703,23 +719,62 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
                                            (int *)wk.work_q.p, BCD_WORK_INTS, wk.stream));
         wk.clean_flags = wk.clean_lines = wk.clean_dc = wk.clean_wq = true;
     }
+    const bool marking = prm->marked_skip_probability > 0.f;
+    // Round 6: with marking and 3 x 3 patches the estimate is enqueued BEHIND every marking batch, valid only if that batch decided the last pixel and the
+    // masks passed their checks (one device word says so: k_sum_counter_lines); the host waits once per batch -- for that word and the list lengths together,
+    // inside bayes() -- where it used to wait for the batch, then for the lists.  A batch that leaves pixels undecided (rare: the batch is sized from the
+    // previous frame) costs the empty launches of one skipped estimate.
+    const bool speculate = marking && w == 1;
+    const long long REDO = 1ll << 40;
+    bool estimated = false;
     for (int attempt = 0, mode = 2; attempt < 4; ++attempt) { // production kernels; if they complain: general formula (own-list kernel, then the dense one), then exact kernels
         RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, mode));
         if (prof && attempt == 0) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
-        RCCHK(active_set(ctx, wk, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, W, H, w, b, row_begin, row_end,
-                         prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)wk.state.p, &st.active_rounds));
-        if (mode == 1) break;
-        if (!(prm->marked_skip_probability > 0.f)) HIPCHK(ctx, hipStreamSynchronize(wk.stream)); // no marking batch brought the flag back
+        if (!speculate) {
+            RCCHK(active_set(ctx, wk, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, W, H, w, b, row_begin, row_end,
+                             prm->marked_skip_probability, prm->use_random_pixel_order, seed, (uint8_t *)wk.state.p, &st.active_rounds));
+            if (mode == 1) break;
+            if (!marking) HIPCHK(ctx, hipStreamSynchronize(wk.stream)); // no marking batch brought the flag back
+        } else {
+            HIPCHK(ctx, bcd_launch_active_init((const int32_t *)wk.nsim.p, W, H, w, row_begin, row_end, prm->marked_skip_probability, seed, 0, (uint8_t *)wk.state.p, wk.stream));
+            wk.dep_ready = false;
+            if (attempt == 0) HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_pixcov, 0)); // covariances computed, accumulators cleared (long done)
+            long long *d_total = reinterpret_cast<long long *>((int *)wk.counters.p + 48), *h_total = reinterpret_cast<long long *>(wk.h_counters + 48);
+            const uint32_t key_seed = prm->use_random_pixel_order == 2 ? bcd_strip_order_seed(W, H, w, b) : seed; // (as active_set)
+            int rounds = 0;
+            long long before = -1;
+            for (;;) {
+                RCCHK(active_step_enqueue(ctx, wk, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, W, H, w, b, row_begin, row_end, prm->use_random_pixel_order,
+                                          key_seed, 0, (uint8_t *)wk.state.p, d_total, mode != 1));
+                HIPCHK(ctx, hipMemcpyAsync(h_total, d_total, sizeof(long long), hipMemcpyDeviceToHost, wk.stream));
+                bool skipped = false;
+                wk.clean_flags = wk.clean_lines = false; // (consumed by the similarity pass and the batch)
+                RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p, (const uint8_t *)wk.state.p, W, H, w, b,
+                            prm->min_eigen_value, d_sum, d_count, true, 0, H, d_total, h_total, &skipped));
+                int undecided = 0, n = 0;
+                active_step_collect(wk, &undecided, &n); // (bayes() waited for an event behind the batch's counters)
+                rounds += n;
+                if (!skipped) { estimated = true; (void)similarity_redo_mode(wk); break; } // (0 by construction; keeps the workspace's memory of uniform sample counts)
+                if (*h_total >= REDO) break; // the masks did not pass: again with the next kind of kernels
+                if (before >= 0 && *h_total >= before) { set_err(ctx, "marking fixed point made no progress"); return BCD_HIP_EDEVICE; }
+                before = *h_total;
+            }
+            wk.rounds_hint = rounds;
+            st.active_rounds = rounds;
+            if (estimated) break;
+        }
         const int redo = similarity_redo_mode(wk);
         if (redo == 0) break; // inputs inside the guarded range, uniform-count guess right, borderline list not overflowed
         mode = (redo == 3 && (mode == 2 || wk.nz_used)) ? 3 : 1; // (wk.nz_used: the own-list kernel declined and the workspace has noted it -- the dense kernel is next)
     }
     progress_add(ctx, 0.5 * (double)npix); // similar patches selected, processed set known
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
-    HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_pixcov, 0)); // covariances computed, accumulators cleared (long done)
-    wk.clean_flags = wk.clean_lines = false; // (consumed, or never used by this configuration)
-    RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p,
-                (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count, true));
+    if (!estimated) {
+        HIPCHK(ctx, hipStreamWaitEvent(wk.stream, wk.ev_pixcov, 0)); // covariances computed, accumulators cleared (long done)
+        wk.clean_flags = wk.clean_lines = false; // (consumed, or never used by this configuration)
+        RCCHK(bayes(ctx, wk, d_colors, (const float *)wk.pixcov.p, (const uint32_t *)wk.mask.p, (const int32_t *)wk.nsim.p,
+                    (const uint8_t *)wk.state.p, W, H, w, b, prm->min_eigen_value, d_sum, d_count, true));
+    }
     wk.clean_dc = wk.clean_wq = false;
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[3], wk.stream));
     if (d_out) HIPCHK(ctx, bcd_launch_finalize(d_sum, d_count, (int64_t)npix, d_out, wk.stream));
@@ -1448,6 +1503,20 @@ int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const floa
     if (!ctx || !d_colors || !d_pixcov || !d_mask || !d_nsim || !d_state || !d_sum || !d_count) return bad(ctx, "bad argument");
     DEVICE_GUARD(ctx);
     return bayes(ctx, ctx->main, d_colors, d_pixcov, d_mask, d_nsim, d_state, W, H, w, b, min_eig, d_sum, d_count);
+}
+
+int bcd_hip_bayes_accumulate_rows(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixcov, const uint32_t *d_mask,
+                                  const int32_t *d_nsim, const uint8_t *d_state, int W, int H, int w, int b, float min_eig,
+                                  float *d_sum, int32_t *d_count, int row_begin, int row_end, const int64_t *d_skip_if, const int64_t *h_skip_if, int *skipped)
+{
+    if (!ctx || !d_colors || !d_pixcov || !d_mask || !d_nsim || !d_state || !d_sum || !d_count) return bad(ctx, "bad argument");
+    if (d_skip_if && (!h_skip_if || !skipped)) return bad(ctx, "a speculative estimate needs the host copy of its word and a place for the verdict");
+    DEVICE_GUARD(ctx);
+    bool sk = false;
+    const int rc = bayes(ctx, ctx->main, d_colors, d_pixcov, d_mask, d_nsim, d_state, W, H, w, b, min_eig, d_sum, d_count, false, row_begin, row_end,
+                         reinterpret_cast<const long long *>(d_skip_if), reinterpret_cast<const long long *>(h_skip_if), d_skip_if ? &sk : nullptr);
+    if (skipped) *skipped = sk ? 1 : 0;
+    return rc;
 }
 
 int bcd_hip_finalize(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int64_t npix, float *d_out)

@@ -485,8 +485,8 @@ bool allreduce(bcd_hip_multi *m, int rank, int ch, long long *value)
 }
 
 // RCCL transport: the rank's contribution is already in d_red[rank][ch], produced on the channel's stream (bcd_hip_active_step_enqueue); the sum over
-// all ranks comes back with ONE synchronisation of that stream
-bool allreduce_device(bcd_hip_multi *m, int rank, int ch, long long *value)
+// all ranks is copied to h_red[rank][ch] in stream order; the caller synchronises (allreduce_device does, for callers with nothing else to enqueue)
+bool allreduce_device_enqueue(bcd_hip_multi *m, int rank, int ch)
 {
     trace_op(m, rank, ch, 1, 0, 0);
     hipStream_t st = m->stream[rank][ch];
@@ -498,7 +498,13 @@ bool allreduce_device(bcd_hip_multi *m, int rank, int ch, long long *value)
     }
     if (r != ncclSuccess) { fail(m, std::string("RCCL all-reduce failed: ") + ncclGetErrorString(r)); return false; }
     MCHK(m, rank, hipMemcpyAsync(m->h_red[rank][ch], m->d_red[rank][ch], sizeof(long long), hipMemcpyDeviceToHost, st));
-    MCHK(m, rank, hipStreamSynchronize(st));
+    return true;
+}
+
+bool allreduce_device(bcd_hip_multi *m, int rank, int ch, long long *value)
+{
+    if (!allreduce_device_enqueue(m, rank, ch)) return false;
+    MCHK(m, rank, hipStreamSynchronize(m->stream[rank][ch]));
     *value = *m->h_red[rank][ch];
     return true;
 }
@@ -584,6 +590,12 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
     if (gated && !m->gate[rank].wait1(s, g.S)) return false; // phase 1 of this scale: after the coarser scales' marking
     int rounds = 0;
     const long long REDO = 1ll << 40; // added to the all-reduced count of undecided pixels by a rank whose masks are not valid
+    // Round 6: on the RCCL transport with 3 x 3 patches the estimate is enqueued BEHIND every marking batch and its all-reduce, valid only if the
+    // all-reduced count came out zero (the list and fallback kernels look at the word on the device); the host waits once per batch, inside
+    // bcd_hip_bayes_accumulate_rows, with the estimate kernels already in the queue -- it used to wait for the batch, for the all-reduce and for the lists,
+    // each time with an empty queue behind it.
+    const bool speculate = marking && talk && m->use_rccl && w == 1;
+    bool estimated = false;
     for (;;) { // the marking problem; once more from the start if some rank has to recompute its masks
         if (marking && talk) {
             // |S| of the b boundary lines comes from their owner (locally their windows are cut by the band edge)
@@ -605,7 +617,14 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
                 if (talk && m->use_rccl) {
                     ECHK(m, rank, c, bcd_hip_active_step_enqueue(c, mask, nsim, W, rows, w, b, r0, r1, job.prm.use_random_pixel_order, seed, row_offset, state,
                                                                  reinterpret_cast<int64_t *>(m->d_red[rank][s]), verdict_known ? 0 : 1));
-                    if (!allreduce_device(m, rank, s, &total)) return false; // (synchronises the scale's stream)
+                    if (speculate) {
+                        if (!allreduce_device_enqueue(m, rank, s)) return false;
+                        int skipped = 0;
+                        ECHK(m, rank, c, bcd_hip_bayes_accumulate_rows(c, col, pixcov, mask, nsim, state, W, rows, w, b, job.prm.min_eigen_value, sum, cnt, r0, r1,
+                                                                       reinterpret_cast<const int64_t *>(m->d_red[rank][s]), reinterpret_cast<const int64_t *>(m->h_red[rank][s]), &skipped));
+                        total = *m->h_red[rank][s]; // (the call waited for an event behind the copy of the all-reduced word)
+                        estimated = !skipped;
+                    } else if (!allreduce_device(m, rank, s, &total)) return false; // (synchronises the scale's stream)
                     int32_t undecided = 0;
                     ECHK(m, rank, c, bcd_hip_active_step_collect(c, &undecided, nullptr));
                     if (!verdict_known) { int redo = 0; ECHK(m, rank, c, bcd_hip_similarity_masks_verdict(c, &redo)); my_redo = redo != 0; }
@@ -638,10 +657,9 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
     }
     m->gate[rank].finish1(s); // the finer scales may mark; nothing of this scale is enqueued on a communicator until phase 2
     progress_add(m, 0.5 * (double)(r1 - r0) * W); // similar patches selected, processed set known
-    // halo lines are processed by their owner
-    if (r0 > 0) MCHK(m, rank, hipMemsetAsync(state, 0, (size_t)r0 * W, st));
-    if (r1 < rows) MCHK(m, rank, hipMemsetAsync(state + (size_t)r1 * W, 0, (size_t)(rows - r1) * W, st));
-    ECHK(m, rank, c, bcd_hip_bayes_accumulate(c, col, pixcov, mask, nsim, state, W, rows, w, b, job.prm.min_eigen_value, sum, cnt));
+    // halo lines are processed by their owner: only the owned lines are listed
+    if (!estimated)
+        ECHK(m, rank, c, bcd_hip_bayes_accumulate_rows(c, col, pixcov, mask, nsim, state, W, rows, w, b, job.prm.min_eigen_value, sum, cnt, r0, r1, nullptr, nullptr, nullptr));
     // accumulator halos: the (b + w) lines written outside the owned band belong to the neighbours
     float *rx_us = (float *)B(bcd_hip_multi::RX_UP_S).p, *rx_ds = (float *)B(bcd_hip_multi::RX_DN_S).p;
     int32_t *rx_uc = (int32_t *)B(bcd_hip_multi::RX_UP_C).p, *rx_dc = (int32_t *)B(bcd_hip_multi::RX_DN_C).p;

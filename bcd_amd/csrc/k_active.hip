@@ -300,16 +300,20 @@ __global__ __launch_bounds__(256) void k_mark_round(const uint32_t *__restrict__
 // compact lists of processed pixels: strong (full Bayesian path) and weak (fallback path); one atomic per counter
 // per workgroup, wavefront offsets through LDS
 __global__ __launch_bounds__(1024) void k_active_lists(const uint8_t *__restrict__ state, const int32_t *__restrict__ nsim,
-                                                       int64_t npix, int min_strong,
+                                                       int64_t p_begin, int64_t npix /* pixels [p_begin, npix) */, int min_strong,
                                                        int32_t *__restrict__ strong_list, int32_t *__restrict__ weak_list,
-                                                       int32_t *__restrict__ counters /* [0]=strong [1]=weak, [2..3] sum |S| (64-bit) */)
+                                                       int32_t *__restrict__ counters /* [0]=strong [1]=weak, [2..3] sum |S| (64-bit) */,
+                                                       const long long *__restrict__ skip_if /* optional: the launch does nothing when this word is not zero */)
 {
+    // (round 6) launched behind a marking batch whose outcome the host has not seen yet: undecided pixels left (or masks to recompute) -> no lists,
+    // and the estimate kernels that follow find none
+    if (skip_if && *skip_if != 0) return;
     // LISTS_PER_THREAD x 1024 pixels per workgroup and ONE set of atomics on the list counters for all of them (same-address atomics
     // are served one at a time: with 1024 pixels per workgroup the 2 025 x 3 atomics of a 1080p scale were most of this kernel's time)
     __shared__ int ws[LISTS_PER_THREAD][16], ww[LISTS_PER_THREAD][16], base[2];
     __shared__ long long wt[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t p0 = (int64_t)blockIdx.x * (1024 * LISTS_PER_THREAD) + threadIdx.x;
+    const int64_t p0 = p_begin + (int64_t)blockIdx.x * (1024 * LISTS_PER_THREAD) + threadIdx.x;
     unsigned long long bs[LISTS_PER_THREAD], bw[LISTS_PER_THREAD];
     long long tot = 0;
 #pragma unroll
@@ -367,11 +371,14 @@ hipError_t bcd_launch_active_round(const uint32_t *mask, const int32_t *nsim, ui
     return hipGetLastError();
 }
 
-hipError_t bcd_launch_active_lists(const uint8_t *state, const int32_t *nsim, int64_t npix, int min_strong,
-                                   int32_t *strong_list, int32_t *weak_list, int32_t *counters, hipStream_t st)
+// pixels [p_begin, p_end) of the state image (the owned lines of a row band: halo lines are processed by their owner); skip_if: see the kernel
+hipError_t bcd_launch_active_lists(const uint8_t *state, const int32_t *nsim, int64_t p_begin, int64_t p_end, int min_strong,
+                                   int32_t *strong_list, int32_t *weak_list, int32_t *counters, hipStream_t st, const long long *skip_if)
 {
-    hipLaunchKernelGGL(k_active_lists, dim3((unsigned)((npix + 1024 * LISTS_PER_THREAD - 1) / (1024 * LISTS_PER_THREAD))), dim3(1024), 0, st, state, nsim, npix, min_strong,
-                       strong_list, weak_list, counters);
+    if (p_end <= p_begin) return hipSuccess;
+    const int64_t n = p_end - p_begin;
+    hipLaunchKernelGGL(k_active_lists, dim3((unsigned)((n + 1024 * LISTS_PER_THREAD - 1) / (1024 * LISTS_PER_THREAD))), dim3(1024), 0, st, state, nsim, p_begin, p_end, min_strong,
+                       strong_list, weak_list, counters, skip_if);
     return hipGetLastError();
 }
 

@@ -427,8 +427,10 @@ __global__ __launch_bounds__(64) void k_bayes_weak_w1(const float *__restrict__ 
 constexpr int WT = 16; // tile edge
 __global__ __launch_bounds__(256) void k_bayes_weak_tile(const float *__restrict__ colors, const uint32_t *__restrict__ mask,
                                                          const uint8_t *__restrict__ state, const int32_t *__restrict__ nsim, int min_strong,
-                                                         BayesGeom g, float *sum, int32_t *cnt)
+                                                         BayesGeom g, float *sum, int32_t *cnt, int row_begin, int row_end /* only pixels of these lines */,
+                                                         const long long *__restrict__ skip_if /* optional: the launch does nothing when this word is not zero */)
 {
+    if (skip_if && *skip_if != 0) return; // (launched behind a marking batch whose outcome the host has not seen yet, like k_active_lists)
     extern __shared__ float lds[];
     const int b1 = g.b + 1, TW = WT + 2 * b1, row3 = TW * 3;
     float *win = lds;                                         // TW x TW x 3 colours
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void k_bayes_weak_tile(const float *__restrict
     const int lx = tid & (WT - 1), ly = tid >> 4, gx = tx0 + lx, gy = ty0 + ly;
     const bool inside = gx < W && gy < H;
     const long long pg = (long long)gy * W + gx;
-    const bool weak = inside && state[pg] == BCD_ST_IN && nsim[pg] < min_strong;
+    const bool weak = inside && gy >= row_begin && gy < row_end && state[pg] == BCD_ST_IN && nsim[pg] < min_strong;
     if (tid == 0) n_weak = 0;
     __syncthreads();
     {
@@ -627,14 +629,14 @@ hipError_t bcd_launch_bayes_strong(const float *colors, const float *pixcov, con
 
 // the tiled fallback kernel (3 x 3 patches): needs no list -- it reads the marking states and |S| itself
 hipError_t bcd_launch_bayes_weak_tiles(const float *colors, const uint32_t *mask, const uint8_t *state, const int32_t *nsim, int min_strong,
-                                       int W, int H, int b, float *sum, int32_t *cnt, hipStream_t st)
+                                       int W, int H, int b, float *sum, int32_t *cnt, hipStream_t st, int row_begin, int row_end, const long long *skip_if)
 {
     BayesGeom g = make_geom(W, H, 1, b);
     if (g.words > 32) return hipErrorInvalidValue;
     const int TW = WT + 2 * (b + 1);
     const size_t lds = (size_t)((TW * TW * 3 + 3) & ~3) * 4 + (size_t)(WT + 2) * (WT + 2) * 16 + (256 + 4 * 192) * sizeof(uint16_t);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_bayes_weak_tile, dim3((W + WT - 1) / WT, (H + WT - 1) / WT), dim3(256), lds, st, colors, mask, state, nsim, min_strong, g, sum, cnt);
+    hipLaunchKernelGGL(k_bayes_weak_tile, dim3((W + WT - 1) / WT, (H + WT - 1) / WT), dim3(256), lds, st, colors, mask, state, nsim, min_strong, g, sum, cnt, row_begin, row_end, skip_if);
     return hipGetLastError();
 }
 

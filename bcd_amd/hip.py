@@ -45,7 +45,7 @@ SYMBOLS = [
     "bcd_hip_multi_unique_id", "bcd_hip_multi_rccl_info", "bcd_hip_multi_create_rank", "bcd_hip_multi_rank_configure", "bcd_hip_multi_rank_upload", "bcd_hip_multi_rank_step",
     "bcd_hip_multi_rank_download", "bcd_hip_multi_rank_renew_ids", "bcd_hip_multi_set_loopback", "bcd_hip_multi_selftest_transport",
     "bcd_hip_scale_begin", "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_similarity_masks_deferred", "bcd_hip_similarity_masks_verdict", "bcd_hip_similarity_masks_exact", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step", "bcd_hip_active_step_enqueue", "bcd_hip_active_step_collect",
-    "bcd_hip_bayes_accumulate", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
+    "bcd_hip_bayes_accumulate", "bcd_hip_bayes_accumulate_rows", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
     "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_strip_order_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels", "bcd_hip_selftest_approx_distance", "bcd_hip_selftest_bin_work", "bcd_hip_selftest_nz_distance", "bcd_hip_eig27_batch",
 ]

@@ -288,6 +288,16 @@ int bcd_hip_bayes_accumulate(bcd_hip_ctx *ctx, const float *d_colors, const floa
                              const uint32_t *d_mask, const int32_t *d_nsim, const uint8_t *d_state,
                              int W, int H, int patch_radius, int search_radius, float min_eigen_value,
                              float *d_sum, int32_t *d_count);
+/* The same for the processed pixels of lines [row_begin, row_end) only (a row band's owned lines), optionally SPECULATIVE (round 6; patch radius 1):
+ * d_skip_if points at a device word that the work already enqueued on the context's stream leaves at zero when this estimate is wanted (the band
+ * driver: the all-reduced count of undecided pixels of the marking batch just enqueued), h_skip_if at the host copy of that word, copied on the same
+ * stream before this call.  The call enqueues the lists and the estimate kernels -- which do nothing when the word is not zero -- waits for ONE event
+ * (list lengths + the word) and reports *skipped = 1 if the word was not zero: the caller continues its marking and calls again. */
+int bcd_hip_bayes_accumulate_rows(bcd_hip_ctx *ctx, const float *d_colors, const float *d_pixel_cov,
+                                  const uint32_t *d_mask, const int32_t *d_nsim, const uint8_t *d_state,
+                                  int W, int H, int patch_radius, int search_radius, float min_eigen_value,
+                                  float *d_sum, int32_t *d_count, int row_begin, int row_end,
+                                  const int64_t *d_skip_if, const int64_t *h_skip_if, int *skipped);
 /* Denoiser::finalAggregation   src/core/Denoiser.cpp:458-469 */
 int bcd_hip_finalize(bcd_hip_ctx *ctx, const float *d_sum, const int32_t *d_count, int64_t npix, float *d_out);
 /* the same on `rows` lines of a row band (multi-GPU path), with the accumulator halos received from the neighbouring bands added
