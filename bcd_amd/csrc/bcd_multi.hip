@@ -128,49 +128,58 @@ struct HostBarrier {
 };
 
 // ---- CommGate: the order in which the scale threads of a rank enqueue their communication operations -------------------------
-// Every rank must enqueue the same global sequence (header).  The sequence is PHASE-major (round 4): phase 1 = everything the marking
-// needs (|S| of the boundary lines, the states and the all-reduced count of every batch; a data-dependent number of operations, but
-// the same number on every rank -- the all-reduce decides it), phase 2 = the accumulator halos:
-//     P1(scale S-1) ... P1(scale 1)  P1(scale 0)   P2(scale S-1) ... P2(scale 0)   merges
-// so a scale waits for the COARSER scales' marking before its own, never for their estimates.  Until round 4 the sequence was
-// scale-major (scale s first talked when every coarser scale was through its whole chain): the tails of the three scales of a band ran
-// one after the other, 3.5 ms for a band whose kernels take 2.7 ms (profiles/r04_band_timeline_*.txt).  The coarse scales wait with their
-// accumulator exchange until the finest scale's marking is enqueued -- they have slack.
+// Every rank must enqueue the same global sequence (header).  The sequence is PHASE-major (round 4): phase 1 = what the marking needs, phase 2 = the
+// accumulator halos, so a scale waits for the COARSER scales' marking before its own, never for their estimates (until round 4 the sequence was
+// scale-major: the tails of the three scales of a band ran one after the other, 3.5 ms for a band whose kernels take 2.7 ms,
+// profiles/r04_band_timeline_*.txt).  Round 6: phase 1 is cut in two.
+//     P1(S-1) ... P1(0)    R(S-1) ... R(0)    P2(S-1) ... P2(0)    merges
+// P1(s) = the operations of the scale's FIRST marking batch (|S| of the boundary lines, the boundary states, the all-reduced count): a fixed number of
+// operations, so the scale opens the gate for the next finer one as soon as it has ENQUEUED them -- it used to open it when its marking was complete, which
+// it only knows after the last all-reduce has come back to the host: the three marking phases of a band ran one after the other in TIME, each behind a
+// host round trip and the wake-up of the next thread, and the finest scale sat 0.16 ms behind its masks waiting for its turn
+// (profiles/r06_band_timeline_before_gate_split.txt).  R(s) = whatever the scale's marking needs beyond its first batch (further batches, a restart
+// after a rank recomputed its masks): a data-dependent number of operations, normally none, but the same number on every rank -- the all-reduce decides
+// it -- and enqueued only after every scale's P1 and the coarser scales' R, so the global sequence stays one sequence.  P2 follows every scale's R.
 struct CommGate {
     std::mutex m;
     std::condition_variable cv;
-    unsigned done1 = 0, done2 = 0; // bit s: scale s has enqueued its last operation of phase 1 / phase 2 of this frame
+    unsigned done1 = 0, doner = 0, done2 = 0; // bit s: scale s has enqueued its last operation of P1 / R / P2 of this frame
     std::atomic<bool> *abort_flag = nullptr;
-    void reset() { std::lock_guard<std::mutex> lk(m); done1 = done2 = 0; }
-    void finish1(int s)
+    void reset() { std::lock_guard<std::mutex> lk(m); done1 = doner = done2 = 0; }
+    void set(unsigned &bits, int s)
     {
-        { std::lock_guard<std::mutex> lk(m); done1 |= 1u << s; }
+        { std::lock_guard<std::mutex> lk(m); bits |= 1u << s; }
         cv.notify_all();
     }
-    void finish2(int s)
-    {
-        { std::lock_guard<std::mutex> lk(m); done2 |= 1u << s; }
-        cv.notify_all();
-    }
+    void finish1(int s) { set(done1, s); }
+    void finish_r(int s) { set(doner, s); }
+    void finish2(int s) { set(done2, s); }
     void finish(int s) // the scale leaves (normally or not): nobody waits for it any longer
     {
-        { std::lock_guard<std::mutex> lk(m); done1 |= 1u << s; done2 |= 1u << s; }
+        { std::lock_guard<std::mutex> lk(m); done1 |= 1u << s; doner |= 1u << s; done2 |= 1u << s; }
         cv.notify_all();
     }
     static unsigned coarser(int s, int S) { return ((1u << S) - 1u) & ~((2u << s) - 1u); }
-    bool wait1(int s, int S) // before the first phase-1 operation of scale s
+    template <class Pred> bool wait(Pred ready)
     {
-        const unsigned need = coarser(s, S);
         std::unique_lock<std::mutex> lk(m);
-        while ((done1 & need) != need && !abort_flag->load()) cv.wait_for(lk, std::chrono::milliseconds(50));
+        while (!ready() && !abort_flag->load()) cv.wait_for(lk, std::chrono::milliseconds(50));
         return !abort_flag->load();
     }
-    bool wait2(int s, int S) // before the phase-2 operations of scale s
+    bool wait1(int s, int S) // before the first P1 operation of scale s
+    {
+        const unsigned need = coarser(s, S);
+        return wait([&]() { return (done1 & need) == need; });
+    }
+    bool wait_r(int s, int S) // before the first R operation of scale s
     {
         const unsigned all = (1u << S) - 1u, need = coarser(s, S);
-        std::unique_lock<std::mutex> lk(m);
-        while (((done1 & all) != all || (done2 & need) != need) && !abort_flag->load()) cv.wait_for(lk, std::chrono::milliseconds(50));
-        return !abort_flag->load();
+        return wait([&]() { return (done1 & all) == all && (doner & need) == need; });
+    }
+    bool wait2(int s, int S) // before the P2 operations of scale s
+    {
+        const unsigned all = (1u << S) - 1u, need = coarser(s, S);
+        return wait([&]() { return (doner & all) == all && (done2 & need) == need; });
     }
 };
 
@@ -485,7 +494,7 @@ bool allreduce(bcd_hip_multi *m, int rank, int ch, long long *value)
 }
 
 // RCCL transport: the rank's contribution is already in d_red[rank][ch], produced on the channel's stream (bcd_hip_active_step_enqueue); the sum over
-// all ranks is copied to h_red[rank][ch] in stream order; the caller synchronises (allreduce_device does, for callers with nothing else to enqueue)
+// all ranks is copied to h_red[rank][ch] in stream order; the caller synchronises the stream (or an event behind the copy) before it reads it
 bool allreduce_device_enqueue(bcd_hip_multi *m, int rank, int ch)
 {
     trace_op(m, rank, ch, 1, 0, 0);
@@ -498,14 +507,6 @@ bool allreduce_device_enqueue(bcd_hip_multi *m, int rank, int ch)
     }
     if (r != ncclSuccess) { fail(m, std::string("RCCL all-reduce failed: ") + ncclGetErrorString(r)); return false; }
     MCHK(m, rank, hipMemcpyAsync(m->h_red[rank][ch], m->d_red[rank][ch], sizeof(long long), hipMemcpyDeviceToHost, st));
-    return true;
-}
-
-bool allreduce_device(bcd_hip_multi *m, int rank, int ch, long long *value)
-{
-    if (!allreduce_device_enqueue(m, rank, ch)) return false;
-    MCHK(m, rank, hipStreamSynchronize(m->stream[rank][ch]));
-    *value = *m->h_red[rank][ch];
     return true;
 }
 
@@ -587,7 +588,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
     }
     const bool talk = g.world > 1 || m->loopback; // (loopback: one rank that exchanges with itself, see bcd_hip_multi::loopback)
     const bool gated = m->ordered && talk;
-    if (gated && !m->gate[rank].wait1(s, g.S)) return false; // phase 1 of this scale: after the coarser scales' marking
+    if (gated && !m->gate[rank].wait1(s, g.S)) return false; // P1 of this scale: after the coarser scales' P1
     int rounds = 0;
     const long long REDO = 1ll << 40; // added to the all-reduced count of undecided pixels by a rank whose masks are not valid
     // Round 6: on the RCCL transport with 3 x 3 patches the estimate is enqueued BEHIND every marking batch and its all-reduce, valid only if the
@@ -596,9 +597,18 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
     // each time with an empty queue behind it.
     const bool speculate = marking && talk && m->use_rccl && w == 1;
     bool estimated = false;
+    // CommGate: the operations of the first batch are P1, everything after them R
+    bool in_p1 = true, in_r = false;
+    auto end_p1 = [&]() { if (in_p1) { in_p1 = false; m->gate[rank].finish1(s); } };
+    auto before_op = [&]() -> bool { // called before every communication operation of the marking
+        if (in_p1 || in_r || !gated) return true;
+        in_r = true;
+        return m->gate[rank].wait_r(s, g.S);
+    };
     for (;;) { // the marking problem; once more from the start if some rank has to recompute its masks
         if (marking && talk) {
             // |S| of the b boundary lines comes from their owner (locally their windows are cut by the band edge)
+            if (!before_op()) return false;
             if (!exchange(m, rank, s, nsim + (size_t)r0 * W, up ? nsim + (size_t)(r0 - b) * W : nullptr, (size_t)b * W * 4,
                           nsim + (size_t)(r1 - b) * W, down ? nsim + (size_t)r1 * W : nullptr, (size_t)b * W * 4)) return false;
         }
@@ -608,23 +618,25 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
         if (marking) {
             long long before = -1;
             for (;;) {
+                if (talk && !before_op()) return false;
                 if (talk && !exchange(m, rank, s, state + (size_t)r0 * W, up ? state + (size_t)(r0 - b) * W : nullptr, (size_t)b * W,
                                              state + (size_t)(r1 - b) * W, down ? state + (size_t)r1 * W : nullptr, (size_t)b * W)) return false;
-                // Round 6: one synchronisation per batch instead of two.  The batch leaves the rank's contribution (undecided pixels, + REDO when its
-                // masks are not valid: the same test on the device) in the all-reduce buffer, the all-reduce and the copy of its result follow in stream
-                // order, and the host waits once.
+                // Round 6: one synchronisation per batch.  The batch leaves the rank's contribution (undecided pixels, + REDO when its masks are not
+                // valid: the same test on the device) in the all-reduce buffer; the all-reduce and the copy of its result follow in stream order.
                 long long total = 0;
                 if (talk && m->use_rccl) {
                     ECHK(m, rank, c, bcd_hip_active_step_enqueue(c, mask, nsim, W, rows, w, b, r0, r1, job.prm.use_random_pixel_order, seed, row_offset, state,
                                                                  reinterpret_cast<int64_t *>(m->d_red[rank][s]), verdict_known ? 0 : 1));
+                    if (!allreduce_device_enqueue(m, rank, s)) return false;
+                    end_p1(); // the first batch is in the queue: the next finer scale may enqueue its own (before this one's outcome is known)
                     if (speculate) {
-                        if (!allreduce_device_enqueue(m, rank, s)) return false;
                         int skipped = 0;
                         ECHK(m, rank, c, bcd_hip_bayes_accumulate_rows(c, col, pixcov, mask, nsim, state, W, rows, w, b, job.prm.min_eigen_value, sum, cnt, r0, r1,
                                                                        reinterpret_cast<const int64_t *>(m->d_red[rank][s]), reinterpret_cast<const int64_t *>(m->h_red[rank][s]), &skipped));
-                        total = *m->h_red[rank][s]; // (the call waited for an event behind the copy of the all-reduced word)
-                        estimated = !skipped;
-                    } else if (!allreduce_device(m, rank, s, &total)) return false; // (synchronises the scale's stream)
+                        estimated = !skipped; // (the call waited for an event behind the copy of the all-reduced word)
+                    } else
+                        MCHK(m, rank, hipStreamSynchronize(st));
+                    total = *m->h_red[rank][s];
                     int32_t undecided = 0;
                     ECHK(m, rank, c, bcd_hip_active_step_collect(c, &undecided, nullptr));
                     if (!verdict_known) { int redo = 0; ECHK(m, rank, c, bcd_hip_similarity_masks_verdict(c, &redo)); my_redo = redo != 0; }
@@ -642,6 +654,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
                         if (my_redo) total += REDO;
                     }
                     if (talk && !allreduce(m, rank, s, &total)) return false;
+                    end_p1();
                 }
                 if (!verdict_known) {
                     verdict_known = true;
@@ -655,7 +668,8 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
         if (!restart) break;
         if (my_redo) ECHK(m, rank, c, bcd_hip_similarity_masks_exact(c, hist, ns, W, rows, D, w, b, tau, mask, nsim));
     }
-    m->gate[rank].finish1(s); // the finer scales may mark; nothing of this scale is enqueued on a communicator until phase 2
+    end_p1();                   // (no marking: nothing was enqueued)
+    m->gate[rank].finish_r(s);  // the marking of this scale is complete: nothing of it is enqueued on a communicator until P2
     progress_add(m, 0.5 * (double)(r1 - r0) * W); // similar patches selected, processed set known
     // halo lines are processed by their owner: only the owned lines are listed
     if (!estimated)
@@ -663,7 +677,7 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
     // accumulator halos: the (b + w) lines written outside the owned band belong to the neighbours
     float *rx_us = (float *)B(bcd_hip_multi::RX_UP_S).p, *rx_ds = (float *)B(bcd_hip_multi::RX_DN_S).p;
     int32_t *rx_uc = (int32_t *)B(bcd_hip_multi::RX_UP_C).p, *rx_dc = (int32_t *)B(bcd_hip_multi::RX_DN_C).p;
-    if (gated && !m->gate[rank].wait2(s, g.S)) return false; // phase 2: after every scale's marking and the coarser scales' accumulators
+    if (gated && !m->gate[rank].wait2(s, g.S)) return false; // P2: after every scale's marking (P1 and R) and the coarser scales' accumulators
     if (talk) {
         Seg acc[2] = { { sum, rx_us, (size_t)halo * W * 12, sum + (size_t)(rows - halo) * W * 3, rx_ds, (size_t)halo * W * 12 },
                        { cnt, rx_uc, (size_t)halo * W * 4, cnt + (size_t)(rows - halo) * W, rx_dc, (size_t)halo * W * 4 } };

@@ -1150,19 +1150,28 @@ def test_native_multi_rank_driver_ordered_communication(hipctx, monkeypatch, ran
 
 
 def _check_phase_major_order(trace, S, W, halo):
-    """the issue order of bcd_multi.hip's CommGate: marking operations of scale S-1, ..., scale 0, then the accumulator exchange (sums + counts: halo x W x 16
-    bytes) of scale S-1, ..., scale 0, then the merges' exchanges (channel S)"""
+    """the issue order of bcd_multi.hip's CommGate (round 6):  P1(S-1) .. P1(0)  R(S-1) .. R(0)  P2(S-1) .. P2(0)  merges.  P1 of a scale = the three
+    operations of its first marking batch (|S| lines, boundary states, the all-reduced count), R = whatever its marking needed beyond them (further
+    batches; normally nothing), P2 = its accumulator exchange (sums + counts: halo x W x 16 bytes), merges = channel S"""
     chans = [ch for ch, _, _, _ in trace]
     acc = lambda i: trace[i][1] == 0 and max(trace[i][2], trace[i][3]) == halo * (W >> trace[i][0]) * 16   # sums (12 bytes per pixel) + counts (4) in one operation
     p2 = {c: [i for i in range(len(trace)) if chans[i] == c][-1:] for c in range(S)}            # the last operation of a scale's channel
     assert all(len(v) == 1 and acc(v[0]) for v in p2.values())
-    p1 = {c: [i for i in range(len(trace)) if chans[i] == c and i not in p2[c]] for c in range(S)}
+    mark = {c: [i for i in range(len(trace)) if chans[i] == c and i not in p2[c]] for c in range(S)}
+    p1 = {c: v[:3] for c, v in mark.items()}
+    rr = {c: v[3:] for c, v in mark.items()}
+    for c in range(S):
+        assert not p1[c] or [trace[i][1] for i in p1[c]] == [0, 0, 1]                           # exchange, exchange, all-reduce
+        assert not rr[c] or trace[rr[c][-1]][1] == 1                                            # a marking always ends with an all-reduce
+    flat = lambda d: [i for v in d.values() for i in v]
     for c in range(S - 1):
-        assert not p1[c] or not p1[c + 1] or max(p1[c + 1]) < min(p1[c])                       # marking: coarser scales first
+        assert not p1[c] or not p1[c + 1] or max(p1[c + 1]) < min(p1[c])                       # first batches: coarser scales first
+        assert not rr[c] or not rr[c + 1] or max(rr[c + 1]) < min(rr[c])                       # further batches: coarser scales first
         assert max(p2[c + 1]) < min(p2[c])                                                      # accumulators: coarser scales first
-    assert max([i for v in p1.values() for i in v] or [-1]) < min(i for v in p2.values() for i in v)   # every marking operation before any accumulator exchange
+    assert max(flat(p1) or [-1]) < min(flat(rr) or [len(trace)])                                # every first batch before any further batch
+    assert max(flat(p1) + flat(rr) or [-1]) < min(flat(p2))                                     # every marking operation before any accumulator exchange
     merges = [i for i in range(len(trace)) if chans[i] == S]
-    assert merges and min(merges) > max(i for v in p2.values() for i in v)                       # the merges' exchanges come last
+    assert merges and min(merges) > max(flat(p2))                                                # the merges' exchanges come last
 
 
 @pytest.mark.gpu
