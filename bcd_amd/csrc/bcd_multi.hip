@@ -612,15 +612,20 @@ bool scale_worker(const Job &job, int rank, int s, const ScaleBand *bands, bool 
             if (!exchange(m, rank, s, nsim + (size_t)r0 * W, up ? nsim + (size_t)(r0 - b) * W : nullptr, (size_t)b * W * 4,
                           nsim + (size_t)(r1 - b) * W, down ? nsim + (size_t)r1 * W : nullptr, (size_t)b * W * 4)) return false;
         }
-        ECHK(m, rank, c, bcd_hip_active_init(c, nsim, W, rows, w, r0, r1, job.prm.marked_skip_probability, seed, row_offset, state));
+        // Initial states: a function of the GLOBAL pixel index alone (skip draws), so the b boundary lines of the neighbours are initialised here like
+        // their owners initialise them -- the first batch needs no exchange of states (round 6: one communication operation less in front of every
+        // scale's marking); from the second batch on the boundary lines' states come from their owners.
+        ECHK(m, rank, c, bcd_hip_active_init(c, nsim, W, rows, w, up ? r0 - b : r0, down ? r1 + b : r1, job.prm.marked_skip_probability, seed, row_offset, state));
         rounds = 0;
         bool restart = false, my_redo = false;
         if (marking) {
             long long before = -1;
-            for (;;) {
-                if (talk && !before_op()) return false;
-                if (talk && !exchange(m, rank, s, state + (size_t)r0 * W, up ? state + (size_t)(r0 - b) * W : nullptr, (size_t)b * W,
-                                             state + (size_t)(r1 - b) * W, down ? state + (size_t)r1 * W : nullptr, (size_t)b * W)) return false;
+            for (bool first_batch = true;; first_batch = false) {
+                if (talk && !first_batch) {
+                    if (!before_op()) return false;
+                    if (!exchange(m, rank, s, state + (size_t)r0 * W, up ? state + (size_t)(r0 - b) * W : nullptr, (size_t)b * W,
+                                  state + (size_t)(r1 - b) * W, down ? state + (size_t)r1 * W : nullptr, (size_t)b * W)) return false;
+                }
                 // Round 6: one synchronisation per batch.  The batch leaves the rank's contribution (undecided pixels, + REDO when its masks are not
                 // valid: the same test on the device) in the all-reduce buffer; the all-reduce and the copy of its result follow in stream order.
                 long long total = 0;

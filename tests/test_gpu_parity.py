@@ -1150,18 +1150,19 @@ def test_native_multi_rank_driver_ordered_communication(hipctx, monkeypatch, ran
 
 
 def _check_phase_major_order(trace, S, W, halo):
-    """the issue order of bcd_multi.hip's CommGate (round 6):  P1(S-1) .. P1(0)  R(S-1) .. R(0)  P2(S-1) .. P2(0)  merges.  P1 of a scale = the three
-    operations of its first marking batch (|S| lines, boundary states, the all-reduced count), R = whatever its marking needed beyond them (further
-    batches; normally nothing), P2 = its accumulator exchange (sums + counts: halo x W x 16 bytes), merges = channel S"""
+    """the issue order of bcd_multi.hip's CommGate (round 6):  P1(S-1) .. P1(0)  R(S-1) .. R(0)  P2(S-1) .. P2(0)  merges.  P1 of a scale = the two
+    operations of its first marking batch (|S| of the boundary lines, the all-reduced count: the initial states of the neighbours' boundary lines are
+    computed locally), R = whatever its marking needed beyond them (further batches -- boundary states + all-reduce each; normally nothing), P2 = its accumulator exchange (sums + counts: halo x W x 16 bytes), merges = channel S"""
     chans = [ch for ch, _, _, _ in trace]
     acc = lambda i: trace[i][1] == 0 and max(trace[i][2], trace[i][3]) == halo * (W >> trace[i][0]) * 16   # sums (12 bytes per pixel) + counts (4) in one operation
     p2 = {c: [i for i in range(len(trace)) if chans[i] == c][-1:] for c in range(S)}            # the last operation of a scale's channel
     assert all(len(v) == 1 and acc(v[0]) for v in p2.values())
     mark = {c: [i for i in range(len(trace)) if chans[i] == c and i not in p2[c]] for c in range(S)}
-    p1 = {c: v[:3] for c, v in mark.items()}
-    rr = {c: v[3:] for c, v in mark.items()}
+    p1 = {c: v[:2] for c, v in mark.items()}
+    rr = {c: v[2:] for c, v in mark.items()}
     for c in range(S):
-        assert not p1[c] or [trace[i][1] for i in p1[c]] == [0, 0, 1]                           # exchange, exchange, all-reduce
+        assert not p1[c] or [trace[i][1] for i in p1[c]] == [0, 1]                              # exchange, all-reduce
+        assert [trace[i][1] for i in rr[c]] == [0, 1] * (len(rr[c]) // 2)                       # boundary states + all-reduce per further batch
         assert not rr[c] or trace[rr[c][-1]][1] == 1                                            # a marking always ends with an all-reduce
     flat = lambda d: [i for v in d.values() for i in v]
     for c in range(S - 1):
