@@ -176,6 +176,11 @@ struct CommGate {
         const unsigned all = (1u << S) - 1u, need = coarser(s, S);
         return wait([&]() { return (done1 & all) == all && (doner & need) == need; });
     }
+    bool wait_all_p2(int S) // before the merges' operations
+    {
+        const unsigned all = (1u << S) - 1u;
+        return wait([&]() { return (done2 & all) == all; });
+    }
     bool wait2(int s, int S) // before the P2 operations of scale s
     {
         const unsigned all = (1u << S) - 1u, need = coarser(s, S);
@@ -745,10 +750,35 @@ bool rank_compute(const Job &job, int rank)
     std::vector<char> ok(S, 1);
     bool pyramid_ok = true;
     m->gate[rank].reset();
+    auto out_rows = [&](int s, int local_line) { return (float *)B(s, bcd_hip_multi::OUT).p + (size_t)local_line * bands[s].W * 3; };
+    const bool talk = g.world > 1 || m->loopback;
+    // two lines of every unmerged finer output (hi - up(down(hi)) at the band edge), one line of the coarsest (up(lo)): scales [s_begin, s_end) in one operation
+    auto exchange_edge_lines = [&](int s_begin, int s_end) -> bool {
+        Seg lines[MAX_S];
+        for (int s = s_begin; s < s_end; ++s) {
+            const int n = s < S - 1 ? 2 : 1, o0 = bands[s].own0 - bands[s].loc0, o1 = bands[s].own1 - bands[s].loc0;
+            const size_t bytes = (size_t)n * bands[s].W * 12;
+            lines[s - s_begin] = Seg{ out_rows(s, o0), up ? out_rows(s, o0 - n) : nullptr, bytes, out_rows(s, o1 - n), down ? out_rows(s, o1) : nullptr, bytes };
+        }
+        return exchange_n(m, rank, S, lines, s_end - s_begin);
+    };
+    // mergeOutputs of scale s (MultiscaleDenoiser.cpp:453-466) on the band's lines (+ 2 at an interior edge); one line of the merged output then travels
+    auto merge_scale = [&](int s) -> bool {
+        const ScaleBand &sb = bands[s], &nb = bands[s + 1];
+        const int o0 = sb.own0 - sb.loc0, o1 = sb.own1 - sb.loc0;
+        const int m0 = up ? o0 - 2 : o0, m1 = down ? o1 + 2 : o1;
+        const int lo0 = (sb.loc0 + m0) / 2 - nb.loc0;
+        ECHK(m, rank, cm, bcd_hip_merge(cm, out_rows(s, m0), sb.W, m1 - m0, out_rows(s + 1, lo0), 3));
+        if (s > 0 && talk) {
+            const size_t bytes = (size_t)sb.W * 12;
+            if (!exchange(m, rank, S, out_rows(s, o0), up ? out_rows(s, o0 - 1) : nullptr, bytes, out_rows(s, o1 - 1), down ? out_rows(s, o1) : nullptr, bytes)) return false;
+        }
+        return true;
+    };
     auto coarse = [&]() -> bool {
         if (hipSetDevice(m->devices[rank]) != hipSuccess) { fail(m, "hipSetDevice failed"); return false; }
         std::vector<std::thread> th;
-        struct Join { std::vector<std::thread> &th; ~Join() { for (auto &t : th) t.join(); } } join{ th };
+        struct Join { std::vector<std::thread> &th; ~Join() { for (auto &t : th) if (t.joinable()) t.join(); } } join{ th };
         // ---- local pyramid (MultiscaleDenoiser.cpp:41-53)
         for (int s = 1; s < S; ++s) {
             const ScaleBand &prev = bands[s - 1], &cur = bands[s];
@@ -765,7 +795,16 @@ bool rank_compute(const Job &job, int rank)
             // (the event is recorded before the scale's thread exists: its hipStreamWaitEvent sees this frame's record)
             th.emplace_back([&, s]() { ok[s] = scale_worker(job, rank, s, bands) ? 1 : 0; });
         }
-        return true; // (the coarse scales' threads are joined on the way out; each has synchronised its stream)
+        for (auto &t : th) t.join(); // (each coarse scale has synchronised its stream)
+        for (int s = 1; s < S; ++s)
+            if (!ok[s]) return true; // (reported by the caller)
+        // Round 6: the merges among the coarse scales do not wait for the finest one.  Their exchanges come behind every scale's accumulator exchange
+        // in the global sequence (the finest scale's is enqueued long before its estimate has run), the finest scale's own merge follows in the caller.
+        if (m->ordered && talk && !m->gate[rank].wait_all_p2(S)) return false;
+        if (talk && !exchange_edge_lines(1, S)) return false;
+        for (int s = S - 2; s >= 1; --s)
+            if (!merge_scale(s)) return false;
+        return true;
     };
     {
         std::thread helper;
@@ -779,29 +818,10 @@ bool rank_compute(const Job &job, int rank)
         if (!ok[s]) { m->abort_flag.store(true); return false; }
     // the merges follow the finest scale's last kernel in stream order (the coarse scales have synchronised their streams)
     if (S > 1) MCHK(m, rank, hipStreamWaitEvent(sm, m->ev_tail[rank], 0));
-    // ---- two lines of every unmerged finer output (hi - up(down(hi)) at the band edge), one line of the coarsest (up(lo))
-    auto out_rows = [&](int s, int local_line) { return (float *)B(s, bcd_hip_multi::OUT).p + (size_t)local_line * bands[s].W * 3; };
-    const bool talk = g.world > 1 || m->loopback;
-    if (S > 1 && talk) {
-        Seg lines[MAX_S];
-        for (int s = 0; s < S; ++s) {
-            const int n = s < S - 1 ? 2 : 1, o0 = bands[s].own0 - bands[s].loc0, o1 = bands[s].own1 - bands[s].loc0;
-            const size_t bytes = (size_t)n * bands[s].W * 12;
-            lines[s] = Seg{ out_rows(s, o0), up ? out_rows(s, o0 - n) : nullptr, bytes, out_rows(s, o1 - n), down ? out_rows(s, o1) : nullptr, bytes };
-        }
-        if (!exchange_n(m, rank, S, lines, S)) return false; // the edge lines of every scale's output in one operation
-    }
-    // ---- merges coarse to fine (MultiscaleDenoiser.cpp:453-466); between two merges one line of the merged output travels
-    for (int s = S - 2; s >= 0; --s) {
-        const ScaleBand &sb = bands[s], &nb = bands[s + 1];
-        const int o0 = sb.own0 - sb.loc0, o1 = sb.own1 - sb.loc0;
-        const int m0 = up ? o0 - 2 : o0, m1 = down ? o1 + 2 : o1;
-        const int lo0 = (sb.loc0 + m0) / 2 - nb.loc0;
-        ECHK(m, rank, cm, bcd_hip_merge(cm, out_rows(s, m0), sb.W, m1 - m0, out_rows(s + 1, lo0), 3));
-        if (s > 0 && talk) {
-            const size_t bytes = (size_t)sb.W * 12;
-            if (!exchange(m, rank, S, out_rows(s, o0), up ? out_rows(s, o0 - 1) : nullptr, bytes, out_rows(s, o1 - 1), down ? out_rows(s, o1) : nullptr, bytes)) return false;
-        }
+    // ---- the finest scale's merge: its two edge lines travel, then hi -= up(down(hi)); hi += up(lo) with the (merged) scale 1
+    if (S > 1) {
+        if (talk && !exchange_edge_lines(0, 1)) return false;
+        if (!merge_scale(0)) return false;
     }
     MCHK(m, rank, hipStreamSynchronize(sm));
     if (S > 1) progress_add(m, 0.5 * (double)(bands[0].own1 - bands[0].own0) * bands[0].W); // (the finest scale's estimate: its worker did not wait for it)
