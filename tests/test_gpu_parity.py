@@ -687,6 +687,55 @@ def test_1080p_bench_workload_against_the_oracle(hipctx):
     assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL_FULL_SIZE
 
 
+def _nonuniform_full_size_check(hipctx, W, H, frame, seed, expect_paths):
+    """a frame whose sample counts are not one power of two, at a timed leg's size, 3 scales, -m 1 -r 1, against the oracle's ordered visit: the own-list
+    distance kernel and the pixel-major mask kernel serve the finest scale (similarity_path 2), a coarse scale with hundreds of samples per pixel after its
+    downscale_sums takes the decline path to the dense kernel's general formula (path 1; which scales do is a property of the frame and pinned per test),
+    and the frame is the oracle's"""
+    import bcd_amd.hip as bh
+    S = 3
+    col, ns, hist, cov = frame
+    prm = bh.default_params(m=1.0, random_order=1, seed=seed)
+    fresh = bh.Context(0)                                            # (a workspace with no memory of declined sizes: the decline path itself runs)
+    try:
+        got = fresh.denoise(*dev(col, ns, hist, cov), S, prm).cpu().numpy()
+        paths = [fresh.stats(s).similarity_path for s in range(S)]
+        full = fresh.stats(0).processed - fresh.stats(0).fallback
+    finally:
+        fresh.close()
+    assert paths == expect_paths, paths
+    assert full > 1000                                               # the full Bayesian estimate is exercised on the finest scale
+    threads = min(128, _os.cpu_count() or 1)
+    want = ol.denoise_multiscale(col, ns, hist, cov, S, ol.params(m=1.0, skip_seed=seed, threads=threads), orders=_orders(W, H, 1, 1, seed, S))
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert rel_linf(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL_FULL_SIZE
+    return paths
+
+
+@pytest.mark.gpu
+def test_1080p_24spp_frame_against_the_oracle(hipctx):
+    """bench.py's leg `nonuniform_uniform_24spp` at its full size (the general-sample-count path became production and was only checked at
+    96 x 72): 1920 x 1080, a uniform 24 samples per pixel -- not a power of two, so the count products do not drop out"""
+    import bcd_amd.core as core
+    W, H = 1920, 1080
+    _nonuniform_full_size_check(hipctx, W, H, core.synthetic_scene(W, H, 24, 1234, 0.35, 0.01), 1234, [2, 2, 1])
+
+
+@pytest.mark.gpu
+def test_1080p_mixed_sample_counts_frame_against_the_oracle(hipctx):
+    """bench.py's leg `nonuniform_mixed_16_24_32_48` at its full size: per-pixel counts drawn from {16, 24, 32, 48} (48-spp statistics thinned per pixel, as
+    bench.py builds them)"""
+    import bcd_amd.core as core
+    W, H = 1920, 1080
+    col48, ns48, hist48, cov48 = core.synthetic_scene(W, H, 48, 1234, 0.35, 0.01)
+    keep = np.random.default_rng(5).choice(np.array([1.0 / 3.0, 0.5, 2.0 / 3.0, 1.0], np.float32), size=(H, W, 1)).astype(np.float32)
+    ns_mix = np.ascontiguousarray(np.rint(ns48 * keep).astype(np.float32))
+    hist_mix = np.ascontiguousarray(hist48 * (ns_mix / ns48))
+    assert sorted(np.unique(ns_mix)) == [16.0, 24.0, 32.0, 48.0]
+    _nonuniform_full_size_check(hipctx, W, H, (col48, ns_mix, hist_mix, cov48), 1234, [2, 1, 1])
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif((_os.cpu_count() or 1) < 64 and not _os.environ.get("BCD_TEST_SLOW"), reason="the 4K oracle run needs >= 64 host cores (80 s on 128 threads of the GPU box); BCD_TEST_SLOW=1 forces it")
 def test_4k_config3_frame_against_the_oracle(hipctx):
