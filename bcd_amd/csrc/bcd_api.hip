@@ -313,7 +313,7 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(b);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
     RCCHK(ensure(ctx, wk.fwd, npix * ((nd + 31) / 32) * sizeof(uint32_t)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (wk.ev_used < MAX_EVENT_PAIRS) {
@@ -388,14 +388,14 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         BcdBorderline bl = { 0.f, (uint2 *)wk.border.p, d_flag + 3, capacity };
         // (round 5) General sample counts (adaptive sampling, 24 spp, ...; src/core/DenoisingUnit.cpp:371-383 handles any n1, n2): the own-list kernel
         // evaluates them at the cost of uniform ones (1.9 - 2.0 ms at 1080p against 2.9 - 3.0 ms for the dense kernel's general formula).
-        // Its planes are pixel-major and have a mask kernel of their own.  It raises flag bit 2 when its absolute-error check fails (coarse scales of
+        // Its planes are pixel-major (two aligned records per pixel, round 6) and have a mask kernel of their own.  It raises flag bit 2 when its absolute-error check fails (coarse scales of
         // frames with hundreds of samples per pixel): the pass is then repeated with the dense kernel, and the workspace remembers.
         const bool use_nz = !pre && uni_n == 0.f && !wk.nz_is_declined(W, H) && bcd_pairdist_nz_supported(D, b) && npix * (size_t)nd < ((size_t)1 << 31);
         wk.nz_used = use_nz;
         if (pre) { if (e0) --wk.ev_used; } // (nothing to time: the planes are there)
         else if (use_nz) {
             if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
-            HIPCHK(ctx, bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, (long long)nd, 1, d_flag, tau, 3, wk.stream));
+            HIPCHK(ctx, bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, 0, 0, d_flag, tau, 3, wk.stream));
             if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
         } else {
             if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
@@ -1616,12 +1616,12 @@ int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, con
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     float *T2 = nullptr;
     uint8_t *C2 = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&T2, npix * nd * sizeof(float)));
-    if (hipMalloc((void **)&C2, npix * nd) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
+    if (hipMalloc((void **)&C2, npix * std::max(nd, 96)) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
     int rc = BCD_HIP_OK;
     do {
         int *d_flag = (int *)wk.counters.p + 40;
@@ -1675,7 +1675,7 @@ int bcd_hip_selftest_bin_work(bcd_hip_ctx *ctx, const float *d_hist, const float
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int *d_flag = (int *)wk.counters.p + 40;
     unsigned long long *d_work = reinterpret_cast<unsigned long long *>((int32_t *)wk.counters.p + 48); // (8-byte aligned: words 48..53)
@@ -1726,12 +1726,12 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     float *T2 = nullptr;
     uint8_t *C2 = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&T2, npix * nd * sizeof(float)));
-    if (hipMalloc((void **)&C2, npix * nd) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
+    if (hipMalloc((void **)&C2, npix * std::max(nd, 96)) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
     int rc = BCD_HIP_OK;
     do {
         int *d_flag = (int *)wk.counters.p + 40;
@@ -1782,12 +1782,12 @@ int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const fl
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * nd));
+    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     float *T2 = nullptr;
     uint8_t *C2 = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&T2, npix * nd * sizeof(float)));
-    if (hipMalloc((void **)&C2, npix * nd) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
+    if (hipMalloc((void **)&C2, npix * std::max(nd, 96)) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = BCD_HIP_OK;
     do {
@@ -1815,7 +1815,7 @@ int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const fl
             for (int r = 0; r < reps + 1; ++r) {
                 hipError_t e = hipEventRecord(e0, wk.stream);
                 if (e == hipSuccess) {
-                    if (which == 0) e = bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, T2, C2, (long long)nd, 1, d_flag, tau, variant, wk.stream);
+                    if (which == 0) e = bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, 0, d_flag, tau, variant, wk.stream); // (the production layout)
                     else if (which == 1) e = bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, 1, (long long)npix, d_flag, tau, variant, wk.stream);
                     else e = bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag + 1, which == 2 ? -1.f : 0.f, wk.stream);
                 }
@@ -1831,7 +1831,7 @@ int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const fl
             float ms = 0.f;
             for (int r = 0; r < 2 && rc == BCD_HIP_OK; ++r)
                 if (hipMemsetAsync(d_prof, 0, sizeof(hp), wk.stream) != hipSuccess || hipEventRecord(e0, wk.stream) != hipSuccess ||
-                    bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, T2, C2, (long long)nd, 1, d_flag, tau, variant, wk.stream, d_prof) != hipSuccess ||
+                    bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, 0, d_flag, tau, variant, wk.stream, d_prof) != hipSuccess ||
                     hipEventRecord(e1, wk.stream) != hipSuccess ||
                     hipMemcpyAsync(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost, wk.stream) != hipSuccess || hipStreamSynchronize(wk.stream) != hipSuccess) rc = BCD_HIP_EDEVICE;
             if (rc != BCD_HIP_OK) break;

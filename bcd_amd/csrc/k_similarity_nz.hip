@@ -227,7 +227,17 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
     const int dlB = (ipB + NZ_B) / NZ_SIDE, dcB = ipB - NZ_SIDE * dlB; // (ipB == 0: dl = dc = 0)
     const int ownB = jB * PS, offB = ownB + dlB * RS + dcB * PS, spB = jB + dlB * NZ_NCS + dcB;
     const float margin = NZ_ABS_MARGIN * tau * 16777216.f; // (the bound is formed in units of u = 2^-24)
-    const unsigned int eA = (unsigned int)ipA * (unsigned int)t_ds, eB = (unsigned int)ipB * (unsigned int)t_ds; // (plane elements fit 32 bits: checked by the launcher)
+    // where the lane's entry goes: element = base + pixel * mult (plane elements fit 32 bits: checked by the launcher).  t_ds != 0: the general form
+    // (displacement i at i * t_ds + pixel * t_ps).  t_ds == 0: the SPLIT pixel-major layout the production path uses (round 6) -- two records per pixel, each
+    // aligned to its size: record A = 64 entries (displacements 0..63) at pixel * 64, record B = 32 entries at W H 64 + pixel * 32 holding displacements
+    // 65..84 at positions 0..19 and displacement 64 at position 20.  An A item's store is then one aligned 128-byte line (T) / 64 bytes (counts), and the
+    // mask kernel's two passes read disjoint lines (with the 85-entry records of round 5 both passes fetched nearly every line of the planes).
+    const bool split = t_ds == 0;
+    const unsigned int npix_all = (unsigned int)W * (unsigned int)H;
+    const unsigned int baseA = split ? (lane < 63 ? (unsigned int)ipA : npix_all * 64u + 20u) : (unsigned int)ipA * (unsigned int)t_ds;
+    const unsigned int multA = split ? (lane < 63 ? 64u : 32u) : (unsigned int)t_ps;
+    const unsigned int baseB = split ? (lane < 60 ? npix_all * 64u + (unsigned int)(ipB - 65) : 0u) : (unsigned int)ipB * (unsigned int)t_ds;
+    const unsigned int multB = split ? (lane < 60 ? 32u : 64u) : (unsigned int)t_ps;
 
     auto grab = [&]() __attribute__((always_inline)) {
         int v = 0;
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
                     // (the bound of the header with the larger of its two factors on every term; the count-ratio term only where a bin was live)
                     const float bound = fmaf((float)(max(Ln, C1y) + 10), fmaf(qq, A1, rho * (Sy + A2)), Tv + ((Cm > 0 || A2 > 0.f) ? extra : 0.f));
                     imprecise = imprecise || bound > margin * (float)C;
-                    const unsigned int e = eA + pix * (unsigned int)t_ps;
+                    const unsigned int e = baseA + pix * multA;
                     T[e] = __float2half_rn(fmaxf(Tv, 0.f));
                     Cn[e] = (uint8_t)C;
                 }
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
                     // (the bound of the header with the larger of its two factors on every term; the count-ratio term only where a bin was live)
                     const float bound = fmaf((float)(max(Ln, C1y) + 10), fmaf(qq, A1, rho * (Sy + A2)), Tv + ((Cm > 0 || A2 > 0.f) ? extra : 0.f));
                     imprecise = imprecise || bound > margin * (float)C;
-                    const unsigned int e = eB + pix * (unsigned int)t_ps;
+                    const unsigned int e = baseB + pix * multB;
                     T[e] = __float2half_rn(fmaxf(Tv, 0.f));
                     Cn[e] = (uint8_t)C;
                 }
@@ -326,54 +336,59 @@ __global__ __launch_bounds__(NZ_THREADS, 4) void k_pairdist_nz(const float *__re
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Forward similarity bits from PIXEL-major planes (element (pixel, displacement i) at pixel * 85 + i: what k_pairdist_nz writes with
-// t_ps = 85, t_ds = 1).  Lanes = displacements, so the 3 x 3 patch sum of a displacement stays in one lane: a wavefront walks along a
-// strip of FWD_PM_RB lines, loads per column the FWD_PM_RB + 2 plane lines of its displacement (one coalesced 128-byte + 64-byte read per
-// line), keeps the last two columns in registers, and decides a column of FWD_PM_RB pixels per step -- any summation order: these are the
+// Forward similarity bits from the SPLIT PIXEL-major planes k_pairdist_nz writes with (t_ps, t_ds) = (0, 0): per pixel a record A of 64 entries
+// (displacements 0..63, at pixel * 64) and a record B of 32 entries (at W H 64 + pixel * 32: displacements 65..84 at positions 0..19, displacement 64 at
+// position 20).  Lanes = displacements, so the 3 x 3 patch sum of a displacement stays in one lane: a wavefront walks along a
+// strip of FWD_PM_RB lines, loads per column the FWD_PM_RB + 2 plane lines of its displacement (one aligned 128-byte line + 64 bytes per pixel in pass 0),
+// keeps the last columns in registers, and decides a column of FWD_PM_RB pixels per step -- any summation order: these are the
 // approximate planes, pairs inside tau (1 +- delta) go to the borderline list exactly like in k_fwd_masks_w1 (k_similarity.hip).
-//   CHUNK 0: displacements 0..63 of one strip (words 0 and 1 of the pixel's three forward words come straight from the ballot);
-//   CHUNK 1: displacements 64..84 of three strips (lanes 21 j .. 21 j + 20 = strip 3 blockIdx.x + j; word 2).
+//   CHUNK 0: record A of one strip (words 0 and 1 of the pixel's three forward words come straight from the ballot);
+//   CHUNK 1: record B of three strips (lanes 21 j .. 21 j + 20 = strip 3 blockIdx.x + j; word 2).
 // ---------------------------------------------------------------------------------------------------
-constexpr int FWD_PM_RB = 4, FWD_PM_ND = NZ_SIDE * NZ_B + NZ_B + 1; // 85
+constexpr int FWD_PM_RB = 4;
 
+// Round 6: a workgroup is FWD_PM_WV wavefronts on vertically adjacent strips of lines, marching along the same columns: the two plane lines a strip shares
+// with the next one are fetched by both within the same few hundred cycles and come out of the CU's L1 the second time (as single-wavefront workgroups the
+// two readers sat on different XCDs and both went to HBM: 6 lines read per 4 decided), and the column strips are 32 wide (4 warm-up columns per strip).
+constexpr int FWD_PM_WV = 4;
+#define FWD_PM_REC (CHUNK == 0 ? 64u : 32u)
 template <int CHUNK>
-__global__ __launch_bounds__(64) void k_fwd_masks_pm(const __half *__restrict__ T, const uint8_t *__restrict__ Cn, int W, int H, float tau_lo,
+__global__ __launch_bounds__(64 * FWD_PM_WV) void k_fwd_masks_pm( /* FWD_PM_REC: entries per pixel of the record this pass reads */const __half *__restrict__ T, const uint8_t *__restrict__ Cn, int W, int H, float tau_lo,
                                                      BcdBorderline bl, uint32_t *__restrict__ fwd, int strip_cols, int nstrips)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int sub = CHUNK == 0 ? 0 : lane / 21;
-    const int idx = CHUNK == 0 ? lane : 64 + (lane - 21 * sub);
+    const int pos = CHUNK == 0 ? lane : lane - 21 * sub;                     // position inside the pixel's record A (64 entries) / record B (32 entries)
+    const int idx = CHUNK == 0 ? lane : (pos < 20 ? 65 + pos : 64);          // the displacement it holds (k_pairdist_nz, split layout)
     const int strip = CHUNK == 0 ? (int)blockIdx.x : 3 * (int)blockIdx.x + sub;
     const bool lane_on = (CHUNK == 0 || lane < 63) && strip < nstrips;
     const int dl = (idx + NZ_B) / NZ_SIDE, dc = idx - NZ_SIDE * dl; // (idx 0: the self pair)
-    const int rb = blockIdx.y * FWD_PM_RB;
+    const int rb = (blockIdx.y * FWD_PM_WV + (threadIdx.x >> 6)) * FWD_PM_RB;
+    if (rb >= H) return; // (no barriers in this kernel)
     const int cs = min(strip, nstrips - 1) * strip_cols, ce = min(W, cs + strip_cols);
     const int ncols = strip_cols; // (uniform loop bound; columns beyond a strip's end are gated by c < ce)
     unsigned int line_off[FWD_PM_RB + 2];
 #pragma unroll
-    for (int i = 0; i < FWD_PM_RB + 2; ++i) line_off[i] = (unsigned int)(min(max(rb - 1 + i, 0), H - 1) * W) * FWD_PM_ND + idx;
-    // the plane values of three consecutive columns live in registers (t0 | t1 | t2 = columns c - 1 | c | c + 1 of the step that decides column c);
-    // the loads of columns c + 2 and c + 3 are in flight meanwhile, so a step never waits for loads it has just issued
-    float t0[FWD_PM_RB + 2], t1[FWD_PM_RB + 2], t2[FWD_PM_RB + 2];
-    int n0[FWD_PM_RB + 2], n1[FWD_PM_RB + 2], n2[FWD_PM_RB + 2];
+    for (int i = 0; i < FWD_PM_RB + 2; ++i) line_off[i] = (CHUNK == 0 ? 0u : (unsigned int)(W * H) * 64u) + (unsigned int)(min(max(rb - 1 + i, 0), H - 1) * W) * FWD_PM_REC + pos;
+    // The plane values of four consecutive columns live in registers: a step decides column c from columns c - 1 | c | c + 1, column c + 2 is in flight, and
+    // the loads of column c + 3 are issued into the registers of column c - 1 as soon as its sums are taken.  The four register sets ROTATE BY NAME (the
+    // loop body is four steps, round 6): until then every step ended with `t0 = t1; t1 = t2; ... t3 = t4`, and a move out of a register a load is still
+    // writing waits for that load -- each step waited for the loads it had just issued, 1.5 us of exposed memory latency per column.
+    float tA[FWD_PM_RB + 2], tB[FWD_PM_RB + 2], tC[FWD_PM_RB + 2], tD[FWD_PM_RB + 2];
+    int nA[FWD_PM_RB + 2], nB[FWD_PM_RB + 2], nC[FWD_PM_RB + 2], nD[FWD_PM_RB + 2];
     auto load = [&](int c, float (&t)[FWD_PM_RB + 2], int (&n)[FWD_PM_RB + 2]) __attribute__((always_inline)) {
-        const unsigned int co = (unsigned int)min(max(c, 0), W - 1) * FWD_PM_ND;
+        const unsigned int co = (unsigned int)min(max(c, 0), W - 1) * FWD_PM_REC;
 #pragma unroll
         for (int i = 0; i < FWD_PM_RB + 2; ++i) { t[i] = __half2float(T[line_off[i] + co]); n[i] = Cn[line_off[i] + co]; }
     };
-    float t3[FWD_PM_RB + 2];
-    int n3[FWD_PM_RB + 2];
-    load(cs - 1, t0, n0);
-    load(cs, t1, n1);
-    load(cs + 1, t2, n2);
-    load(cs + 2, t3, n3);
-    for (int step = 0; step < ncols; ++step) {
-        const int c = cs + step; // the column decided in this step
-        float t4[FWD_PM_RB + 2], h[FWD_PM_RB + 2];
-        int n4[FWD_PM_RB + 2], hn[FWD_PM_RB + 2];
-        load(c + 3, t4, n4); // (two columns ahead of the last one this step reads: 24 loads in flight per lane)
+    // one step: decide column c from (p | q | r) = columns (c - 1 | c | c + 1); afterwards p holds column c + 3
+    auto step = [&](int c, float (&tp)[FWD_PM_RB + 2], int (&np)[FWD_PM_RB + 2], const float (&tq)[FWD_PM_RB + 2], const int (&nq)[FWD_PM_RB + 2],
+                    const float (&tr)[FWD_PM_RB + 2], const int (&nr)[FWD_PM_RB + 2]) __attribute__((always_inline)) {
+        float h[FWD_PM_RB + 2];
+        int hn[FWD_PM_RB + 2];
 #pragma unroll
-        for (int i = 0; i < FWD_PM_RB + 2; ++i) { h[i] = (t0[i] + t1[i]) + t2[i]; hn[i] = n0[i] + n1[i] + n2[i]; }
+        for (int i = 0; i < FWD_PM_RB + 2; ++i) { h[i] = (tp[i] + tq[i]) + tr[i]; hn[i] = np[i] + nq[i] + nr[i]; }
+        load(c + 3, tp, np);
         const int qc = c + dc;
         const bool cols_ok = lane_on && c < ce && c >= 1 && c <= W - 2 && qc >= 1 && qc <= W - 2;
 #pragma unroll
@@ -390,7 +405,9 @@ __global__ __launch_bounds__(64) void k_fwd_masks_pm(const __half *__restrict__ 
                 if (CHUNK == 0) {
                     if (lane < 2 && c < ce) fwd[(size_t)(r * W + c) * 3 + lane] = lane ? (uint32_t)(ms >> 32) : (uint32_t)ms;
                 } else {
-                    if (lane < 63 && lane == 21 * sub && strip < nstrips && c < ce) fwd[(size_t)(r * W + c) * 3 + 2] = (uint32_t)(ms >> (21 * sub)) & 0x1fffffu;
+                    // word 2 of the pixel: bit 0 = displacement 64 (position 20 of the record), bits 1..20 = displacements 65..84 (positions 0..19)
+                    const uint32_t bits = (uint32_t)(ms >> (21 * sub)) & 0x1fffffu;
+                    if (lane < 63 && lane == 21 * sub && strip < nstrips && c < ce) fwd[(size_t)(r * W + c) * 3 + 2] = ((bits & 0xfffffu) << 1) | (bits >> 20);
                 }
             }
             if (mb != 0ull) { // (rare) append the borderline pairs of this line: one atomic per wavefront
@@ -404,8 +421,16 @@ __global__ __launch_bounds__(64) void k_fwd_masks_pm(const __half *__restrict__ 
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < FWD_PM_RB + 2; ++i) { t0[i] = t1[i]; t1[i] = t2[i]; t2[i] = t3[i]; t3[i] = t4[i]; n0[i] = n1[i]; n1[i] = n2[i]; n2[i] = n3[i]; n3[i] = n4[i]; }
+    };
+    load(cs - 1, tA, nA);
+    load(cs, tB, nB);
+    load(cs + 1, tC, nC);
+    load(cs + 2, tD, nD);
+    for (int c = cs; c < cs + ncols; c += 4) { // (ncols is a multiple of four; columns beyond a strip's end are gated by c < ce)
+        step(c, tA, nA, tB, nB, tC, nC);
+        step(c + 1, tB, nB, tC, nC, tD, nD);
+        step(c + 2, tC, nC, tD, nD, tA, nA);
+        step(c + 3, tD, nD, tA, nA, tB, nB);
     }
 }
 
@@ -414,11 +439,11 @@ __global__ __launch_bounds__(64) void k_fwd_masks_pm(const __half *__restrict__ 
 int bcd_pairdist_nz_supported(int D, int b) { return b == NZ_B && (D == 60 || D == 36 || D == 24); }
 
 // T / Cn element (pixel, displacement index i) lives at i * t_ds + pixel * t_ps: (1, W*H) is the plane-major layout of k_pairdist_rw,
-// (stride >= 85, 1) a pixel-major one.  variant: bit 0 = own bins by v_readlane instead of scalar loads, bit 1 = straight-line bin body
+// (stride >= 85, 1) a pixel-major one; (0, 0) selects the split pixel-major layout k_fwd_masks_pm reads (96 entries per pixel: see the kernel).  variant: bit 0 = own bins by v_readlane instead of scalar loads, bit 1 = straight-line bin body
 hipError_t bcd_launch_pairdist_nz(const float *hist, const float *ns, int W, int H, int D, int b, void *T, uint8_t *Cn, long long t_ps, long long t_ds,
                                   int *d_range_flag, float tau, int variant, hipStream_t st, unsigned long long *prof = nullptr)
 {
-    if (!bcd_pairdist_nz_supported(D, b) || (long long)W * H * (NZ_SIDE * NZ_B + NZ_B + 1) >= (1ll << 31)) return hipErrorInvalidValue;
+    if (!bcd_pairdist_nz_supported(D, b) || (long long)W * H * 96 >= (1ll << 31)) return hipErrorInvalidValue;
     const int tx = (W + NZ_TC - 1) / NZ_TC, ty = (H + NZ_TR - 1) / NZ_TR;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
@@ -460,15 +485,15 @@ hipError_t bcd_launch_pairdist_nz(const float *hist, const float *ns, int W, int
     return hipErrorInvalidValue;
 }
 
-// forward bits from the pixel-major planes of bcd_launch_pairdist_nz (t_ps = 85, t_ds = 1); ap: the borderline list (tau_hi is set here)
+// forward bits from the split pixel-major planes of bcd_launch_pairdist_nz (t_ps = t_ds = 0); ap: the borderline list (tau_hi is set here)
 hipError_t bcd_launch_fwd_masks_pm(const void *T, const uint8_t *Cn, int W, int H, float tau, uint32_t *fwd, const BcdBorderline *ap, hipStream_t st)
 {
     if (!ap) return hipErrorInvalidValue;
     BcdBorderline bl = *ap;
     bl.tau_hi = tau * (1.f + BCD_APPROX_DELTA);
     const float tau_lo = tau * (1.f - BCD_APPROX_DELTA);
-    const int strip_cols = 16, nstrips = (W + strip_cols - 1) / strip_cols, nrb = (H + FWD_PM_RB - 1) / FWD_PM_RB;
-    hipLaunchKernelGGL(k_fwd_masks_pm<0>, dim3(nstrips, nrb), dim3(64), 0, st, static_cast<const __half *>(T), Cn, W, H, tau_lo, bl, fwd, strip_cols, nstrips);
-    hipLaunchKernelGGL(k_fwd_masks_pm<1>, dim3((nstrips + 2) / 3, nrb), dim3(64), 0, st, static_cast<const __half *>(T), Cn, W, H, tau_lo, bl, fwd, strip_cols, nstrips);
+    const int strip_cols = 32, nstrips = (W + strip_cols - 1) / strip_cols, nrb = ((H + FWD_PM_RB - 1) / FWD_PM_RB + FWD_PM_WV - 1) / FWD_PM_WV;
+    hipLaunchKernelGGL(k_fwd_masks_pm<0>, dim3(nstrips, nrb), dim3(64 * FWD_PM_WV), 0, st, static_cast<const __half *>(T), Cn, W, H, tau_lo, bl, fwd, strip_cols, nstrips);
+    hipLaunchKernelGGL(k_fwd_masks_pm<1>, dim3((nstrips + 2) / 3, nrb), dim3(64 * FWD_PM_WV), 0, st, static_cast<const __half *>(T), Cn, W, H, tau_lo, bl, fwd, strip_cols, nstrips);
     return hipGetLastError();
 }
