@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -176,6 +177,19 @@ struct bcd_hip_ctx {
     void *progress_user = nullptr;
     std::mutex progress_mutex;
     double progress_done = 0.0, progress_total = 0.0;
+    // bcd_hip_denoise_begin / _wait (round 6): one frame of this context in flight on a worker thread of its own, so that a caller can keep a second
+    // context busy meanwhile (frames of a sequence, AOV passes: the distance kernels of one frame fill the chip under the latency-bound tail of another)
+    struct Async {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        bool has_job = false, in_flight = false, quit = false;
+        int rc = 0;
+        const float *col = nullptr, *ns = nullptr, *hist = nullptr, *cov = nullptr;
+        float *out = nullptr;
+        int W = 0, H = 0, D = 0, S = 0;
+        bcd_hip_params prm;
+    } async;
 };
 
 namespace {
@@ -940,6 +954,11 @@ int bcd_hip_ctx_create(bcd_hip_ctx **out, int device, void *hip_stream)
 void bcd_hip_ctx_destroy(bcd_hip_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->async.th.joinable()) { // (a frame still in flight is finished first)
+        { std::lock_guard<std::mutex> lk(ctx->async.mu); ctx->async.quit = true; }
+        ctx->async.cv.notify_all();
+        ctx->async.th.join();
+    }
     DeviceGuard guard(ctx);
     (void)hipDeviceSynchronize();
     work_destroy(ctx->main);
@@ -1144,6 +1163,48 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, 
         if (s < nb_scales - 1) RCCHK(bcd_hip_merge(ctx, out[s], ws[s], hh[s], out[s + 1], 3));
     }
     return BCD_HIP_OK;
+}
+
+int bcd_hip_denoise_begin(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov,
+                          int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *d_out)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    if (!d_colors || !d_ns || !d_hist || !d_cov || !d_out) return bad(ctx, "null image pointer");
+    RCCHK(check_params(ctx, W, H, D, prm));
+    if (nb_scales < 1 || nb_scales > MAX_SCALES) return bad(ctx, "bad number of scales");
+    bcd_hip_ctx::Async &a = ctx->async;
+    std::unique_lock<std::mutex> lk(a.mu);
+    if (a.in_flight) return bad(ctx, "a frame of this context is already in flight: call bcd_hip_denoise_wait first");
+    a.col = d_colors; a.ns = d_ns; a.hist = d_hist; a.cov = d_cov; a.out = d_out; a.W = W; a.H = H; a.D = D; a.S = nb_scales; a.prm = *prm;
+    a.has_job = true; a.in_flight = true; a.rc = BCD_HIP_OK;
+    if (!a.th.joinable())
+        a.th = std::thread([ctx]() {
+            bcd_hip_ctx::Async &j = ctx->async;
+            std::unique_lock<std::mutex> l(j.mu);
+            for (;;) {
+                j.cv.wait(l, [&]() { return j.has_job || j.quit; });
+                if (!j.has_job) return; // (quit)
+                j.has_job = false;
+                l.unlock();
+                const int rc = bcd_hip_denoise(ctx, j.col, j.ns, j.hist, j.cov, j.W, j.H, j.D, j.S, &j.prm, j.out); // (synchronises the context's streams)
+                l.lock();
+                j.rc = rc;
+                j.in_flight = false;
+                j.cv.notify_all();
+            }
+        });
+    lk.unlock();
+    a.cv.notify_all();
+    return BCD_HIP_OK;
+}
+
+int bcd_hip_denoise_wait(bcd_hip_ctx *ctx)
+{
+    if (!ctx) return BCD_HIP_EINVAL;
+    bcd_hip_ctx::Async &a = ctx->async;
+    std::unique_lock<std::mutex> lk(a.mu);
+    a.cv.wait(lk, [&]() { return !a.in_flight; });
+    return a.rc;
 }
 
 int bcd_hip_denoise_band(bcd_hip_ctx *ctx, const float *d_colors, const float *d_ns, const float *d_hist, const float *d_cov,

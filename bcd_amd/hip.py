@@ -40,7 +40,7 @@ class ScaleStats(C.Structure):
 SYMBOLS = [
     "bcd_hip_ctx_create", "bcd_hip_ctx_destroy", "bcd_hip_last_error", "bcd_hip_device_count", "bcd_hip_default_params",
     "bcd_hip_set_profiling", "bcd_hip_set_concurrent_scales", "bcd_hip_set_fast_similarity", "bcd_hip_set_strict_eigensolver", "bcd_hip_set_cu_share", "bcd_hip_get_stats", "bcd_hip_kernel_time", "bcd_hip_reset_kernel_time",
-    "bcd_hip_denoise", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_last_upload_bytes", "bcd_hip_selftest_pack32", "bcd_hip_set_progress_callback",
+    "bcd_hip_denoise", "bcd_hip_denoise_begin", "bcd_hip_denoise_wait", "bcd_hip_denoise_band", "bcd_hip_denoise_bands", "bcd_hip_denoise_host", "bcd_hip_denoise_host_ex", "bcd_hip_last_upload_bytes", "bcd_hip_selftest_pack32", "bcd_hip_set_progress_callback",
     "bcd_hip_multi_create", "bcd_hip_multi_destroy", "bcd_hip_multi_last_error", "bcd_hip_multi_get_stats", "bcd_hip_multi_set_progress_callback", "bcd_hip_multi_set_frame_timeout", "bcd_hip_multi_set_comm_trace", "bcd_hip_multi_get_comm_trace", "bcd_hip_multi_denoise_host",
     "bcd_hip_multi_unique_id", "bcd_hip_multi_rccl_info", "bcd_hip_multi_create_rank", "bcd_hip_multi_rank_configure", "bcd_hip_multi_rank_upload", "bcd_hip_multi_rank_step",
     "bcd_hip_multi_rank_download", "bcd_hip_multi_rank_renew_ids", "bcd_hip_multi_set_loopback", "bcd_hip_multi_selftest_transport",
@@ -128,6 +128,18 @@ class Context:
         if out is None:
             out = torch.empty((H, W, 3), dtype=torch.float32, device=hist.device)
         self._chk(lib().bcd_hip_denoise(self.h, _dp(col), _dp(ns), _dp(hist), _dp(cov), W, H, D, nscales, C.byref(prm), _dp(out)))
+        return out
+
+    def denoise_begin(self, col, ns, hist, cov, nscales, prm, out):
+        """bcd_hip_denoise_begin: returns at once; the tensors must stay alive and untouched until denoise_wait()"""
+        H, W, D = hist.shape
+        self._chk(lib().bcd_hip_denoise_begin(self.h, _dp(col), _dp(ns), _dp(hist), _dp(cov), W, H, D, nscales, C.byref(prm), _dp(out)))
+        self._inflight = (col, ns, hist, cov, out, prm)   # (kept alive until denoise_wait; a refused call leaves the frame in flight alone)
+
+    def denoise_wait(self):
+        self._chk(lib().bcd_hip_denoise_wait(self.h))
+        out = self._inflight[4] if getattr(self, "_inflight", None) else None
+        self._inflight = None
         return out
 
     def denoise_band(self, col, ns, hist, cov, row_begin, row_end, prm, seed, sum_, cnt):

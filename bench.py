@@ -443,6 +443,38 @@ def main():
         extras["textured_low_noise"] = dict(tex_low, workload="the textured frame with sigma 0.10, no spikes")
         extras["m0"] = dict(leg((col, ns, hist, cov), bh.default_params(b=b, w=w, m=0.0, random_order=args.random_order, seed=1234), 2),
                             workload="the default frame with -m 0 (no marking: every main pixel is processed)")
+        # Two frames in flight (never `value`): sequences and AOV passes are independent frames, and the distance kernels of one frame
+        # fill the chip under the latency-bound tail of another.  Two engine contexts, each with the headline frame in flight on its own worker thread
+        # (bcd_hip_denoise_begin / _wait); a context starts its next frame as soon as its last one is complete, so the two drift out of phase.
+        ctx_b = bh.Context(local_rank)
+        out_b = torch.empty_like(out)
+        ctx_b.denoise(*d_in, S, prm, out_b)          # (grows the second context's workspaces; also the reference result)
+        ctx_b.denoise(*d_in, S, prm, out_b)
+        ref2 = out_b.clone()
+        torch.cuda.synchronize()
+        pairs = 8
+        t1 = time.perf_counter()
+        ctx.denoise_begin(*d_in, S, prm, out)
+        ctx_b.denoise_begin(*d_in, S, prm, out_b)
+        for _ in range(pairs - 1):
+            ctx.denoise_wait()
+            ctx.denoise_begin(*d_in, S, prm, out)
+            ctx_b.denoise_wait()
+            ctx_b.denoise_begin(*d_in, S, prm, out_b)
+        ctx.denoise_wait()
+        ctx_b.denoise_wait()
+        torch.cuda.synchronize()
+        ms_pipe = (time.perf_counter() - t1) * 1e3 / (2 * pairs)
+        ok_fin = torch.isfinite(ref2)
+        dev_pipe = max(float((torch.where(ok_fin, out - ref2, torch.zeros_like(out)).abs().max() / ref2[ok_fin].abs().max()).item()),
+                       float((torch.where(ok_fin, out_b - ref2, torch.zeros_like(out)).abs().max() / ref2[ok_fin].abs().max()).item()))
+        assert dev_pipe < 1e-5, "frames in flight differ from the blocking call: %g" % dev_pipe
+        extras["pipelined_2frames"] = {"value": round(W * H / 1e6 / (ms_pipe * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms_pipe, 4), "steps": 2 * pairs,
+                                       "rel_linf_vs_blocking_call": dev_pipe,
+                                       "workload": "the headline frame, two engine contexts with one frame in flight each (bcd_hip_denoise_begin / _wait): frames per "
+                                                   "second of a sequence, not the latency of a frame -- never `value`"}
+        ctx_b.close()
+        del out_b, ref2
         # General sample counts (src/core/DenoisingUnit.cpp:371-383 takes any n1, n2): the headline frame at a uniform 24 spp (not
         # a power of two: the count products do not drop out) and with per-pixel counts drawn from {16, 24, 32, 48} (48-spp statistics thinned per
         # pixel: histogram and count scaled by 1/3, 1/2, 2/3 or 1 -- what an adaptive sampler's early exit leaves).  Both take the own-list distance

@@ -115,6 +115,15 @@ int bcd_hip_denoise(bcd_hip_ctx *ctx, const float *d_colors, const float *d_nsam
                     const float *d_histograms, const float *d_covariances,
                     int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *d_out);
 
+/* The same call in two halves (round 6): _begin hands the frame to a worker thread of the context and returns at once, _wait returns when the frame is
+ * complete (d_out valid, every stream of the context synchronised) with the status bcd_hip_denoise would have returned.  One frame per context at a
+ * time; inputs, output and the context must stay untouched until _wait.  For callers with independent frames (a sequence, AOV passes): two contexts
+ * with a frame in flight each keep the chip busier than one blocking call after the other -- the results are those of the blocking call. */
+int bcd_hip_denoise_begin(bcd_hip_ctx *ctx, const float *d_colors, const float *d_nsamples,
+                          const float *d_histograms, const float *d_covariances,
+                          int W, int H, int D, int nb_scales, const bcd_hip_params *prm, float *d_out);
+int bcd_hip_denoise_wait(bcd_hip_ctx *ctx);
+
 /* row-block variant for multi-GPU tiling: the images are a horizontal band of a larger frame;
  * only main pixels on local lines [main_row_begin, main_row_end) are processed, and instead of the
  * finalised colours the raw accumulators are returned (d_sum W*H*3 floats, d_count W*H int32), so

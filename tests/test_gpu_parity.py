@@ -1754,6 +1754,36 @@ def test_whole_frame_through_the_rccl_transport_in_loopback(hipctx, m):
 
 
 @pytest.mark.gpu
+def test_two_frames_in_flight_equal_the_blocking_calls(hipctx):
+    """bcd_hip_denoise_begin / _wait: two contexts with a (different) frame in flight each, several rounds; every result is the blocking call's, a second
+    _begin on a busy context is refused, a bad argument is reported by _begin itself"""
+    import torch
+    import bcd_amd.core as core
+    import bcd_amd.hip as bh
+    W, H, S = 320, 200, 3
+    prm = bh.default_params(m=1.0, random_order=1, seed=5)
+    frames = [dev(*core.synthetic_scene(W, H, 16, 3 + i, 0.12 + 0.1 * i, 0.005)) for i in range(2)]
+    want = [hipctx.denoise(*f, S, prm).clone() for f in frames]
+    other = bh.Context(0)
+    try:
+        outs = [torch.empty_like(want[0]) for _ in range(2)]
+        ctxs = [hipctx, other]
+        for rnd in range(3):
+            for i in (0, 1):
+                ctxs[i].denoise_begin(*frames[(i + rnd) % 2], S, prm, outs[i])
+            with pytest.raises(bh.BcdHipError):
+                ctxs[0].denoise_begin(*frames[0], S, prm, outs[0])          # one frame per context
+            for i in (0, 1):
+                ctxs[i].denoise_wait()
+                assert rel_linf(outs[i].cpu().numpy(), want[(i + rnd) % 2].cpu().numpy()) < 1e-5
+        with pytest.raises(bh.BcdHipError):
+            other.denoise_begin(*frames[0], 0, prm, outs[1])                # no scales: refused at once, nothing in flight
+        other.denoise_wait()                                                # (returns immediately)
+    finally:
+        other.close()
+
+
+@pytest.mark.gpu
 def test_release_engines_gives_the_memory_back(hipctx):
     """bcd::releaseEngines(): the cached engine contexts of libbcdcore (grow-only workspaces) are destroyed and rebuilt on demand"""
     import torch
