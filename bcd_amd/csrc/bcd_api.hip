@@ -667,6 +667,12 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
                 RCCHK(launch_chunk(first, n, defer, nullptr));
                 if (defer) { wk.redo.pending = true; wk.redo.first = first; wk.redo.n = n; wk.redo.cus = cus; }
             }
+            if (ahead > 0 && remaining > 0) {
+                // the guess was too small (a frame unlike its predecessor: -m 0 after -m 1): this frame has gone through in chunks of the guessed size;
+                // the records grow to what the next frame of its kind needs NOW, in the frame that met the change (the growth waits for the chunks)
+                HIPCHK(ctx, hipStreamSynchronize(wk.stream));
+                RCCHK(ensure(ctx, wk.gscratch, rec * (size_t)std::min(n_strong, chunk_max)));
+            }
         }
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 23, d_c + 7, sizeof(int32_t), hipMemcpyDeviceToHost, wk.stream)); // read after the scale's last synchronisation
     } else {

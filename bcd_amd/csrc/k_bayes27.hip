@@ -1501,16 +1501,26 @@ __device__ __attribute__((noinline)) void win_covariance(float *tile, const floa
 
 // the records of PHASE 1 from the covariance tile: C (LD layout), A = C - N in the eigensolver's 28 x 28 layout (the matrix whose negative
 // eigenvalues are clamped, Step 1 (:421-436); padding row / column zero), noise and mean -- whole 256-byte lines per store instruction
+// Round 6: the records leave as 16-byte stores.  C (the 28 x 29 tile as it lies) is a straight copy; A = C - N is the tile with its 81 block-diagonal
+// entries changed IN the tile (one wavefront: its LDS instructions execute in order) and then copied row by row into the 28-column record.  The loop this
+// replaces decided per element whether it lies on the block diagonal (two divisions by three, a table look-up and a select for each of 784 entries: ~360
+// vector instructions per item, as many as the member loops).
 __device__ __attribute__((noinline)) void win_write_records(float *__restrict__ recA, float *__restrict__ recC, float *__restrict__ recX,
-                                                            const float *tile, const float *noise, const float *mean, int lane)
+                                                            float *tile, const float *noise, const float *mean, int lane)
 {
     LDS_POINTER(tile); LDS_POINTER(noise); LDS_POINTER(mean);
-    for (int e = lane; e < K * LD; e += 64) recC[e] = tile[e];
-    for (int e = lane; e < KP * JLD; e += 64) {
-        const int r = e / JLD, c = e - r * JLD, ro = r / 3, co = c / 3;
-        // the block-diagonal noise covariance: 3 x 3 block of pixel ro (symmetric storage xx,yy,zz,yz,xz,xy)
-        const float nv = (ro == co && r < K && c < K) ? noise[ro * 6 + noise_idx(r - 3 * ro, c - 3 * co)] : 0.f;
-        recA[e] = tile[r * LD + c] - nv;
+    static_assert((K * LD + 3) / 4 <= KP * LD / 4 && MSZ % 4 == 0, "whole 16-byte groups inside the tile and the record");
+    for (int q = lane; q < (K * LD + 3) / 4; q += 64) reinterpret_cast<float4 *>(recC)[q] = reinterpret_cast<const float4 *>(tile)[q];
+    // the block-diagonal noise covariance: 3 x 3 block of patch pixel ro (symmetric storage xx,yy,zz,yz,xz,xy)
+    for (int t = lane; t < P * 9; t += 64) {
+        const int ro = t / 9, ij = t - 9 * ro, i = ij / 3, j = ij - 3 * i;
+        float *e = tile + (3 * ro + i) * LD + 3 * ro + j;
+        *e -= noise[ro * 6 + noise_idx(i, j)];
+    }
+    for (int e = lane; e < KP * (JLD / 4); e += 64) {
+        const int r = e / (JLD / 4), q = e - r * (JLD / 4);
+        const float *src = tile + r * LD + 4 * q; // (rows of the tile are 29 floats apart: four 4-byte reads)
+        reinterpret_cast<float4 *>(recA)[e] = make_float4(src[0], src[1], src[2], src[3]);
     }
     if (lane < P * 6) recX[lane] = noise[lane];
     if (lane < K) recX[P * 6 + lane] = mean[lane];

@@ -398,12 +398,15 @@ def main():
             d = [torch.from_numpy(a).cuda() for a in frame]
             ctx.denoise(*d, S, prm_leg, out)
             torch.cuda.synchronize()
+            each = []
             t1 = time.perf_counter()
             for _ in range(reps):
-                ctx.denoise(*d, S, prm_leg, out)
+                t2 = time.perf_counter()
+                ctx.denoise(*d, S, prm_leg, out)   # (a blocking call: every stream of the context is synchronised when it returns)
+                each.append(round((time.perf_counter() - t2) * 1e3, 3))
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t1) * 1e3 / reps
-            return {"value": round(W * H / 1e6 / (ms * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms, 4), "steps": reps,
+            return {"value": round(W * H / 1e6 / (ms * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms, 4), "steps": reps, "ms_each": each,
                     "per_scale": per_scale_stats(ctx, S)}
         # ---- what a drop-in caller gets: bcd_hip_denoise_host on HOST buffers (pageable, like a DeepImage's std::vector): upload of the
         # four planes, the same denoise, download of the result.  Never `value`; PCIe moves (D + 10) * 4 + 12 bytes per pixel.
