@@ -281,6 +281,10 @@ int check_params(bcd_hip_ctx *ctx, int W, int H, int D, const bcd_hip_params *pr
     return BCD_HIP_OK;
 }
 
+// bytes of the count planes of a scale: nd per pixel, or the 96 of the own-list kernel's split pixel-major records (b = 6) if that is more.  ONE place:
+// the host-buffer entry point computes planes ahead of similarity(), and a larger request there would free them (found by the environment-switch test)
+size_t count_plane_bytes(size_t npix, int nd) { return npix * (size_t)std::max(nd, 96); }
+
 // did the last similarity() pass on this workspace leave the range flag raised or overflow its borderline list?  (valid after the
 // stream has been synchronised; the caller then repeats the pass with exact_mode = 1)
 // a user of the workspace's counters / flags / work queues / sub-counter lines outside the scale chain (self-tests, the eigensolver entry point): whatever
@@ -327,7 +331,7 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(b);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
+    RCCHK(ensure(ctx, wk.Cn, count_plane_bytes(npix, nd)));
     RCCHK(ensure(ctx, wk.fwd, npix * ((nd + 31) / 32) * sizeof(uint32_t)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (wk.ev_used < MAX_EVENT_PAIRS) {
@@ -1300,7 +1304,7 @@ int bcd_hip_denoise_host_ex(bcd_hip_ctx *ctx, const float *h_colors, const float
         if (!ctx->upload_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
         const int nd = bcd_delta_count(b);
         RCCHK(ensure(ctx, wk.T, np * nd * sizeof(float)));
-        RCCHK(ensure(ctx, wk.Cn, np * nd));
+        RCCHK(ensure(ctx, wk.Cn, count_plane_bytes(np, nd))); // (the size similarity() will ask for: a larger request there would REALLOCATE the planes computed here)
         RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
         int *d_flag = (int *)wk.counters.p + 40;
         HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), ctx->stream));
@@ -1683,7 +1687,7 @@ int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, con
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
+    RCCHK(ensure(ctx, wk.Cn, count_plane_bytes(npix, nd)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     float *T2 = nullptr;
     uint8_t *C2 = nullptr;
@@ -1742,7 +1746,7 @@ int bcd_hip_selftest_bin_work(bcd_hip_ctx *ctx, const float *d_hist, const float
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
+    RCCHK(ensure(ctx, wk.Cn, count_plane_bytes(npix, nd)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     int *d_flag = (int *)wk.counters.p + 40;
     unsigned long long *d_work = reinterpret_cast<unsigned long long *>((int32_t *)wk.counters.p + 48); // (8-byte aligned: words 48..53)
@@ -1793,7 +1797,7 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
+    RCCHK(ensure(ctx, wk.Cn, count_plane_bytes(npix, nd)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     float *T2 = nullptr;
     uint8_t *C2 = nullptr;
@@ -1849,7 +1853,7 @@ int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const fl
     const size_t npix = (size_t)W * H;
     const int nd = bcd_delta_count(search_radius);
     RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, npix * std::max(nd, 96))); // (96: the split pixel-major records of the own-list kernel, b = 6)
+    RCCHK(ensure(ctx, wk.Cn, count_plane_bytes(npix, nd)));
     RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
     float *T2 = nullptr;
     uint8_t *C2 = nullptr;
