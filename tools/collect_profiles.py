@@ -10,13 +10,14 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 COPIES = [("final_noextras_stats.txt", "kernel_stats_1080p_no_extras.txt"), ("final_noextras_line.json", "bench_line_1080p_no_extras.json"),
           ("final_default_stats.txt", "kernel_stats_1080p_default_cmd.txt"), ("final_default_line.json", "bench_line_1080p_default_cmd.json"),
           ("final_serial_stats.txt", "kernel_stats_1080p_serial_scales.txt"), ("final_unprofiled_line.json", "bench_line_1080p_unprofiled.json"),
           ("final_timeline.txt", "timeline_1080p_one_step.txt"), ("final_4k_stats.txt", "kernel_stats_4k.txt"), ("final_4k_b12_stats.txt", "kernel_stats_4k_b12.txt"),
           ("final_4k_b12_serial_stats.txt", "kernel_stats_4k_b12_serial_scales.txt"),
-          ("final_nonuni_stats.txt", "kernel_stats_1080p_nonuniform.txt"), ("final_nonuni_serial_stats.txt", "kernel_stats_1080p_nonuniform_serial_scales.txt"), ("final_band_timeline.txt", "band_timeline_phase_major_gate.txt")]
+          ("final_nonuni_stats.txt", "kernel_stats_1080p_nonuniform.txt"), ("final_nonuni_serial_stats.txt", "kernel_stats_1080p_nonuniform_serial_scales.txt"), ("final_band_timeline.txt", "band_timeline_p1_r_p2_gate.txt"),
+          ("final_band_host_trace.txt", "band_host_trace.txt"), ("final_fetch_per_kernel.txt", "pmc_fetch_size_per_kernel.txt")]
 for src, dst in COPIES:
     shutil.copyfile(os.path.join(G, src), os.path.join(P, "%s_%s" % (tag, dst)))
 shutil.copyfile(os.path.join(G, "pmc_traffic.json"), os.path.join(P, "pmc_traffic.json"))

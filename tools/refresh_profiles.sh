@@ -19,7 +19,13 @@ tools/prof.sh final_nonuni --no-extras --spp 24 --steps 10 --warmup 2 > /dev/nul
 BCD_HIP_SERIAL_SCALES=1 tools/prof.sh final_nonuni_serial --no-extras --spp 24 --steps 10 --warmup 2 > /dev/null
 # one rank's band of the 4K frame through the band driver with RCCL in loopback (bench.py predicted_8gpu): kernel timeline of one step
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d $R/gpurun_out/prof_final_band -o band -- python $R/bench.py --predict-band-child > $R/gpurun_out/final_band.log 2>&1)
-python tools/timeline.py $(ls gpurun_out/prof_final_band/*.db | head -1) 3.2 > gpurun_out/final_band_timeline.txt
+python tools/timeline.py $(ls gpurun_out/prof_final_band/*.db | head -1) 3.0 > gpurun_out/final_band_timeline.txt
+# ... and where its host threads wait (HIP runtime trace beside the kernel trace; no counters in this run)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --hip-runtime-trace -d $R/gpurun_out/prof_final_band_host -o band -- python $R/bench.py --predict-band-child > /dev/null 2>&1)
+python tools/host_trace.py $(ls gpurun_out/prof_final_band_host/*.db | head -1) 3.2 15 | head -400 > gpurun_out/final_band_host_trace.txt
+# FETCH_SIZE of every kernel of a step (scales serialised; one counter pass, kernel trace only)
+(cd /tmp && export TMPDIR=/tmp && BCD_HIP_SERIAL_SCALES=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch_all -o x -- python $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /dev/null 2>&1)
+python tools/fetch_per_kernel.py $(ls gpurun_out/pmc_fetch_all/*.db | head -1) > gpurun_out/final_fetch_per_kernel.txt
 # HBM traffic of the pair-distance kernel (TCC counters, separate passes): the headline size and the 4K frame
 tools/pmc_traffic.sh > gpurun_out/final_pmc_traffic.log 2>&1
 tools/pmc_traffic.sh --width 3840 --height 2160 --spp 8 --sigma 0.15 --spikes 0 >> gpurun_out/final_pmc_traffic.log 2>&1
