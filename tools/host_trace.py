@@ -18,7 +18,7 @@ kern = list(db.execute("select s.kernel_name, d.%s, d.%s, d.stream_id from %s d 
 t_end = max(r[2] for r in kern); t0 = t_end - span_ms * 1e6
 reg, strs = tab("rocpd_region"), tab("rocpd_string")
 rcols = [r[1] for r in db.execute("pragma table_info(%s)" % reg)]
-rows = list(db.execute("select s.string, r.start, r.end, r.tid from %s r join %s s on r.name_id = s.id where r.end >= ? order by r.start" % (reg, strs), (t0,)))
+rows = list(db.execute("select s.string, r.start, r.end, r.tid from %s r join %s s on r.name_id = s.id where r.end >= ? and r.start <= ? order by r.start" % (reg, strs), (t0, t_end)))
 ev = []
 for n, s, e, q in kern:
     if s >= t0:
