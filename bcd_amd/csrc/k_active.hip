@@ -105,6 +105,30 @@ __global__ __launch_bounds__(256) void k_active_round(const uint32_t *__restrict
 // final value, so a stale read delays a decision and never changes it.
 // the (2B+1)^2 window bitmap of a pixel at tile position (lx, ly) from per-row bitmaps of the tile + halo (bit lc of
 // rows[lr] = cell (lr, lc)): window line j is the field of 2B+1 bits starting at column lx of row ly + j
+// the WORDS mask / dependency words of one pixel as 16- or 8-byte loads (round 6): the per-word form was WORDS separate 4-byte loads per lane at a lane stride
+// of WORDS * 4 bytes -- 20 passes of 64 scattered addresses through the L1 at b = 12, and the kernels that read them wait on exactly those loads
+// (profiles/r05_pmc_b12_mask_kernels.txt).  (Global loads need dword alignment only; the records are WORDS * 4 bytes apart.)
+template <int WORDS>
+__device__ inline void load_pixel_words(const uint32_t *__restrict__ src, uint32_t (&out)[WORDS])
+{
+    if constexpr (WORDS % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < WORDS / 4; ++q) {
+            const uint4 v = reinterpret_cast<const uint4 *>(src)[q];
+            out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+        }
+    } else if constexpr (WORDS % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < WORDS / 2; ++q) {
+            const uint2 v = reinterpret_cast<const uint2 *>(src)[q];
+            out[2 * q] = v.x; out[2 * q + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < WORDS; ++j) out[j] = src[j];
+    }
+}
+
 template <int B, class RowPtr>
 __device__ inline void window_bits(uint32_t (&w)[((2 * B + 1) * (2 * B + 1) + 31) / 32], RowPtr rows, int lx, int ly)
 {
@@ -183,9 +207,11 @@ __global__ __launch_bounds__(256) void k_mark_deps(const uint32_t *__restrict__ 
             const uint32_t e = (uint32_t)(hq < hp) | ((uint32_t)(hq == hp) & (uint32_t)(k < KC));
             return e << bit;
         };
+        uint32_t simw[WORDS];
+        load_pixel_words<WORDS>(mask + p * WORDS, simw);
 #pragma unroll
         for (int j = 0; j < WORDS; ++j) {
-            const uint32_t sim = mask[p * WORDS + j];
+            const uint32_t sim = simw[j];
             uint32_t m = sim & same[j], keep = sim & lower[j];
             while (m) {
                 const int b0 = __ffs(m) - 1;
@@ -228,7 +254,8 @@ __global__ __launch_bounds__(256) void k_mark_round(const uint32_t *__restrict__
     // every load of the tile is issued before the first one is used (the halo lines and the dependency words: one round trip to memory, not one per line)
     uint32_t dword[WORDS];
 #pragma unroll
-    for (int j = 0; j < WORDS; ++j) dword[j] = pending ? dep[p * WORDS + j] : 0u;
+    for (int j = 0; j < WORDS; ++j) dword[j] = 0u;
+    if (pending) load_pixel_words<WORDS>(dep + p * WORDS, dword);
     {
         constexpr int NL = (tw + 3) / 4;
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
