@@ -6,7 +6,8 @@ seeded random order): the pyramid build, and per scale the pair-distance / mask 
 Bayesian patch kernel, finalisation and merge.  Inputs are resident in HBM before the timed region.
 After the timed region (N = 1, untimed, skipped by --no-extras): the pair-distance kernel with the scales serialised
 (`roofline.isolated_*`), the host-buffer call a drop-in user makes (`end_to_end`: PCIe both ways inside), the low-noise variant of
-the frame (`low_noise`), a textured frame whose similar sets depend on the noise (`textured`), the same frame with -m 0 (`m0`), the 3840x2160
+the frame (`low_noise`), a textured frame whose similar sets depend on the noise (`textured`), the same frame with -m 0 (`m0`), two frames in flight on two engine
+contexts (`pipelined_2frames`), frames with general sample counts (`nonuniform_*`), the 3840x2160
 frame of BASELINE.json configs[3] (`frame_4k`; at N > 1 the same frame over the same row bands, measured before the timed
 region: the per-N points of the 4K strong-scaling curve) and of configs[4] (`frame_4k_b12_prefilter`, N = 1), and the CPU oracle on all host cores and on one core (`cpu_baseline`).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into horizontal bands of
