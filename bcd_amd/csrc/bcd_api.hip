@@ -32,6 +32,7 @@ hipError_t bcd_launch_masks_finish(int, int, int, float, uint32_t *, int32_t *, 
 int bcd_pairdist_rw_supported(int D);
 hipError_t bcd_launch_pairdist_rw(const float *, const float *, int, int, int, int, void * /* binary16 T planes */, uint8_t *, int *, float, hipStream_t);
 hipError_t bcd_launch_pairdist_rw_rows(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, int, int, hipStream_t);
+hipError_t bcd_launch_pairdist_rw_ratio(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, unsigned int *, hipStream_t);
 int bcd_pairdist_rw_tile_lines();
 struct BcdSparseUploader;
 BcdSparseUploader *bcd_sparse_create();
@@ -39,10 +40,7 @@ void bcd_sparse_destroy(BcdSparseUploader *);
 void bcd_sparse_frame_begin(BcdSparseUploader *);
 void bcd_sparse_frame_bytes(const BcdSparseUploader *, long long *, long long *);
 hipError_t bcd_sparse_upload(BcdSparseUploader *, float *, const float *, size_t, hipStream_t);
-int bcd_pairdist_nz_supported(int D, int b);
 void bcd_bayes27_set_strict_eigensolver(int on);
-hipError_t bcd_launch_fwd_masks_pm(const void *, const uint8_t *, int, int, float, uint32_t *, const BcdBorderline *, hipStream_t);
-hipError_t bcd_launch_pairdist_nz(const float *, const float *, int, int, int, int, void *, uint8_t *, long long, long long, int *, float, int, hipStream_t, unsigned long long *prof = nullptr);
 hipError_t bcd_launch_pairdist_rw_counting(const float *, const float *, int, int, int, int, void *, uint8_t *, int *, float, unsigned long long *, hipStream_t);
 hipError_t bcd_launch_spike_rows(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *, float *, float *, int, int,
                                  hipStream_t);
@@ -99,7 +97,7 @@ struct DevBuf {
 struct Work {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, cnt_lines, work_q, pixcov, sum, cnt, gscratch, dep, tmp_lo, border; // grow-only
+    DevBuf T, Cn, mask, fwd, nsim, state, strong, weak, counters, cnt_lines, work_q, pixcov, sum, cnt, gscratch, dep, tmp_lo, border, ratio_stats; // grow-only
     int border_capacity = 0;       // entries of `border` offered to the last fast similarity pass (0: the exact kernels ran)
     int rounds_hint = 0;           // marking launches the last problem needed
     int last_batch = 0;            // launches of the batch active_step_enqueue left in flight
@@ -125,13 +123,13 @@ struct Work {
     // uniform-sample-count speculation of the approximate distance kernel (similarity()): did the last frames on this workspace fail it?
     bool nonuniform = false;
     bool speculated = false;       // the current pass launched the uniform kernel on the first pixel's count, unchecked by the host
-    // the own-list kernel raised its absolute-error flag on frames of these sizes on this workspace: the dense kernel's general formula serves them (a small
+    // the RATIO form of the distance kernel raised its absolute-error flag on frames of these sizes on this workspace: the reference's operations serve them (a small
     // set, oldest replaced: serialised scales share one workspace, a caller may alternate frame sizes)
-    struct { int W = 0, H = 0; } nz_declined[4];
-    int nz_declined_next = 0;
-    bool nz_is_declined(int W, int H) const { for (const auto &k : nz_declined) if (k.W == W && k.H == H) return true; return false; }
-    bool nz_used = false;          // the current pass ran the own-list kernel (k_similarity_nz.hip)
-    int nz_W = 0, nz_H = 0;        // ... on a frame of this size
+    struct { int W = 0, H = 0; } ratio_declined[4];
+    int ratio_declined_next = 0;
+    bool ratio_is_declined(int W, int H) const { for (const auto &k : ratio_declined) if (k.W == W && k.H == H) return true; return false; }
+    bool ratio_used = false;          // the current pass ran the RATIO form of the distance kernel (general sample counts)
+    int ratio_W = 0, ratio_H = 0;        // ... on a frame of this size
     // (round 4) k_scale_begin cleared these at the head of the scale's stream: the first user takes them as they are, a repeated use (second
     // similarity attempt, second marking batch, second chunk of a long list) clears its own as before
     bool clean_flags = false, clean_lines = false, clean_dc = false, clean_wq = false;
@@ -281,9 +279,9 @@ int check_params(bcd_hip_ctx *ctx, int W, int H, int D, const bcd_hip_params *pr
     return BCD_HIP_OK;
 }
 
-// bytes of the count planes of a scale: nd per pixel, or the 96 of the own-list kernel's split pixel-major records (b = 6) if that is more.  ONE place:
-// the host-buffer entry point computes planes ahead of similarity(), and a larger request there would free them (found by the environment-switch test)
-size_t count_plane_bytes(size_t npix, int nd) { return npix * (size_t)std::max(nd, 96); }
+// bytes of the count planes of a scale.  ONE place: the host-buffer entry point computes planes ahead of similarity(), and a larger request there
+// would free them (round 6: it happened when one of the two grew, found by the environment-switch test on a fresh context)
+size_t count_plane_bytes(size_t npix, int nd) { return npix * (size_t)nd; }
 
 // did the last similarity() pass on this workspace leave the range flag raised or overflow its borderline list?  (valid after the
 // stream has been synchronised; the caller then repeats the pass with exact_mode = 1)
@@ -307,8 +305,8 @@ int similarity_redo_mode(Work &wk)
     const bool overflow = fast && wk.h_counters[43] > wk.border_capacity;
     if (fast && (wk.speculated || other_count)) wk.nonuniform = other_count;
     if (flag == 0 && !other_count && !overflow) return 0;
-    if (fast && wk.nz_used && (flag & 4) != 0) { // the own-list kernel's absolute-error check: the dense kernel's general formula serves this workspace from now on
-        if (!wk.nz_is_declined(wk.nz_W, wk.nz_H)) { wk.nz_declined[wk.nz_declined_next] = { wk.nz_W, wk.nz_H }; wk.nz_declined_next = (wk.nz_declined_next + 1) & 3; }
+    if (fast && wk.ratio_used && (flag & 4) != 0) { // the RATIO form's absolute-error check: the reference's operations serve this frame size on this workspace from now on
+        if (!wk.ratio_is_declined(wk.ratio_W, wk.ratio_H)) { wk.ratio_declined[wk.ratio_declined_next] = { wk.ratio_W, wk.ratio_H }; wk.ratio_declined_next = (wk.ratio_declined_next + 1) & 3; }
         if ((flag & ~4) == 0) return 3;
     }
     return (flag == 0 && other_count) ? 3 : 1; // (a void launch has no meaningful list count: other_count alone decides)
@@ -366,8 +364,8 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
     wk.h_counters[42] = 0;
     wk.h_counters[43] = 0;
     wk.border_capacity = 0;
-    wk.nz_used = false;
-    wk.nz_W = W; wk.nz_H = H;
+    wk.ratio_used = false;
+    wk.ratio_W = W; wk.ratio_H = H;
     // fixed samples per pixel, a power of two (the usual case): the distance kernel drops the sample-count products (exactly,
     // see k_pairdist).  One small reduction and one host round trip at the head of the chain (~30 us).
     float uni_n = pre ? wk.planes.uni_n : 0.f;
@@ -404,16 +402,17 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         RCCHK(ensure(ctx, wk.border, (size_t)capacity * sizeof(uint2)));
         wk.border_capacity = capacity;
         BcdBorderline bl = { 0.f, (uint2 *)wk.border.p, d_flag + 3, capacity };
-        // (round 5) General sample counts (adaptive sampling, 24 spp, ...; src/core/DenoisingUnit.cpp:371-383 handles any n1, n2): the own-list kernel
-        // evaluates them at the cost of uniform ones (1.9 - 2.0 ms at 1080p against 2.9 - 3.0 ms for the dense kernel's general formula).
-        // Its planes are pixel-major (two aligned records per pixel, round 6) and have a mask kernel of their own.  It raises flag bit 2 when its absolute-error check fails (coarse scales of
-        // frames with hundreds of samples per pixel): the pass is then repeated with the dense kernel, and the workspace remembers.
-        const bool use_nz = !pre && uni_n == 0.f && !wk.nz_is_declined(W, H) && bcd_pairdist_nz_supported(D, b) && npix * (size_t)nd < ((size_t)1 << 31);
-        wk.nz_used = use_nz;
+        // General sample counts (adaptive sampling, 24 spp, ...; src/core/DenoisingUnit.cpp:371-383 handles any n1, n2): the RATIO form of the dense kernel
+        // (round 6, k_similarity_fast.hip) evaluates them at the cost of uniform ones -- 1.83 ms at 1080p against 1.73 for the uniform kernel, 3.0 ms for the
+        // reference's operations and 1.97 + 0.07 ms for the own-list kernel of round 5, which it replaced -- and checks afterwards that the absolute errors it
+        // adds stay inside the verified band (flag bit 2: the pass is then repeated with the reference's operations, and the workspace remembers the size).
+        const bool use_ratio = !pre && uni_n == 0.f && !wk.ratio_is_declined(W, H);
+        wk.ratio_used = use_ratio;
         if (pre) { if (e0) --wk.ev_used; } // (nothing to time: the planes are there)
-        else if (use_nz) {
+        else if (use_ratio) {
+            RCCHK(ensure(ctx, wk.ratio_stats, 128 * sizeof(unsigned int)));
             if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
-            HIPCHK(ctx, bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, 0, 0, d_flag, tau, 3, wk.stream));
+            HIPCHK(ctx, bcd_launch_pairdist_rw_ratio(d_hist, d_ns, W, H, D, b, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, tau, (unsigned int *)wk.ratio_stats.p, wk.stream));
             if (e1) HIPCHK(ctx, hipEventRecord(e1, wk.stream));
         } else {
             if (e0) HIPCHK(ctx, hipEventRecord(e0, wk.stream));
@@ -422,12 +421,8 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
         }
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 40, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 42, d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, wk.stream)); // "another sample count" (plain-store flag)
-        if (use_nz) {
-            HIPCHK(ctx, bcd_launch_fwd_masks_pm(wk.T.p, (const uint8_t *)wk.Cn.p, W, H, tau, (uint32_t *)wk.fwd.p, &bl, wk.stream));
-            HIPCHK(ctx, bcd_launch_masks_finish(W, H, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream, &bl, d_hist, d_ns, D));
-        } else
-            HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream,
-                                         &bl, d_hist, d_ns, D));
+        HIPCHK(ctx, bcd_launch_masks((const float *)wk.T.p, (const uint8_t *)wk.Cn.p, W, H, w, b, tau, d_mask, d_count, (uint32_t *)wk.fwd.p, wk.stream,
+                                     &bl, d_hist, d_ns, D));
         HIPCHK(ctx, hipMemcpyAsync(wk.h_counters + 43, d_flag + 3, sizeof(int), hipMemcpyDeviceToHost, wk.stream));
         if (exact_mode == 0) {
             HIPCHK(ctx, hipStreamSynchronize(wk.stream));
@@ -435,7 +430,7 @@ int similarity(bcd_hip_ctx *ctx, Work &wk, const float *d_hist, const float *d_n
             if (redo == 3) {
                 RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 3));
                 HIPCHK(ctx, hipStreamSynchronize(wk.stream));
-                if (similarity_needs_redo(wk) && similarity_redo_mode(wk) == 3) { // (the own-list kernel declined: once more with the dense kernel)
+                if (similarity_needs_redo(wk) && similarity_redo_mode(wk) == 3) { // (the RATIO form declined: once more with the reference's operations)
                     RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, tau, d_mask, d_count, 3));
                     HIPCHK(ctx, hipStreamSynchronize(wk.stream));
                 }
@@ -751,7 +746,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     const bool speculate = marking && w == 1;
     const long long REDO = 1ll << 40;
     bool estimated = false;
-    for (int attempt = 0, mode = 2; attempt < 4; ++attempt) { // production kernels; if they complain: general formula (own-list kernel, then the dense one), then exact kernels
+    for (int attempt = 0, mode = 2; attempt < 4; ++attempt) { // production kernels; if they complain: general sample counts (RATIO form, then the reference's operations), then exact kernels
         RCCHK(similarity(ctx, wk, d_hist, d_ns, W, H, D, w, b, prm->hist_dist_threshold, (uint32_t *)wk.mask.p, (int32_t *)wk.nsim.p, mode));
         if (prof && attempt == 0) HIPCHK(ctx, hipEventRecord(wk.ev_stage[1], wk.stream));
         if (!speculate) {
@@ -789,7 +784,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
         }
         const int redo = similarity_redo_mode(wk);
         if (redo == 0) break; // inputs inside the guarded range, uniform-count guess right, borderline list not overflowed
-        mode = (redo == 3 && (mode == 2 || wk.nz_used)) ? 3 : 1; // (wk.nz_used: the own-list kernel declined and the workspace has noted it -- the dense kernel is next)
+        mode = (redo == 3 && (mode == 2 || wk.ratio_used)) ? 3 : 1; // (wk.ratio_used: the RATIO form declined and the workspace has noted it -- the reference's operations are next)
     }
     progress_add(ctx, 0.5 * (double)npix); // similar patches selected, processed set known
     if (prof) HIPCHK(ctx, hipEventRecord(wk.ev_stage[2], wk.stream));
@@ -816,7 +811,7 @@ int mono_accumulate(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const flo
     int64_t ns = 0, nw = 0, tot = 0;
     bayes_counts(wk, &ns, &nw, &tot);
     st.processed = ns + nw; st.fallback = nw; st.similar_total = tot;
-    st.similarity_path = wk.border_capacity > 0 ? (wk.nz_used ? 2 : 1) : 0;
+    st.similarity_path = wk.border_capacity > 0 ? (wk.ratio_used ? 2 : 1) : 0;
     st.borderline_pairs = wk.border_capacity > 0 ? wk.h_counters[43] : 0;
     st.cu_share = ctx->cu_share_pct * (&wk != &ctx->main ? ctx->coarse_share : 100) / 100;
     st.spectral_inverses = wk.h_counters[23];
@@ -885,7 +880,7 @@ int work_init(bcd_hip_ctx *ctx, Work &w, hipStream_t stream)
 
 void work_destroy(Work &w)
 {
-    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.cnt_lines, &w.work_q, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep, &w.tmp_lo, &w.border };
+    DevBuf *bufs[] = { &w.T, &w.Cn, &w.mask, &w.fwd, &w.nsim, &w.state, &w.strong, &w.weak, &w.counters, &w.cnt_lines, &w.work_q, &w.pixcov, &w.sum, &w.cnt, &w.gscratch, &w.dep, &w.tmp_lo, &w.border, &w.ratio_stats };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (w.h_counters) (void)hipHostFree(w.h_counters);
     for (auto &pr : w.ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1692,7 +1687,7 @@ int bcd_hip_selftest_distance_kernels(bcd_hip_ctx *ctx, const float *d_hist, con
     float *T2 = nullptr;
     uint8_t *C2 = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&T2, npix * nd * sizeof(float)));
-    if (hipMalloc((void **)&C2, npix * std::max(nd, 96)) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
+    if (hipMalloc((void **)&C2, npix * nd) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
     int rc = BCD_HIP_OK;
     do {
         int *d_flag = (int *)wk.counters.p + 40;
@@ -1802,7 +1797,7 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
     float *T2 = nullptr;
     uint8_t *C2 = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&T2, npix * nd * sizeof(float)));
-    if (hipMalloc((void **)&C2, npix * std::max(nd, 96)) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
+    if (hipMalloc((void **)&C2, npix * nd) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
     int rc = BCD_HIP_OK;
     do {
         int *d_flag = (int *)wk.counters.p + 40;
@@ -1820,8 +1815,11 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
             hipMemsetAsync(T2, 0, npix * nd * sizeof(float), wk.stream) != hipSuccess || hipMemsetAsync(C2, 0, npix * nd, wk.stream) != hipSuccess) {
             rc = BCD_HIP_EDEVICE; break;
         }
-        // approximate planes (production variant) against the exact planes (compiler's division, general formula)
-        if (bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream) != hipSuccess ||
+        // approximate planes (production variant: the uniform kernel, or -- general sample counts -- the RATIO form with its verdict in flag bit 2) against the
+        // exact planes (compiler's division, general formula)
+        if (uni_n == 0.f && ensure(ctx, wk.ratio_stats, 128 * sizeof(unsigned int)) != BCD_HIP_OK) { rc = BCD_HIP_ENOMEM; break; }
+        if ((uni_n != 0.f ? bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, uni_n, wk.stream)
+                          : bcd_launch_pairdist_rw_ratio(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag, 1.f, (unsigned int *)wk.ratio_stats.p, wk.stream)) != hipSuccess ||
             bcd_launch_pairdist(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, d_flag, 0.f, wk.stream) != hipSuccess ||
             bcd_launch_max_rel_dev((const float *)wk.T.p, T2, (const uint8_t *)wk.Cn.p, C2, W, H, search_radius, d_res, wk.stream) != hipSuccess) {
             rc = BCD_HIP_EDEVICE; break;
@@ -1833,90 +1831,11 @@ int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, cons
             hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
         memcpy(max_rel_dev, &h[0], sizeof(float));
         *count_mismatches = (int64_t)h[1];
-        if (flags) *flags = (uni_n > 0.f ? 2 : 1) | (flag << 4);
+        if (flags) *flags = (uni_n > 0.f ? 2 : 3) | (flag << 4); // low nibble: 2 = uniform kernel, 3 = RATIO form; above: the kernels' flag word (4: the RATIO form declined)
     } while (false);
     (void)hipFree(T2);
     (void)hipFree(C2);
     if (rc != BCD_HIP_OK) set_err(ctx, "approximate-distance self-test failed to run");
-    return rc;
-}
-
-// self-test + timing of the own-list distance kernel (k_similarity_nz.hip) against the exact planes and against the dense approximate kernel
-int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_ns, int W, int H, int D, int search_radius, float tau, int variant, int reps,
-                                 float *max_rel_dev, int64_t *count_mismatches, int *flags, float *ms_nz, float *ms_nz_plane_major, float *ms_dense, int64_t *prof8)
-{
-    if (!ctx || !d_hist || !d_ns || !max_rel_dev || !count_mismatches || !flags || !ms_nz || !ms_nz_plane_major || !ms_dense || W <= 0 || H <= 0 || reps < 1) return bad(ctx, "bad argument");
-    DEVICE_GUARD(ctx);
-    touch(ctx->main);
-    if (!bcd_pairdist_nz_supported(D, search_radius)) { set_err(ctx, "no own-list kernel for this depth / search radius"); return BCD_HIP_EUNSUPPORTED; }
-    Work &wk = ctx->main;
-    const size_t npix = (size_t)W * H;
-    const int nd = bcd_delta_count(search_radius);
-    RCCHK(ensure(ctx, wk.T, npix * nd * sizeof(float)));
-    RCCHK(ensure(ctx, wk.Cn, count_plane_bytes(npix, nd)));
-    RCCHK(ensure(ctx, wk.counters, 64 * sizeof(int32_t)));
-    float *T2 = nullptr;
-    uint8_t *C2 = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&T2, npix * nd * sizeof(float)));
-    if (hipMalloc((void **)&C2, npix * std::max(nd, 96)) != hipSuccess) { (void)hipFree(T2); set_err(ctx, "hipMalloc"); return BCD_HIP_EDEVICE; }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int rc = BCD_HIP_OK;
-    do {
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
-        int *d_flag = (int *)wk.counters.p + 40;
-        unsigned int *d_res = reinterpret_cast<unsigned int *>((int32_t *)wk.counters.p + 32);
-        if (hipMemsetAsync(d_flag, 0, 4 * sizeof(int), wk.stream) != hipSuccess || hipMemsetAsync(d_res, 0, 2 * sizeof(unsigned int), wk.stream) != hipSuccess ||
-            hipMemsetAsync(wk.T.p, 0, npix * nd * sizeof(float), wk.stream) != hipSuccess || hipMemsetAsync(wk.Cn.p, 0, npix * nd, wk.stream) != hipSuccess ||
-            hipMemsetAsync(T2, 0, npix * nd * sizeof(float), wk.stream) != hipSuccess || hipMemsetAsync(C2, 0, npix * nd, wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
-        // own-list planes in the plane-major layout against the exact planes (compiler's division, general formula)
-        if (bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, 1, (long long)npix, d_flag, tau, variant, wk.stream) != hipSuccess ||
-            bcd_launch_pairdist(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, d_flag + 1, 0.f, wk.stream) != hipSuccess ||
-            bcd_launch_max_rel_dev((const float *)wk.T.p, T2, (const uint8_t *)wk.Cn.p, C2, W, H, search_radius, d_res, wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
-        unsigned int h[2] = { 0u, 0u };
-        int flag = 0;
-        if (hipMemcpyAsync(h, d_res, sizeof(h), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
-            hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, wk.stream) != hipSuccess ||
-            hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
-        memcpy(max_rel_dev, &h[0], sizeof(float));
-        *count_mismatches = (int64_t)h[1];
-        *flags = flag;
-        // timing: own-list kernel, pixel-major planes (into the scratch planes) and plane-major; the dense kernel
-        float best[4] = { -1.f, -1.f, -1.f, -1.f };
-        for (int which = 0; which < 4 && rc == BCD_HIP_OK; ++which)
-            for (int r = 0; r < reps + 1; ++r) {
-                hipError_t e = hipEventRecord(e0, wk.stream);
-                if (e == hipSuccess) {
-                    if (which == 0) e = bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, 0, d_flag, tau, variant, wk.stream); // (the production layout)
-                    else if (which == 1) e = bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, 1, (long long)npix, d_flag, tau, variant, wk.stream);
-                    else e = bcd_launch_pairdist_rw(d_hist, d_ns, W, H, D, search_radius, wk.T.p, (uint8_t *)wk.Cn.p, d_flag + 1, which == 2 ? -1.f : 0.f, wk.stream);
-                }
-                if (e != hipSuccess || hipEventRecord(e1, wk.stream) != hipSuccess || hipStreamSynchronize(wk.stream) != hipSuccess) { rc = BCD_HIP_EDEVICE; break; }
-                float ms = 0.f;
-                (void)hipEventElapsedTime(&ms, e0, e1);
-                if (r > 0 && (best[which] < 0.f || ms < best[which])) best[which] = ms;
-            }
-        *ms_nz = best[0]; *ms_nz_plane_major = best[1]; *ms_dense = best[2];
-        if (prof8 && rc == BCD_HIP_OK) { // the counting instantiation (second of two launches; its own duration in microseconds in prof8[6])
-            unsigned long long *d_prof = reinterpret_cast<unsigned long long *>((int32_t *)wk.counters.p + 48); // (words 48..59)
-            unsigned long long hp[6] = { 0, 0, 0, 0, 0, 0 };
-            float ms = 0.f;
-            for (int r = 0; r < 2 && rc == BCD_HIP_OK; ++r)
-                if (hipMemsetAsync(d_prof, 0, sizeof(hp), wk.stream) != hipSuccess || hipEventRecord(e0, wk.stream) != hipSuccess ||
-                    bcd_launch_pairdist_nz(d_hist, d_ns, W, H, D, search_radius, T2, C2, 0, 0, d_flag, tau, variant, wk.stream, d_prof) != hipSuccess ||
-                    hipEventRecord(e1, wk.stream) != hipSuccess ||
-                    hipMemcpyAsync(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost, wk.stream) != hipSuccess || hipStreamSynchronize(wk.stream) != hipSuccess) rc = BCD_HIP_EDEVICE;
-            if (rc != BCD_HIP_OK) break;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            for (int i = 0; i < 6; ++i) prof8[i] = (int64_t)hp[i];
-            prof8[6] = (int64_t)(ms * 1000.f);
-            prof8[7] = (int64_t)(best[3] * 1000.f); // the dense kernel with the general (non-uniform) formula, microseconds
-        }
-    } while (false);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(T2);
-    (void)hipFree(C2);
-    if (rc != BCD_HIP_OK) set_err(ctx, "own-list distance self-test failed to run");
     return rc;
 }
 

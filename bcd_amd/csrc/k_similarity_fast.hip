@@ -75,12 +75,27 @@ template <int D> struct RwLayout {
 // COUNT (measurement only, bcd_hip_selftest_bin_work): the same kernel also counts the bins it evaluates -- per lane (b1 + b2 > 1: the
 // reference's own count, DenoisingUnit.cpp:379-381) and per wavefront instruction stream (a bin is issued when ANY of the 64 pairs needs it)
 // -- into work_count[0..1]; the production instantiation carries no trace of it.
-template <int D, bool UNI, bool COUNT = false>
-__global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H,
+//
+// RATIO (round 6; UNI = false): general sample counts at the cost of uniform ones.  With rho = n1 / n2 the reference's term is
+//     (n2 b1 - n1 b2)^2 / (n1 n2 (b1 + b2))  =  (n2 / n1) (b1 - rho b2)^2 / (b1 + b2)
+// in real arithmetic: ONE fma per bin instead of two multiplies, a subtraction and a product in the denominator, rho by one reciprocal per pixel pair
+// (rho = 1 exactly for equal counts: a frame with a uniform count that is no power of two -- 24 spp -- then runs the arithmetic of the UNI kernel).
+// The planes stay approximate planes: what changes is that the kernel and the reference no longer share `diff` and `den`, which adds ABSOLUTE
+// errors to the relative bound of the header (u = 2^-24, s = b1 + b2, B = the mass of a histogram, r = max(rho, 1 / rho)):
+//   reference vs real arithmetic:  diff = RN(RN(n2 b1) - RN(n1 b2)) is off by <= u (n2 b1 + n1 b2) + u |diff|, so a term by <= 2u r s (+ relative 7u);
+//   here vs real arithmetic:       d' = RN(b1 - rho' b2), rho' = rho (1 + 3u): |d' - d| <= u |d| + 3u rho b2, a term by <= 6u max(1, rho) b2 (+ relative);
+// summed over the evaluated bins of a pixel pair: |T' - T_ref| <= u r (2 B1 + 8 B2) + the relative part <= 10 u r max(B1, B2).  The kernel records
+//   kappa = max over the pixels of B / n   and   G = max over the pairs with C > 0 of  r max(n1, n2) / C
+// (so that 10 u r max(B1, B2) <= 10 u kappa G C for every pair), and k_ratio_verdict raises flag bit 2 (value 4) when
+//     10 u kappa G  >  2^-12 tau          (what the relative errors leave of the verified band: 2^-10 - 2^-11 [binary16] - 2e-5 [fp32] = 4.7e-4 > 2^-12)
+// -- the host then repeats the scale with the reference's operations (RATIO = false).  Pairs with C = 0 have T = 0 exactly either way.
+template <int D, bool UNI, bool COUNT = false, bool RATIO = false>
+__global__ __launch_bounds__(RW_THREADS, (UNI || RATIO) ? 4 : 2) void k_pairdist_rw(const float *__restrict__ hist, const float *__restrict__ ns, int W, int H,
                                                               int b, __half *__restrict__ T, uint8_t *__restrict__ Cn, int *range_flag,
                                                               float uni_n, int tile_row0 /* first tile row of this launch */,
-                                                              unsigned long long *work_count = nullptr)
+                                                              unsigned long long *work_count = nullptr, unsigned int *ratio_stats = nullptr /* RATIO: 8 lines of (kappa, G) */)
 {
+    static_assert(!(UNI && RATIO), "RATIO is a form of the general kernel");
     using L = RwLayout<D>;
     constexpr int Q = D / 4, NPRE = L::NPRE;
     extern __shared__ float4 lds4[];
@@ -169,7 +184,18 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
         // and the workgroup leaves at once
         if (UNI && __syncthreads_or(other_count)) { if (threadIdx.x == 0) range_flag[2] = 1; return; }
         if (!UNI && inside) n1 = ns[pix];
+        if (RATIO && hv == 0) { // kappa: the mass of the own histogram per unit of its sample count, the largest of the wavefront to its XCD's line
+            float mass = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) mass += h1[k];
+            float kap = inside ? mass * __builtin_amdgcn_rcpf(n1) * 1.00001f : 0.f; // (59 additions, a reciprocal, a product: rounded up)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) kap = fmaxf(kap, __shfl_xor(kap, off));
+            unsigned int *line = ratio_stats + 16 * (blockIdx.x & 7);
+            if (lane == 0 && __float_as_uint(kap) > *reinterpret_cast<volatile unsigned int *>(line)) atomicMax(line, __float_as_uint(kap)); // (non-negative floats order like their bits)
+        }
     }
+    float gmax = 0.f; // RATIO: largest r max(n1, n2) / C over this lane's pairs
 
     // one image line (columns col0 + cbeg ...) -> registers / -> its ring slot
     auto fetch_line = [&](float4 (&pre)[NPRE], float &pre_n, int g, int cbeg, int wcols) __attribute__((always_inline)) {
@@ -228,8 +254,9 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                 const int dc = cbeg + j;
                 const float *nb = nrow + (lane + j) * D;
                 const float *nb_next = nrow + (lane + min(j + 2, nc - 1)) * D; // (a harmless re-read after the last displacement)
-                float n2 = 1.f, n12 = 1.f;
+                float n2 = 1.f, n12 = 1.f, rho = 1.f;
                 if (!UNI) { n2 = nrow_n[lane + j]; n12 = n1 * n2; }
+                if (RATIO) rho = n1 == n2 ? 1.f : n1 * __builtin_amdgcn_rcpf(n2);
                 // (sum, number of bins counted) as one packed pair: the bin's term and its count go in with a single v_pk_fma_f32
                 v2f acc2 = { 0.f, 0.f };
                 v2f pd = { 0.f, 1.f }, pr = { 0.f, 1.f };
@@ -242,10 +269,11 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                     auto term = [&](int e) __attribute__((always_inline)) {
                         const float b1 = h1[4 * q + e];
                         if (UNI) { const float d = b1 - b2[e]; return d * d; }
+                        if (RATIO) { const float d = fmaf(-rho, b2[e], b1); return d * d; }
                         const float d = n2 * b1 - n1 * b2[e];
                         return d * d;
                     };
-                    auto den = [&](float s_) __attribute__((always_inline)) { return UNI ? s_ : n12 * s_; };
+                    auto den = [&](float s_) __attribute__((always_inline)) { return (UNI || RATIO) ? s_ : n12 * s_; };
                     // a wave-uniform branch per group of 4 bins (most groups are empty for all 64 pixels of a line segment), then a
                     // divergent branch (execz) per bin: DenoisingUnit.cpp:379 decides exactly which bins count
                     // (the group test is spelled as four lane masks OR-ed on the scalar unit: written as a per-lane `any`, the compiler
@@ -281,7 +309,13 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
                 const int nc_ = c + dc;
                 if (inside && nc_ >= 0 && nc_ < W && nr < H) {
                     const size_t o = (size_t)bcd_delta_index(dl, dc, b) * plane + pix;
-                    T[o] = __float2half_rn(acc2.x); // binary16 plane (a sum beyond 65504 becomes +inf: far above any admitted tau)
+                    float tv = acc2.x;
+                    if (RATIO) { // (from rho alone: the neighbour's count is not kept across the bins)
+                        const float q = rho == 1.f ? 1.f : __builtin_amdgcn_rcpf(rho);     // n2 / n1
+                        tv *= q;
+                        if (acc2.y > 0.f) gmax = fmaxf(gmax, fmaxf(rho, q) * (n1 * fmaxf(1.f, q)) * __builtin_amdgcn_rcpf(acc2.y)); // r max(n1, n2) / C
+                    }
+                    T[o] = __float2half_rn(tv); // binary16 plane (a sum beyond 65504 becomes +inf: far above any admitted tau)
                     Cn[o] = (uint8_t)(int)acc2.y;
                 }
             }
@@ -292,11 +326,29 @@ __global__ __launch_bounds__(RW_THREADS, UNI ? 4 : 2) void k_pairdist_rw(const f
             }
         }
     }
+    if (RATIO) {
+        gmax *= 1.00001f; // (rho carries 3u, then three reciprocals and three products: rounded up)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
+        unsigned int *line = ratio_stats + 16 * (blockIdx.x & 7) + 1;
+        if (lane == 0 && __float_as_uint(gmax) > *reinterpret_cast<volatile unsigned int *>(line)) atomicMax(line, __float_as_uint(gmax));
+    }
     if (COUNT && lane == 0 && work_count) {
         atomicAdd(work_count, (unsigned long long)cnt_lane_bins);
         atomicAdd(work_count + 1, (unsigned long long)cnt_wave_bins);
         atomicAdd(work_count + 2, (unsigned long long)cnt_wave_groups);
     }
+}
+
+// the a-posteriori check of the RATIO form (see k_pairdist_rw): one wavefront
+__global__ void k_ratio_verdict(const unsigned int *__restrict__ stats, float tau, int *range_flag)
+{
+    const int lane = threadIdx.x;
+    float kap = lane < 8 ? __uint_as_float(stats[16 * lane]) : 0.f, g = lane < 8 ? __uint_as_float(stats[16 * lane + 1]) : 0.f;
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) { kap = fmaxf(kap, __shfl_xor(kap, off)); g = fmaxf(g, __shfl_xor(g, off)); }
+    // 10 u kappa G <= 2^-12 tau, u = 2^-24  <=>  10 kappa G <= 4096 tau; NaN (a NaN count or bin: also caught by the range flag) fails
+    if (lane == 0 && !(10.f * kap * g <= 4096.f * tau)) atomicOr(range_flag, 4);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -461,6 +513,40 @@ static hipError_t pairdist_rw_rows(const float *hist, const float *ns, int W, in
 #undef BCD_RW_DEPTH
 #undef BCD_RW_LAUNCH
     return hipErrorInvalidValue;
+}
+
+// general sample counts by the RATIO form (whole frame): clears `stats` (128 words), runs the kernel and its verdict (flag value 4 in d_range_flag[0]
+// when the form's absolute-error check fails: the caller repeats the pass with bcd_launch_pairdist_rw(..., uni_n = 0))
+hipError_t bcd_launch_pairdist_rw_ratio(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,
+                                        float tau, unsigned int *stats, hipStream_t st)
+{
+    if (!stats) return hipErrorInvalidValue;
+    dim3 grid((W + RW_TW - 1) / RW_TW, (H + RW_TH - 1) / RW_TH), block(RW_THREADS);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    hipError_t e = hipMemsetAsync(stats, 0, 128 * sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+#define BCD_RW_RATIO(DD)                                                                                             \
+    case DD: {                                                                                                       \
+        const size_t lds = (size_t)RwLayout<DD>::LDS_DWORDS * 4;                                                     \
+        static std::atomic<int> granted[64];                                                                         \
+        if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || granted[dev].load() == 0)) {                                 \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairdist_rw<DD, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                           \
+            if (dev >= 0 && dev < 64) granted[dev].store(1);                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_pairdist_rw<DD, false, false, true>), grid, block, lds, st, hist, ns, W, H, b, static_cast<__half *>(T), Cn, d_range_flag, 0.f, 0, \
+                           (unsigned long long *)nullptr, stats);                                                    \
+    } break;
+    switch (D) {
+    BCD_RW_RATIO(60)
+    BCD_RW_RATIO(36)
+    BCD_RW_RATIO(24)
+    default: return hipErrorInvalidValue;
+    }
+#undef BCD_RW_RATIO
+    hipLaunchKernelGGL(k_ratio_verdict, dim3(1), dim3(64), 0, st, stats, tau, d_range_flag);
+    return hipGetLastError();
 }
 
 hipError_t bcd_launch_pairdist_rw_rows(const float *hist, const float *ns, int W, int H, int D, int b, void *T /* binary16 planes */, uint8_t *Cn, int *d_range_flag,

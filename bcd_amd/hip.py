@@ -47,7 +47,7 @@ SYMBOLS = [
     "bcd_hip_scale_begin", "bcd_hip_pixel_cov", "bcd_hip_similarity_masks", "bcd_hip_similarity_masks_deferred", "bcd_hip_similarity_masks_verdict", "bcd_hip_similarity_masks_exact", "bcd_hip_window_distances", "bcd_hip_active_set", "bcd_hip_active_init", "bcd_hip_active_step", "bcd_hip_active_step_enqueue", "bcd_hip_active_step_collect",
     "bcd_hip_bayes_accumulate", "bcd_hip_bayes_accumulate_rows", "bcd_hip_finalize", "bcd_hip_finalize_band", "bcd_hip_downscale_sum", "bcd_hip_downscale_avg",
     "bcd_hip_downscale_cov", "bcd_hip_interpolate", "bcd_hip_merge", "bcd_hip_spike_filter", "bcd_hip_accumulate_samples", "bcd_hip_zero_bad_values",
-    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_strip_order_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels", "bcd_hip_selftest_approx_distance", "bcd_hip_selftest_bin_work", "bcd_hip_selftest_nz_distance", "bcd_hip_eig27_batch",
+    "bcd_hip_visit_order", "bcd_hip_scale_seed", "bcd_hip_strip_order_seed", "bcd_hip_selftest_division", "bcd_hip_selftest_distance_kernels", "bcd_hip_selftest_approx_distance", "bcd_hip_selftest_bin_work", "bcd_hip_eig27_batch",
 ]
 
 _lib = None
@@ -348,17 +348,6 @@ class Context:
         ms = C.c_float(0)
         self._chk(lib().bcd_hip_selftest_bin_work(self.h, _dp(hist), _dp(ns), W, H, D, int(b), int(reps), C.byref(a), C.byref(b_), C.byref(c), C.byref(ms)))
         return a.value, b_.value, c.value, ms.value
-
-    def selftest_nz_distance(self, hist, ns, b=6, tau=1.0, variant=0, reps=3):
-        """own-list distance kernel: (max rel deviation vs exact planes, count mismatches, flags, ms pixel-major, ms plane-major, ms dense kernel)"""
-        H, W, D = hist.shape
-        r, n, f = C.c_float(0), C.c_int64(0), C.c_int(0)
-        m0, m1, m2 = C.c_float(0), C.c_float(0), C.c_float(0)
-        prof = (C.c_int64 * 8)()
-        self._chk(lib().bcd_hip_selftest_nz_distance(self.h, _dp(hist), _dp(ns), W, H, D, int(b), C.c_float(tau), int(variant), int(reps), C.byref(r), C.byref(n), C.byref(f),
-                                                     C.byref(m0), C.byref(m1), C.byref(m2), prof))
-        self.nz_prof = list(prof)
-        return r.value, n.value, f.value, m0.value, m1.value, m2.value
 
     def eig27_batch(self, A):
         """A: (n, 28, 28) symmetric device tensor (row / column 27 zero) -> (eigenvalues (n, 28), eigenvectors (n, 28, 28), kernel ms)"""

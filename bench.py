@@ -398,7 +398,7 @@ def main():
         def leg(frame, prm_leg, reps):
             d = [torch.from_numpy(a).cuda() for a in frame]
             ctx.denoise(*d, S, prm_leg, out)   # two untimed calls: a new kind of frame grows workspaces, settles the marking batch and the list-length
-            ctx.denoise(*d, S, prm_leg, out)   # guess, and (general sample counts) finds out which scales the own-list kernel declines
+            ctx.denoise(*d, S, prm_leg, out)   # guess, and (general sample counts) finds out whether a scale declines the RATIO form of the distance kernel
             torch.cuda.synchronize()
             each = []
             t1 = time.perf_counter()
@@ -482,7 +482,7 @@ def main():
         del out_b, ref2
         # General sample counts (src/core/DenoisingUnit.cpp:371-383 takes any n1, n2): the headline frame at a uniform 24 spp (not
         # a power of two: the count products do not drop out) and with per-pixel counts drawn from {16, 24, 32, 48} (48-spp statistics thinned per
-        # pixel: histogram and count scaled by 1/3, 1/2, 2/3 or 1 -- what an adaptive sampler's early exit leaves).  Both take the own-list distance
+        # pixel: histogram and count scaled by 1/3, 1/2, 2/3 or 1 -- what an adaptive sampler's early exit leaves).  Both take the RATIO form of the distance
         # kernel (similarity_path 2 in per_scale).
         f24 = core.synthetic_scene(W, H, 24, 1234, args.sigma, args.spikes)
         extras["nonuniform_counts"] = {"uniform_24spp": leg(f24, prm, 3)}

@@ -68,8 +68,8 @@ typedef struct bcd_hip_scale_stats {
     float   ms_active;
     float   ms_bayes;
     float   ms_total;
-    int32_t similarity_path;  /* 1 = approximate planes + exact verification at the threshold, 2 = the same with the own-list distance kernel
-                               * (general sample counts, search radius 6), 0 = exact planes */
+    int32_t similarity_path;  /* 1 = approximate planes + exact verification at the threshold, 2 = the same with the RATIO form of the distance
+                               * kernel (general sample counts: any counts that are not one power of two), 0 = exact planes */
     int32_t borderline_pairs; /* pairs re-evaluated exactly (similarity_path >= 1)  */
     int32_t cu_share;         /* share (%) of the CU slots this scale's persistent estimate kernels took (100: all)  */
     int32_t spectral_inverses; /* full estimates (3x3 patches, default search radius) whose matrix inverse failed the sweep's checks and took
@@ -353,18 +353,10 @@ int bcd_hip_selftest_bin_work(bcd_hip_ctx *ctx, const float *d_hist, const float
  * patch distance d(p, p + delta) computed from the approximate planes from the one computed from the exact planes, over all pairs of
  * main pixels (bound 5e-4, measured 2.4e-4; must stay below 2^-10 = 9.8e-4, BCD_APPROX_DELTA, the half-width of the band that is
  * re-evaluated exactly); *count_mismatches = pairs whose
- * integer bin counts differ (must be 0); *flags as *variant above */
+ * integer bin counts differ (must be 0); *flags: low nibble 2 = the uniform kernel ran, 3 = the RATIO form (general sample counts: the production kernel for
+ * them since round 6), the kernels' flag word above it (bit 2, value 4 << 4: the RATIO form's absolute-error check declined) */
 int bcd_hip_selftest_approx_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius,
                                      float *max_rel_dev, int64_t *count_mismatches, int *flags);
-
-/* self-test + timing of the own-list pair-distance kernel (k_pairdist_nz: the loop runs over the own pixel's non-zero bins, the bins with
- * b1 = 0 enter by the closed form the rule of src/core/DenoisingUnit.cpp:379-383 allows; search radius 6 only): *max_rel_dev /
- * *count_mismatches as above (against the exact planes), *flags = the kernel's range (1) / absolute-error (4) flag bits; best-of-reps kernel times:
- * *ms_nz (pixel-major planes), *ms_nz_plane_major, *ms_dense (k_pairdist_rw on the same input).  variant: bit 0 = own bins by v_readlane instead of scalar loads, bit 1 = straight-line bin body;
- * prof8 (may be NULL): shader-clock sums of a counting launch -- staging, S pass, wavefronts inside the item loop, item phase x 16, whole workgroups --, the bin slots
- * issued, that launch's duration in microseconds, and the dense kernel's with the general (non-uniform) formula */
-int bcd_hip_selftest_nz_distance(bcd_hip_ctx *ctx, const float *d_hist, const float *d_nsamples, int W, int H, int D, int search_radius, float tau, int variant,
-                                 int reps, float *max_rel_dev, int64_t *count_mismatches, int *flags, float *ms_nz, float *ms_nz_plane_major, float *ms_dense, int64_t *prof8);
 
 /* the eigensolver of the Bayesian steps on its own (Eigen::SelfAdjointEigenSolver of DenoisingUnit.cpp:589,617 for 27 x 27 matrices):
  * d_A = n symmetric matrices, 28 x 28 floats each, row-major, row / column 27 zero; d_eig[n][28] = eigenvalues (unordered, entry 27 = 0),

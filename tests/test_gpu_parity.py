@@ -567,9 +567,9 @@ def test_other_histogram_depths(hipctx, nbins):
 
 
 @pytest.mark.parametrize("nbins", [12, 8])
-def test_own_list_kernel_other_histogram_depths_and_mixed_counts(hipctx, nbins):
-    """the own-list distance kernel has instantiations for D = 36 and 24 too (pixel stride D + 1 dwords: odd, conflict-free): mixed sample counts
-    at those depths go through it (masks and counts against the oracle), and its planes agree with the exact ones"""
+def test_ratio_form_other_histogram_depths_and_mixed_counts(hipctx, nbins):
+    """the RATIO form of the distance kernel (general sample counts) has instantiations for D = 36 and 24 too: mixed sample counts at those depths go
+    through it (masks and counts against the oracle), and its planes agree with the exact ones"""
     W, H = 90, 50
     rng = np.random.default_rng(nbins)
     samples, _ = ol.synth_samples(W, H, 16, seed=7, sigma=0.3, spike_prob=0.01)
@@ -578,8 +578,8 @@ def test_own_list_kernel_other_histogram_depths_and_mixed_counts(hipctx, nbins):
     ns, mean, cov, hist = ol.oracle_ops()["accumulate"](np.ascontiguousarray(samples[keep]), W, H, nbins)
     assert hist.shape[-1] == 3 * nbins and len(np.unique(ns)) > 3
     d_hist, d_ns = dev(hist, ns)
-    rel, count_mismatches, flags, *_ = hipctx.selftest_nz_distance(d_hist, d_ns, 6, 1.0, 3, 1)
-    assert count_mismatches == 0 and flags == 0 and rel < 2.0 ** -10 / 1.9
+    rel, count_mismatches, flags = hipctx.selftest_approx_distance(d_hist, d_ns, 6)
+    assert count_mismatches == 0 and flags == 3 and rel < 2.0 ** -10 / 1.9     # 3: the RATIO form ran, no flag above it
     mask, cnt = hipctx.similarity_masks(d_hist, d_ns, 1, 6, 1.0)
     wmask, wcnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
     assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask) and np.array_equal(cnt.cpu().numpy(), wcnt)
@@ -688,10 +688,9 @@ def test_1080p_bench_workload_against_the_oracle(hipctx):
 
 
 def _nonuniform_full_size_check(hipctx, W, H, frame, seed, expect_paths):
-    """a frame whose sample counts are not one power of two, at a timed leg's size, 3 scales, -m 1 -r 1, against the oracle's ordered visit: the own-list
-    distance kernel and the pixel-major mask kernel serve the finest scale (similarity_path 2), a coarse scale with hundreds of samples per pixel after its
-    downscale_sums takes the decline path to the dense kernel's general formula (path 1; which scales do is a property of the frame and pinned per test),
-    and the frame is the oracle's"""
+    """a frame whose sample counts are not one power of two, at a timed leg's size, 3 scales, -m 1 -r 1, against the oracle's ordered visit: the RATIO
+    form of the distance kernel serves the scales (similarity_path 2; a scale whose a-posteriori error check fails would take the reference's operations,
+    path 1 -- which scales do is a property of the frame and pinned per test), and the frame is the oracle's"""
     import bcd_amd.hip as bh
     S = 3
     col, ns, hist, cov = frame
@@ -719,7 +718,7 @@ def test_1080p_24spp_frame_against_the_oracle(hipctx):
     96 x 72): 1920 x 1080, a uniform 24 samples per pixel -- not a power of two, so the count products do not drop out"""
     import bcd_amd.core as core
     W, H = 1920, 1080
-    _nonuniform_full_size_check(hipctx, W, H, core.synthetic_scene(W, H, 24, 1234, 0.35, 0.01), 1234, [2, 2, 1])
+    _nonuniform_full_size_check(hipctx, W, H, core.synthetic_scene(W, H, 24, 1234, 0.35, 0.01), 1234, [2, 2, 2])
 
 
 @pytest.mark.gpu
@@ -733,7 +732,7 @@ def test_1080p_mixed_sample_counts_frame_against_the_oracle(hipctx):
     ns_mix = np.ascontiguousarray(np.rint(ns48 * keep).astype(np.float32))
     hist_mix = np.ascontiguousarray(hist48 * (ns_mix / ns48))
     assert sorted(np.unique(ns_mix)) == [16.0, 24.0, 32.0, 48.0]
-    _nonuniform_full_size_check(hipctx, W, H, (col48, ns_mix, hist_mix, cov48), 1234, [2, 1, 1])
+    _nonuniform_full_size_check(hipctx, W, H, (col48, ns_mix, hist_mix, cov48), 1234, [2, 2, 2])
 
 
 @pytest.mark.gpu
@@ -885,31 +884,38 @@ def test_fast_similarity_path_equals_exact_kernels(hipctx, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["bench_noisy", "bench_clean", "mixed_counts", "ragged", "one_tile"])
-@pytest.mark.parametrize("variant", [1, 3])
-def test_own_list_distance_kernel_counts_exact_and_distances_inside_the_band(hipctx, kind, variant):
-    """k_pairdist_nz (production for every frame whose sample counts are not one power of two: similarity_path 2): the pair sums over the own pixel's non-zero bins with the closed form of
-    DenoisingUnit.cpp:379-383 for its empty bins -- bin counts identical to the exact planes', patch distances inside the verified band,
-    no range / absolute-error flag on these inputs; mixed sample counts take the general formula"""
+@pytest.mark.parametrize("kind", ["uniform_24", "uniform_100", "mixed_counts", "mixed_wide_b12", "ragged", "one_tile"])
+def test_ratio_form_of_the_distance_kernel_counts_exact_and_distances_inside_the_band(hipctx, kind):
+    """k_pairdist_rw<D, false, false, RATIO> (production for every frame whose sample counts are not one power of two: similarity_path 2): one fma per bin
+    with rho = n1 / n2, the count ratio applied once per pair -- bin counts identical to the exact planes', patch distances inside the verified band, its
+    absolute-error verdict clear on these inputs; uniform counts that are no power of two (rho == 1: the uniform kernel's arithmetic), counts mixed 1 : 3,
+    the large search window, ragged sizes"""
     import bcd_amd.core as core
-    if kind == "bench_noisy":
-        col, ns, hist, cov = core.synthetic_scene(320, 200, 32, 1234, 0.35, 0.01)
-    elif kind == "bench_clean":
-        col, ns, hist, cov = core.synthetic_scene(320, 200, 32, 1234, 0.10, 0.0)
-    elif kind == "mixed_counts":
+    b = 6
+    if kind == "uniform_24":
+        col, ns, hist, cov = core.synthetic_scene(320, 200, 24, 1234, 0.35, 0.01)
+    elif kind == "uniform_100":
+        col, ns, hist, cov = core.synthetic_scene(200, 120, 100, 5, 0.25, 0.0)
+    elif kind in ("mixed_counts", "mixed_wide_b12"):
         rng = np.random.default_rng(3)
-        samples, _ = ol.synth_samples(200, 64, 16, seed=5, sigma=0.3, spike_prob=0.01)
-        keep = rng.random(samples.shape[0]) < 0.75
-        keep[::16] = True
-        ns, mean, cov, hist = ol.oracle_ops()["accumulate"](np.ascontiguousarray(samples[keep]), 200, 64)
+        W, H = (200, 64) if kind == "mixed_counts" else (120, 70)
+        col, ns, hist, cov = core.synthetic_scene(W, H, 48, 5, 0.3, 0.01)
+        keep = rng.choice(np.array([1.0 / 3.0, 0.5, 2.0 / 3.0, 1.0], np.float32), size=(H, W, 1)).astype(np.float32)
+        ns2 = np.ascontiguousarray(np.rint(ns * keep).astype(np.float32))
+        hist, ns = np.ascontiguousarray(hist * (ns2 / ns)), ns2
+        b = 6 if kind == "mixed_counts" else 12
     elif kind == "ragged":
-        col, ns, hist, cov = core.synthetic_scene(131, 37, 8, 11, 0.3, 0.01)
+        col, ns, hist, cov = core.synthetic_scene(131, 37, 12, 11, 0.3, 0.01)
     else:
-        col, ns, hist, cov = core.synthetic_scene(19, 9, 8, 2, 0.3, 0.01)
+        col, ns, hist, cov = core.synthetic_scene(19, 9, 12, 2, 0.3, 0.01)
     d_hist, d_ns = dev(hist, ns)
-    rel, count_mismatches, flags, ms_nz, ms_pl, ms_dense = hipctx.selftest_nz_distance(d_hist, d_ns, 6, 1.0, variant, 1)
-    assert count_mismatches == 0 and flags == 0
+    rel, count_mismatches, flags = hipctx.selftest_approx_distance(d_hist, d_ns, b)
+    assert count_mismatches == 0 and flags == 3, (count_mismatches, flags)
     assert rel < 2.0 ** -10 / 1.9, rel
+    mask, cnt = hipctx.similarity_masks(d_hist, d_ns, 1, b, 1.0)
+    assert hipctx.stats(0).similarity_path in (0, 1, 2)                  # (stage call: the path is reported by the frame tests)
+    wmask, wcnt = ol.similarity_masks(ns, hist, 1, b, 1.0)
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), wmask) and np.array_equal(cnt.cpu().numpy(), wcnt)
 
 
 @pytest.mark.gpu
@@ -957,9 +963,9 @@ def _drop_samples(W, H, spp, seed, keep_frac, sigma=0.3):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,S", [(0.0, 1), (1.0, 2)])
-def test_frames_with_mixed_sample_counts_take_the_own_list_kernel_and_match_the_oracle(hipctx, m, S):
-    """general sample counts (src/core/DenoisingUnit.cpp:371-383 takes any n1, n2): the production path is the own-list distance kernel + the
-    pixel-major mask kernel (similarity_path 2); the frame is the oracle's"""
+def test_frames_with_mixed_sample_counts_take_the_ratio_form_and_match_the_oracle(hipctx, m, S):
+    """general sample counts (src/core/DenoisingUnit.cpp:371-383 takes any n1, n2): the production path is the RATIO form of the
+    distance kernel (similarity_path 2); the frame is the oracle's"""
     import bcd_amd.hip as bh
     W, H = 96, 72
     col, ns, hist, cov = _drop_samples(W, H, 16, 9, 0.7)
@@ -977,22 +983,26 @@ def test_frames_with_mixed_sample_counts_take_the_own_list_kernel_and_match_the_
 
 
 @pytest.mark.gpu
-def test_own_list_kernel_declines_when_its_error_bound_fails_and_the_dense_kernel_takes_over(hipctx):
-    """hundreds of samples per pixel (a coarse pyramid level): the own-list kernel's absolute-error check fails (flag bit 2), the pass is repeated with the
-    dense kernel's general formula, and the masks are the exact kernels' either way"""
+def test_ratio_form_declines_when_its_error_bound_fails_and_the_reference_operations_take_over(hipctx):
+    """counts spread 1 : 64 over a frame with hundreds of samples per pixel: the RATIO form's a-posteriori check (10 u kappa G <= 2^-12 tau) fails
+    (flag value 4), the pass is repeated with the reference's operations, and the masks are the exact kernels' either way"""
     W, H = 64, 40
     col, ns, hist, cov = _drop_samples(W, H, 16, 4, 0.8)
-    hist, ns = np.ascontiguousarray(hist * 40.0), np.ascontiguousarray(ns * 40.0)   # ~ 500 samples per pixel, counts still mixed
+    scale = np.where(np.random.default_rng(1).random((H, W, 1)) < 0.5, 640.0, 10.0).astype(np.float32)   # 40 ... 10 000 samples per pixel
+    hist, ns = np.ascontiguousarray(hist * scale), np.ascontiguousarray(ns * scale)
     d_hist, d_ns = dev(hist, ns)
-    rel, count_mismatches, flags, *_ = hipctx.selftest_nz_distance(d_hist, d_ns, 6, 1.0, 3, 1)
-    assert count_mismatches == 0 and (flags & 4) != 0
+    rel, count_mismatches, flags = hipctx.selftest_approx_distance(d_hist, d_ns, 6)
+    assert count_mismatches == 0 and (flags & 15) == 3 and ((flags >> 4) & 4) != 0, flags
     import bcd_amd.hip as bh
     fresh = bh.Context(0)                       # (a workspace that has not met such a frame yet)
-    m1, c1 = fresh.similarity_masks(d_hist, d_ns, 1, 6, 1.0)
-    wmask, wcnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
-    assert np.array_equal(m1.cpu().numpy().view(np.uint32), wmask) and np.array_equal(c1.cpu().numpy(), wcnt)
-    m2, c2 = fresh.similarity_masks(d_hist, d_ns, 1, 6, 1.0)      # second call: the workspace goes to the dense kernel directly
-    assert np.array_equal(m2.cpu().numpy().view(np.uint32), wmask)
+    try:
+        m1, c1 = fresh.similarity_masks(d_hist, d_ns, 1, 6, 1.0)
+        wmask, wcnt = ol.similarity_masks(ns, hist, 1, 6, 1.0)
+        assert np.array_equal(m1.cpu().numpy().view(np.uint32), wmask) and np.array_equal(c1.cpu().numpy(), wcnt)
+        m2, c2 = fresh.similarity_masks(d_hist, d_ns, 1, 6, 1.0)      # second call: the workspace goes to the reference's operations directly
+        assert np.array_equal(m2.cpu().numpy().view(np.uint32), wmask)
+    finally:
+        fresh.close()
 
 
 @pytest.mark.gpu
@@ -1827,7 +1837,7 @@ def test_streamed_host_upload_equals_the_resident_path(hipctx, spike_factor):
         assert rel_linf(got, want) < 1e-5
         # both paths stay on the approximate-planes kernels: a single odd pixel that the host's sample (streamed path) or the speculative
         # launch on the first pixel's count (resident path) misses is caught by the kernel's per-pixel check, and the pass is repeated with
-        # the general (non-uniform) formula -- since round 5 by the own-list distance kernel (similarity_path 2)
+        # general sample counts -- since round 6 by the RATIO form of the same kernel (similarity_path 2)
         # (with the prefilter the odd pixel may itself be replaced by a neighbour, which makes the counts uniform again)
         both = (path, hipctx.stats(0).similarity_path)
         assert both == (1, 1) if (variant == "uniform" or spike_factor > 0 and both == (1, 1)) else both == (2, 2)

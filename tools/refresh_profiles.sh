@@ -14,7 +14,7 @@ grep '^{' gpurun_out/final_bench_unprofiled.log | tail -1 > gpurun_out/final_unp
 tools/prof.sh final_4k --no-extras --width 3840 --height 2160 --spp 8 --sigma 0.15 --spikes 0 --steps 6 --warmup 2 > /dev/null
 tools/prof.sh final_4k_b12 --no-extras --width 3840 --height 2160 --spp 8 --sigma 0.25 --spikes 0.01 --search-radius 12 --steps 4 --warmup 1 > /dev/null
 BCD_HIP_SERIAL_SCALES=1 tools/prof.sh final_4k_b12_serial --no-extras --width 3840 --height 2160 --spp 8 --sigma 0.25 --spikes 0.01 --search-radius 12 --steps 4 --warmup 1 > /dev/null
-# general sample counts (round 5): the headline frame at a uniform 24 spp -- own-list distance kernel + pixel-major mask kernel on scales 0 / 1
+# general sample counts: the headline frame at a uniform 24 spp -- the RATIO form of the distance kernel (round 6; round 5: own-list kernel + pixel-major masks)
 tools/prof.sh final_nonuni --no-extras --spp 24 --steps 10 --warmup 2 > /dev/null
 BCD_HIP_SERIAL_SCALES=1 tools/prof.sh final_nonuni_serial --no-extras --spp 24 --steps 10 --warmup 2 > /dev/null
 # one rank's band of the 4K frame through the band driver with RCCL in loopback (bench.py predicted_8gpu): kernel timeline of one step
