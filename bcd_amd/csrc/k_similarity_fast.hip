@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64) void k_verify_pairs_lds(const float *__restrict
         }
         if (live && o == 0) {
             const float d = tot / (float)ctot; // 0/0 = NaN -> not similar
-            if (d <= tau) atomicOr(fwd + (size_t)ent.x * fwords + (ent.y >> 5), 1u << (ent.y & 31));
+            if (d <= tau) atomicOr(fwd + (size_t)(ent.y >> 5) * W * H + ent.x, 1u << (ent.y & 31)); // (word-plane layout: word * pixels + pixel)
         }
     }
 }
