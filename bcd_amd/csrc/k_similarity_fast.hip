@@ -572,9 +572,12 @@ hipError_t bcd_launch_verify_pairs(const float *hist, const float *ns, int W, in
                                    int capacity, uint32_t *fwd, hipStream_t st)
 {
     const int fwords = (bcd_delta_count(b) + 31) / 32;
-    // (the number of pairs is on the device: a fixed grid of 16 wavefronts per CU; with nothing listed every wavefront leaves at once)
+    // (the number of pairs is on the device: a fixed grid of 8 wavefronts per CU; with nothing listed every wavefront leaves at once)
     if ((D & 3) != 0) return hipErrorInvalidValue; // (every depth bcd_pairdist_rw_supported admits is a multiple of four)
-    hipLaunchKernelGGL(k_verify_pairs_lds, dim3(4096), dim3(64), 0, st, hist, ns, W, H, D >> 2, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
+    // grid (round 6, measured on 2.7 M pairs of a 3840x2160 b = 12 scale): 512 wavefronts 3.0 ms (latency: five dependent round trips per trip of 63
+    // pixel pairs), 1024 1.66, 1536 .. 2048 1.20, 3072 .. 7168 1.41, 4096 1.52 (14 workgroups fit a CU's LDS: the last 512 ran as a second round) --
+    // more wavefronts in flight only spread the rows being fetched over more of the list, and the L2 keeps fewer of the shared ones
+    hipLaunchKernelGGL(k_verify_pairs_lds, dim3(2048), dim3(64), 0, st, hist, ns, W, H, D >> 2, b, tau, (const uint2 *)list, d_count, capacity, fwords, fwd);
     return hipGetLastError();
 }
 
