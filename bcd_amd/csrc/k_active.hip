@@ -240,8 +240,10 @@ __global__ __launch_bounds__(256) void k_mark_round(const uint32_t *__restrict__
     constexpr int side = 2 * B + 1, WORDS = (side * side + 31) / 32, tw = 16 + 2 * B;
     static_assert(tw <= 64, "row bitmaps are 64-bit");
     // states of the tile + halo as two bitmaps per row: processed (IN) and undecided
+    // (plain LDS arrays: a `volatile unsigned long long *` alias of them is a GENERIC pointer -- until round 6 every probe below was a flat load with
+    // system scope and a full wait behind it, 50 of them per iteration through 50 precomputed 64-bit addresses: 148 VGPRs at b = 12.  The barriers
+    // between the iterations already keep the compiler from carrying bitmap values across them.)
     __shared__ unsigned long long s_in_[tw], s_und_[tw];
-    volatile unsigned long long *s_in = s_in_, *s_und = s_und_;
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + lx, r = blockIdx.y * 16 + ly;
     const bool inside = c < W && r < H;
@@ -298,8 +300,8 @@ __global__ __launch_bounds__(256) void k_mark_round(const uint32_t *__restrict__
             uint32_t hit_in = 0u, hit_und = 0u;
 #pragma unroll
             for (int j = 0; j < side; ++j) {
-                hit_in |= (uint32_t)(s_in[ly + j] >> lx) & drow[j];
-                hit_und |= (uint32_t)(s_und[ly + j] >> lx) & drow[j];
+                hit_in |= (uint32_t)(s_in_[ly + j] >> lx) & drow[j];
+                hit_und |= (uint32_t)(s_und_[ly + j] >> lx) & drow[j];
             }
             v = hit_in != 0u ? BCD_ST_OUT : (hit_und != 0u ? BCD_ST_UNDECIDED : BCD_ST_IN);
         }
