@@ -168,6 +168,7 @@ def test_pyramid_and_merge_bitexact(hipctx):
     assert bits_equal(hipctx.downscale_sum(d_hist).cpu().numpy(), o["dsum"](hist))
     assert bits_equal(hipctx.downscale_sum(d_ns).cpu().numpy(), o["dsum"](ns))
     assert bits_equal(hipctx.downscale_avg(d_col).cpu().numpy(), o["davg"](col))
+    assert bits_equal(hipctx.downscale_avg(d_hist).cpu().numpy(), o["davg"](hist))  # (depth 60: the four-bins-per-thread kernel, average mode)
     assert bits_equal(hipctx.downscale_cov(d_cov, d_ns).cpu().numpy(), o["dcov"](cov, ns))
     lo = o["davg"](col)
     (d_lo,) = dev(lo)
@@ -833,10 +834,13 @@ def test_distance_planes_of_a_benchmark_frame_bitexact(hipctx, sigma, spikes):
 
 
 @pytest.mark.gpu
-def test_similarity_masks_bitexact_on_a_large_scale(hipctx):
-    """scales of >= 400 k pixels take the four-columns-per-lane forward-mask kernel: masks and counts against the oracle (host threads)"""
+@pytest.mark.parametrize("W,H,b", [(1024, 400, 6), (1000, 402, 3)])
+def test_similarity_masks_bitexact_on_a_large_scale(hipctx, W, H, b):
+    """scales of >= 400 k pixels take the four-columns-per-lane forward-mask kernel: masks and counts against the oracle (host threads).  Second case:
+    a height that is no multiple of the kernel's four-line strips, a width that is no multiple of its 248 columns, and a radius whose 25 forward planes
+    are one short word with an odd count (the kernel evaluates two planes per trip and drops the extra bit; other radii than 6 / 12 also take the
+    generic symmetric-mask kernel on the word-plane layout)"""
     import bcd_amd.core as core
-    W, H, b = 1024, 400, 6
     col, ns, hist, cov = core.synthetic_scene(W, H, 16, 99, 0.3, 0.01)
     # the plane entries of pairs that leave the image are never written: leave fp32 planes of another frame in the workspace first (read as
     # binary16 they are negative numbers and NaNs), so that a kernel that lets them reach a border pixel's decision fails here (round 6)

@@ -1,7 +1,9 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out
-python tools/exp_m0_leg.py --head-only 2>&1 | tail -2
-BCD_HIP_TWO_LANES=0 python tools/exp_m0_leg.py --head-only 2>&1 | tail -2
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "1080p or low_sample or budget" > gpurun_out/r6x_tests.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pyramid or fixtures or pixel_cov or multiscale_parity or similarity_masks_bitexact or mono_parity or band_path_exact or multi_rank_driver_equals" > gpurun_out/r6x_tests.log 2>&1
 echo "rc=$? $(tail -1 gpurun_out/r6x_tests.log)"
+tools/prof.sh r6x_4k --no-extras --width 3840 --height 2160 --spp 8 --sigma 0.15 --spikes 0 --steps 6 --warmup 2 | cut -c60-130
+grep -E "downscale|pixel_cov|total kernel" gpurun_out/r6x_4k_stats.txt | cut -c1-50,76-
+python bench.py --no-extras --no-cpu-baseline --steps 30 --warmup 10 2>&1 | tail -1 | cut -c60-130
+rm -rf gpurun_out/prof_r6x_*
