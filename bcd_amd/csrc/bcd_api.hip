@@ -56,6 +56,7 @@ hipError_t bcd_launch_zero_bad(float *, int64_t, hipStream_t);
 hipError_t bcd_launch_downscale(int, const float *, int, int, int, float *, hipStream_t);
 hipError_t bcd_launch_downscale_cov(const float *, const float *, int, int, float *, hipStream_t);
 hipError_t bcd_launch_interpolate(int, const float *, int, int, int, float *, int, int, hipStream_t);
+hipError_t bcd_launch_merge_interpolate(const float *, const float *, int, int, int, float *, int, int, hipStream_t);
 hipError_t bcd_launch_spike(const float *, const float *, const float *, const float *, int, int, int, float, float *, float *,
                             float *, float *, hipStream_t);
 hipError_t bcd_launch_accumulate_samples(const float *, const float *, int64_t, int, int, float, float, float *, float *, float *, float *, hipStream_t);
@@ -830,8 +831,7 @@ int merge_on(bcd_hip_ctx *ctx, Work &wk, float *d_hi, int W, int H, const float 
     const int w2 = W / 2, h2 = H / 2;
     RCCHK(ensure(ctx, wk.tmp_lo, (size_t)w2 * h2 * D * sizeof(float)));
     HIPCHK(ctx, bcd_launch_downscale(1, d_hi, W, H, D, (float *)wk.tmp_lo.p, wk.stream));
-    HIPCHK(ctx, bcd_launch_interpolate(1, (const float *)wk.tmp_lo.p, w2, h2, D, d_hi, W, H, wk.stream));
-    HIPCHK(ctx, bcd_launch_interpolate(2, d_lo, w2, h2, D, d_hi, W, H, wk.stream));
+    HIPCHK(ctx, bcd_launch_merge_interpolate((const float *)wk.tmp_lo.p, d_lo, w2, h2, D, d_hi, W, H, wk.stream)); // (round 6: the two interpolations in one pass)
     return BCD_HIP_OK;
 }
 
