@@ -492,6 +492,22 @@ def main():
         hist_mix = np.ascontiguousarray(hist48 * (ns_mix / ns48))
         extras["nonuniform_counts"]["mixed_16_24_32_48"] = leg((col48, ns_mix, hist_mix, cov48), prm, 3)
         del col48, ns48, hist48, cov48, hist_mix, ns_mix, f24
+        # BASELINE configs[1]'s frame (1280x720, 3-scale defaults): the small end of north_star's "720p-4K" range, untimed leg
+        if (W, H) != (1280, 720):
+            w7, h7 = 1280, 720
+            d7 = [torch.from_numpy(a).cuda() for a in core.synthetic_scene(w7, h7, args.spp, 1234, args.sigma, args.spikes)]
+            out7 = torch.empty((h7, w7, 3), dtype=torch.float32, device="cuda")
+            ctx.denoise(*d7, S, prm, out7)
+            ctx.denoise(*d7, S, prm, out7)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                ctx.denoise(*d7, S, prm, out7)
+            torch.cuda.synchronize()
+            ms7 = (time.perf_counter() - t1) * 1e3 / 5
+            extras["frame_720p"] = {"value": round(w7 * h7 / 1e6 / (ms7 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms7, 4), "steps": 5,
+                                    "workload": "1280x720 frame of the same generator and flags (BASELINE configs[1]), inputs resident"}
+            del d7, out7
         # BASELINE configs[3]'s frame on this one GPU: the N = 1 point of the 4K strong-scaling curve (north_star), untimed leg
         if not args.no_4k:
             w4, h4 = 3840, 2160
