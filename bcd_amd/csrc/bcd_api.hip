@@ -622,7 +622,9 @@ int bayes(bcd_hip_ctx *ctx, Work &wk, const float *d_colors, const float *d_pixc
     }
     if (w == 1) {
         const size_t rec = bcd_bayes27_record_bytes();
-        const int chunk_max = 1 << 17; // 131072 pixels = 1.3 GB of records
+        // (round 6: 2^18 instead of 2^17 -- half as many drains of the three persistent kernels on a -m 0 frame: 60.9 -> 60.2-60.5 ms at 1080p; sizes aligned to
+        // the eigensolver's 6 144 matrices per round of the grid made no difference)
+        const int chunk_max = 1 << 18; // 262144 pixels = 2.6 GB of records
         RCCHK(ensure(ctx, wk.work_q, BCD_WORK_INTS * sizeof(int32_t)));
         auto launch_chunk = [&](int first, int n, bool defer, const int *d_n) -> int {
             if (wk.clean_wq) wk.clean_wq = false; // (k_scale_begin)

@@ -1934,3 +1934,17 @@ def test_multi_rank_frame_timeout_fails_the_frame_and_the_handle_recovers(hipctx
         md.close()
     want = hipctx.denoise_host(*frame, S, prm)
     assert rel_linf(got, want) < 1e-5
+
+
+@pytest.mark.gpu
+def test_seeded_random_configurations_against_the_oracle(hipctx):
+    """forty seeded random configurations (tools/fuzz_parity.py: ragged / narrow / odd frame sizes, 1-3 scales, b = 1 .. 12, tau 0.5 .. 2, 1 .. 48 samples per
+    pixel and per-pixel mixtures, -m 0 / 1, -r 0 / 1): masks and |S| of the finest scale bit for bit, the frame's finite pattern, relative L-inf < 1e-4.
+    (2 000 cases of the same generator ran clean in round 6; the worst were 2-3-spp frames with sigma 0.05 at 4e-5: ill-conditioned inverses.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    lines = []
+    bad, refused, worst = fz.run_cases(hipctx, 40, 2026, say=lines.append)
+    assert bad == 0 and refused == 0 and worst < TOL, "\n".join(l for l in lines if "MISMATCH" in l or "refused" in l)

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""GPU box: seeded random configurations of the hot path against the CPU oracle (test infrastructure: the oracle is the checker).
+Frame sizes (ragged, narrower than a tile, odd), scales, search radius, threshold, sample counts (1 .. 48, sometimes mixed per pixel), noise level, -m 0 / -m 1,
+-r 0 / -r 1.  Checks per case: similarity masks and |S| of the finest scale bit for bit, the denoised frame's finite pattern and relative L-inf < 1e-4.
+usage: python tools/fuzz_parity.py [n_cases] [seed] [--big] [--only=i,j,..] [--strict] [--dump=dir]   -> one line per case, a summary, exit code 1 on any mismatch
+(--big: frames up to 700 x 400; --only: evaluate these cases of the sequence; --strict: bcd_hip_set_strict_eigensolver)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+sys.path.insert(0, os.path.join(R, "tests"))
+import oracle_lib as ol  # noqa: E402
+import bcd_amd.hip as bh  # noqa: E402
+
+
+def cases(n_cases, seed, only=None, big=False):
+    """the seeded sequence of configurations: dicts with the parameters and the four input images (built only for the cases asked for)"""
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        S = int(rng.choice([1, 2, 3]))
+        b = int(rng.choice([1, 2, 3, 4, 6, 6, 6, 9, 12]))
+        W = int(rng.integers(max(12, 4 << (S - 1)), 700 if big else 150))
+        H = int(rng.integers(max(12, 4 << (S - 1)), 400 if big else 110))
+        spp = int(rng.choice([1, 2, 3, 4, 8, 16, 24, 32, 48]))
+        sigma = float(rng.choice([0.05, 0.15, 0.35, 0.6]))
+        spike = float(rng.choice([0.0, 0.01, 0.05]))
+        tau = float(rng.choice([0.5, 1.0, 1.0, 1.0, 2.0]))
+        m = float(rng.choice([0.0, 1.0, 1.0]))
+        ro = int(rng.choice([0, 1]))
+        seed_c = int(rng.integers(1, 1 << 20))
+        mixed = bool(rng.random() < 0.25) and spp >= 4
+        keep = rng.choice(np.array([0.25, 0.5, 0.75, 1.0], np.float32), size=(H, W, 1)).astype(np.float32) if mixed else None
+        if only is not None and case not in only:
+            continue
+        col, ns, hist, cov, _ = ol.synth_inputs(W, H, spp, seed_c, sigma, spike)
+        if mixed:  # thinned per pixel: what an adaptive sampler's early exit leaves
+            ns2 = np.ascontiguousarray(np.maximum(1.0, np.rint(ns * keep[..., 0] if ns.ndim == 2 else ns * keep)).astype(np.float32))
+            hist = np.ascontiguousarray(hist * (ns2 / ns).reshape(H, W, 1)).astype(np.float32)
+            ns = ns2
+        yield dict(case=case, S=S, b=b, W=W, H=H, spp=spp, sigma=sigma, spike=spike, tau=tau, m=m, ro=ro, seed=seed_c, mixed=mixed, col=col, ns=ns, hist=hist, cov=cov)
+
+
+def visiting_orders(c):
+    if c["m"] == 0.0:
+        return None
+    orders, w_, h_ = [], c["W"], c["H"]
+    for s in range(c["S"]):
+        orders.append(bh.visit_order(w_, h_, 1, c["ro"], bh.scale_seed(c["seed"], s)))
+        w_, h_ = w_ // 2, h_ // 2
+    return orders
+
+
+def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None):
+    """n_cases seeded random configurations through `ctx`; returns (mismatches, refused, worst relative L-inf)"""
+    import torch
+    bad, refused, worst = 0, 0, 0.0
+    for c in cases(n_cases, seed, only, big):
+        case, S, b, W, H, spp, sigma, spike, tau, m, ro, mixed = (c[k] for k in ("case", "S", "b", "W", "H", "spp", "sigma", "spike", "tau", "m", "ro", "mixed"))
+        col, ns, hist, cov = c["col"], c["ns"], c["hist"], c["cov"]
+        tag = "%3d: %3dx%-3d S=%d b=%-2d spp=%-2d%s sigma=%.2f spikes=%.2f tau=%.1f -m %g -r %d" % (case, W, H, S, b, spp, "*" if mixed else " ", sigma, spike, tau, m, ro)
+        prm = bh.default_params(m=m, random_order=ro, seed=c["seed"], b=b, tau=tau)
+        d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (col, ns, hist, cov)]
+        try:
+            got = ctx.denoise(*d, S, prm).cpu().numpy()
+        except bh.BcdHipError as e:
+            refused += 1
+            say(tag + "  refused: %s" % str(e)[:90])
+            continue
+        mask, cnt = ctx.similarity_masks(d[2], d[1], 1, b, tau)
+        wmask, wcnt = ol.similarity_masks(ns, hist, 1, b, tau)
+        masks_ok = np.array_equal(mask.cpu().numpy().view(np.uint32), wmask) and np.array_equal(cnt.cpu().numpy(), wcnt)
+        if dump:
+            np.save(os.path.join(dump, "fuzz_%d_%d.npy" % (seed, case)), got)
+        orders = visiting_orders(c)
+        op = ol.params(tau=tau, b=b, m=m)
+        want = ol.denoise_multiscale(col, ns, hist, cov, S, op, orders=orders) if S > 1 else ol.denoise_mono(col, ns, hist, cov, op, order=orders[0] if orders else None)
+        ok = np.isfinite(want)
+        fin_ok = np.array_equal(np.isfinite(got), ok)
+        scale = float(np.max(np.abs(np.where(ok, want, 0)))) or 1.0
+        err = float(np.max(np.abs(np.where(ok, got, 0) - np.where(ok, want, 0))) / scale) if ok.any() else 0.0
+        worst = max(worst, err)
+        good = masks_ok and fin_ok and err < 1e-4
+        bad += 0 if good else 1
+        say(tag + "  masks %s  finite %s  rel Linf %.2e%s" % ("==" if masks_ok else "DIFFER", "==" if fin_ok else "DIFFER", err, "" if good else "   <-- MISMATCH"))
+    return bad, refused, worst
+
+
+def main():
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n_cases = int(argv[0]) if len(argv) > 0 else 60
+    seed = int(argv[1]) if len(argv) > 1 else 2026
+    only, dump = None, None
+    for a in sys.argv[1:]:
+        if a.startswith("--only="):
+            only = set(int(x) for x in a[7:].split(","))
+        if a.startswith("--dump="):
+            dump = a[7:]
+            os.makedirs(dump, exist_ok=True)
+    ctx = bh.Context(0)
+    if "--strict" in sys.argv:
+        bh.set_strict_eigensolver(True)    # the eigensolver's plain stopping rule (1e-12) instead of 2e-9 + first-order correction
+    t0 = time.time()
+    bad, refused, worst = run_cases(ctx, n_cases, seed, say=lambda s: print(s, flush=True), only=only, big="--big" in sys.argv, dump=dump)
+    print("%d cases, %d refused, %d mismatches, worst rel Linf %.2e, %.0f s" % (n_cases, refused, bad, worst, time.time() - t0))
+    ctx.close()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
