@@ -2,8 +2,8 @@
 """GPU box: seeded random configurations of the hot path against the CPU oracle (test infrastructure: the oracle is the checker).
 Frame sizes (ragged, narrower than a tile, odd), scales, search radius, threshold, sample counts (1 .. 48, sometimes mixed per pixel), noise level, -m 0 / -m 1,
 -r 0 / -r 1.  Checks per case: similarity masks and |S| of the finest scale bit for bit, the denoised frame's finite pattern and relative L-inf < 1e-4.
-usage: python tools/fuzz_parity.py [n_cases] [seed] [--big] [--only=i,j,..] [--strict] [--dump=dir]   -> one line per case, a summary, exit code 1 on any mismatch
-(--big: frames up to 700 x 400; --only: evaluate these cases of the sequence; --strict: bcd_hip_set_strict_eigensolver)"""
+usage: python tools/fuzz_parity.py [n_cases] [seed] [--big] [--only=i,j,..] [--strict] [--dump=dir] [--bands]   -> one line per case, a summary, exit code 1 on any mismatch
+(--big: frames up to 700 x 400; --bands: also the row-band driver with 2 .. 4 virtual ranks against the single-GPU frame; --only: evaluate these cases of the sequence; --strict: bcd_hip_set_strict_eigensolver)"""
 import os
 import sys
 import time
@@ -54,10 +54,11 @@ def visiting_orders(c):
     return orders
 
 
-def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None):
+def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, bands=False):
     """n_cases seeded random configurations through `ctx`; returns (mismatches, refused, worst relative L-inf)"""
     import torch
     bad, refused, worst = 0, 0, 0.0
+    rng_b = np.random.default_rng(seed + 1)   # (a stream of its own: the sequence of cases does not depend on --bands)
     for c in cases(n_cases, seed, only, big):
         case, S, b, W, H, spp, sigma, spike, tau, m, ro, mixed = (c[k] for k in ("case", "S", "b", "W", "H", "spp", "sigma", "spike", "tau", "m", "ro", "mixed"))
         col, ns, hist, cov = c["col"], c["ns"], c["hist"], c["cov"]
@@ -84,8 +85,22 @@ def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None):
         err = float(np.max(np.abs(np.where(ok, got, 0) - np.where(ok, want, 0))) / scale) if ok.any() else 0.0
         worst = max(worst, err)
         good = masks_ok and fin_ok and err < 1e-4
+        band_note = ""
+        if bands:  # the row-band driver with 2 .. 4 virtual ranks on this device (in-process transport) against the single-GPU frame
+            ranks = int(rng_b.integers(2, 5))
+            md = bh.MultiDenoiser([0] * ranks)
+            try:
+                gb = md.denoise_host(col, ns, hist, cov, S, prm)
+                eb = float(np.max(np.abs(np.where(ok, gb, 0) - np.where(ok, got, 0))) / scale) if ok.any() else 0.0
+                band_ok = np.array_equal(np.isfinite(gb), np.isfinite(got)) and eb < 1e-5
+                good = good and band_ok
+                band_note = "  %d bands vs one GPU %.1e" % (ranks, eb)
+            except bh.BcdHipError as e:   # (a frame too short for that many bands of that pyramid is declined, not mis-denoised)
+                band_note = "  %d bands declined: %s" % (ranks, str(e)[:60])
+            finally:
+                md.close()
         bad += 0 if good else 1
-        say(tag + "  masks %s  finite %s  rel Linf %.2e%s" % ("==" if masks_ok else "DIFFER", "==" if fin_ok else "DIFFER", err, "" if good else "   <-- MISMATCH"))
+        say(tag + "  masks %s  finite %s  rel Linf %.2e%s%s" % ("==" if masks_ok else "DIFFER", "==" if fin_ok else "DIFFER", err, band_note, "" if good else "   <-- MISMATCH"))
     return bad, refused, worst
 
 
@@ -104,7 +119,7 @@ def main():
     if "--strict" in sys.argv:
         bh.set_strict_eigensolver(True)    # the eigensolver's plain stopping rule (1e-12) instead of 2e-9 + first-order correction
     t0 = time.time()
-    bad, refused, worst = run_cases(ctx, n_cases, seed, say=lambda s: print(s, flush=True), only=only, big="--big" in sys.argv, dump=dump)
+    bad, refused, worst = run_cases(ctx, n_cases, seed, say=lambda s: print(s, flush=True), only=only, big="--big" in sys.argv, dump=dump, bands="--bands" in sys.argv)
     print("%d cases, %d refused, %d mismatches, worst rel Linf %.2e, %.0f s" % (n_cases, refused, bad, worst, time.time() - t0))
     ctx.close()
     sys.exit(1 if bad else 0)
