@@ -1948,3 +1948,9 @@ def test_seeded_random_configurations_against_the_oracle(hipctx):
     lines = []
     bad, refused, worst = fz.run_cases(hipctx, 40, 2026, say=lines.append)
     assert bad == 0 and refused == 0 and worst < TOL, "\n".join(l for l in lines if "MISMATCH" in l or "refused" in l)
+    # ... and thirty of the --wide sequence: host buffers (streamed upload), host buffers + spike prefilter, fractional -m, D = 12 .. 120, w = 0 / 2, -e 1e-3
+    # (600 cases of it ran clean in round 6, worst 3.1e-5), ten of them also through the row-band driver on 2-4 virtual ranks
+    bad, refused, worst = fz.run_cases(hipctx, 30, 31337, say=lines.append, wide=True)
+    assert bad == 0 and refused == 0 and worst < TOL, "\n".join(l for l in lines if "MISMATCH" in l or "refused" in l)
+    bad, refused, worst = fz.run_cases(hipctx, 10, 4242, say=lines.append, bands=True)
+    assert bad == 0 and refused == 0, "\n".join(l for l in lines if "MISMATCH" in l or "refused" in l)

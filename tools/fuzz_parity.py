@@ -2,8 +2,8 @@
 """GPU box: seeded random configurations of the hot path against the CPU oracle (test infrastructure: the oracle is the checker).
 Frame sizes (ragged, narrower than a tile, odd), scales, search radius, threshold, sample counts (1 .. 48, sometimes mixed per pixel), noise level, -m 0 / -m 1,
 -r 0 / -r 1.  Checks per case: similarity masks and |S| of the finest scale bit for bit, the denoised frame's finite pattern and relative L-inf < 1e-4.
-usage: python tools/fuzz_parity.py [n_cases] [seed] [--big] [--only=i,j,..] [--strict] [--dump=dir] [--bands]   -> one line per case, a summary, exit code 1 on any mismatch
-(--big: frames up to 700 x 400; --bands: also the row-band driver with 2 .. 4 virtual ranks against the single-GPU frame; --only: evaluate these cases of the sequence; --strict: bcd_hip_set_strict_eigensolver)"""
+usage: python tools/fuzz_parity.py [n_cases] [seed] [--big] [--only=i,j,..] [--strict] [--dump=dir] [--bands] [--wide]   -> one line per case, a summary, exit code 1 on any mismatch
+(--big: frames up to 700 x 400; --wide: also host buffers / spike prefilter / fractional -m / other depths, patch radii and -e; --bands: also the row-band driver with 2 .. 4 virtual ranks against the single-GPU frame; --only: evaluate these cases of the sequence; --strict: bcd_hip_set_strict_eigensolver)"""
 import os
 import sys
 import time
@@ -44,17 +44,17 @@ def cases(n_cases, seed, only=None, big=False):
         yield dict(case=case, S=S, b=b, W=W, H=H, spp=spp, sigma=sigma, spike=spike, tau=tau, m=m, ro=ro, seed=seed_c, mixed=mixed, col=col, ns=ns, hist=hist, cov=cov)
 
 
-def visiting_orders(c):
+def visiting_orders(c, w=1):
     if c["m"] == 0.0:
         return None
     orders, w_, h_ = [], c["W"], c["H"]
     for s in range(c["S"]):
-        orders.append(bh.visit_order(w_, h_, 1, c["ro"], bh.scale_seed(c["seed"], s)))
+        orders.append(bh.visit_order(w_, h_, w, c["ro"], bh.scale_seed(c["seed"], s)))
         w_, h_ = w_ // 2, h_ // 2
     return orders
 
 
-def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, bands=False):
+def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, bands=False, wide=False):
     """n_cases seeded random configurations through `ctx`; returns (mismatches, refused, worst relative L-inf)"""
     import torch
     bad, refused, worst = 0, 0, 0.0
@@ -62,23 +62,59 @@ def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, ba
     for c in cases(n_cases, seed, only, big):
         case, S, b, W, H, spp, sigma, spike, tau, m, ro, mixed = (c[k] for k in ("case", "S", "b", "W", "H", "spp", "sigma", "spike", "tau", "m", "ro", "mixed"))
         col, ns, hist, cov = c["col"], c["ns"], c["hist"], c["cov"]
-        tag = "%3d: %3dx%-3d S=%d b=%-2d spp=%-2d%s sigma=%.2f spikes=%.2f tau=%.1f -m %g -r %d" % (case, W, H, S, b, spp, "*" if mixed else " ", sigma, spike, tau, m, ro)
-        prm = bh.default_params(m=m, random_order=ro, seed=c["seed"], b=b, tau=tau)
-        d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (col, ns, hist, cov)]
+        # --wide: the other entry points and parameters, drawn from a stream of their own (the sequence of frames stays the plain one)
+        path, w, min_eig, skip_seed, nbins, note = 0, 1, 1e-8, 0, 20, ""
+        if wide:
+            wr = np.random.default_rng([seed, 2, case])
+            path = int(wr.choice([0, 1, 2]))                       # resident buffers / host buffers (streamed upload) / host buffers + spike prefilter
+            if wr.random() < 0.25:
+                m = c["m"] = float(wr.choice([0.3, 0.7]))          # fractional -m: per-pixel hash of the seed, mirrored by the oracle
+                skip_seed = c["seed"]
+            if wr.random() < 0.25:
+                nbins = int(wr.choice([4, 7, 8, 12, 40]))          # D = 12, 21, 24, 36, 120
+                samples, _ = ol.synth_samples(W, H, spp, c["seed"], sigma, spike)
+                ns, col, cov, hist = ol.oracle_ops()["accumulate"](samples, W, H, nbins)
+                mixed = False
+            if wr.random() < 0.15:
+                w = int(wr.choice([0, 2]))                         # generic mask / marking / estimate kernels
+                b = max(b, w + 1)
+                if w == 2 and (min(W, H) >> (S - 1)) < 8:
+                    S = c["S"] = 1
+            if wr.random() < 0.2:
+                min_eig = 1e-3                                     # inverses through the spectral branch
+            note = " path=%d w=%d D=%d e=%g" % (path, w, 3 * nbins, min_eig)
+        tag = "%3d: %3dx%-3d S=%d b=%-2d spp=%-2d%s sigma=%.2f spikes=%.2f tau=%.1f -m %g -r %d%s" % (case, W, H, S, b, spp, "*" if mixed else " ", sigma, spike, tau, m, ro, note)
+        prm = bh.default_params(m=m, random_order=ro, seed=c["seed"], b=b, tau=tau, w=w, min_eig=min_eig)
+        col, ns, hist, cov = (np.ascontiguousarray(a, np.float32) for a in (col, ns, hist, cov))
+        ocol, ons, ohist, ocov = col, ns, hist, cov                # what the oracle denoises (the filtered frame when the prefilter is on)
         try:
-            got = ctx.denoise(*d, S, prm).cpu().numpy()
+            if path == 0:
+                d = [torch.from_numpy(a).cuda() for a in (col, ns, hist, cov)]
+                got = ctx.denoise(*d, S, prm).cpu().numpy()
+            elif path == 1:
+                got = ctx.denoise_host(col, ns, hist, cov, S, prm)
+            else:
+                got = ctx.denoise_host(col, ns, hist, cov, S, prm, spike_factor=2.0)
+                ocol, ons, ohist, ocov = ol.oracle_ops()["spike"](col, ns, hist, cov, 2.0)
         except bh.BcdHipError as e:
             refused += 1
             say(tag + "  refused: %s" % str(e)[:90])
             continue
-        mask, cnt = ctx.similarity_masks(d[2], d[1], 1, b, tau)
-        wmask, wcnt = ol.similarity_masks(ns, hist, 1, b, tau)
+        d_hist, d_ns = torch.from_numpy(np.ascontiguousarray(ohist)).cuda(), torch.from_numpy(np.ascontiguousarray(ons)).cuda()
+        mask, cnt = ctx.similarity_masks(d_hist, d_ns, w, b, tau)
+        wmask, wcnt = ol.similarity_masks(ons, ohist, w, b, tau)
         masks_ok = np.array_equal(mask.cpu().numpy().view(np.uint32), wmask) and np.array_equal(cnt.cpu().numpy(), wcnt)
         if dump:
             np.save(os.path.join(dump, "fuzz_%d_%d.npy" % (seed, case)), got)
-        orders = visiting_orders(c)
-        op = ol.params(tau=tau, b=b, m=m)
-        want = ol.denoise_multiscale(col, ns, hist, cov, S, op, orders=orders) if S > 1 else ol.denoise_mono(col, ns, hist, cov, op, order=orders[0] if orders else None)
+        orders = visiting_orders(c, w)
+        op = ol.params(tau=tau, w=w, b=b, m=m, min_eig=min_eig, skip_seed=skip_seed)
+        try:
+            want = (ol.denoise_multiscale(ocol, ons, ohist, ocov, S, op, orders=orders) if S > 1 else
+                    ol.denoise_mono(ocol, ons, ohist, ocov, op, order=orders[0] if orders else None))
+        except AssertionError as e:   # (the oracle declines a geometry the engine accepted: reported, counted as a mismatch)
+            bad += 1
+            say(tag + "  oracle declined (rc %s)   <-- MISMATCH" % e)
+            continue
         ok = np.isfinite(want)
         fin_ok = np.array_equal(np.isfinite(got), ok)
         scale = float(np.max(np.abs(np.where(ok, want, 0)))) or 1.0
@@ -86,7 +122,7 @@ def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, ba
         worst = max(worst, err)
         good = masks_ok and fin_ok and err < 1e-4
         band_note = ""
-        if bands:  # the row-band driver with 2 .. 4 virtual ranks on this device (in-process transport) against the single-GPU frame
+        if bands and path != 2:  # the row-band driver with 2 .. 4 virtual ranks on this device (in-process transport) against the single-GPU frame
             ranks = int(rng_b.integers(2, 5))
             md = bh.MultiDenoiser([0] * ranks)
             try:
@@ -119,7 +155,7 @@ def main():
     if "--strict" in sys.argv:
         bh.set_strict_eigensolver(True)    # the eigensolver's plain stopping rule (1e-12) instead of 2e-9 + first-order correction
     t0 = time.time()
-    bad, refused, worst = run_cases(ctx, n_cases, seed, say=lambda s: print(s, flush=True), only=only, big="--big" in sys.argv, dump=dump, bands="--bands" in sys.argv)
+    bad, refused, worst = run_cases(ctx, n_cases, seed, say=lambda s: print(s, flush=True), only=only, big="--big" in sys.argv, dump=dump, bands="--bands" in sys.argv, wide="--wide" in sys.argv)
     print("%d cases, %d refused, %d mismatches, worst rel Linf %.2e, %.0f s" % (n_cases, refused, bad, worst, time.time() - t0))
     ctx.close()
     sys.exit(1 if bad else 0)
