@@ -122,8 +122,8 @@ def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, ba
         worst = max(worst, err)
         good = masks_ok and fin_ok and err < 1e-4
         band_note = ""
-        if bands and path != 2:  # the row-band driver with 2 .. 4 virtual ranks on this device (in-process transport) against the single-GPU frame
-            ranks = int(rng_b.integers(2, 5))
+        if bands and path != 2:  # the row-band driver with 2 .. 4 (--big: 2 .. 8) virtual ranks on this device (in-process transport) against the single-GPU frame
+            ranks = int(rng_b.integers(2, 9 if big else 5))
             md = bh.MultiDenoiser([0] * ranks)
             try:
                 gb = md.denoise_host(col, ns, hist, cov, S, prm)
