@@ -497,16 +497,17 @@ def main():
             w7, h7 = 1280, 720
             d7 = [torch.from_numpy(a).cuda() for a in core.synthetic_scene(w7, h7, args.spp, 1234, args.sigma, args.spikes)]
             out7 = torch.empty((h7, w7, 3), dtype=torch.float32, device="cuda")
-            ctx.denoise(*d7, S, prm, out7)
-            ctx.denoise(*d7, S, prm, out7)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(3):   # (a new geometry: workspaces, the marking batch and the coarse scales' CU share settle over the first calls)
                 ctx.denoise(*d7, S, prm, out7)
             torch.cuda.synchronize()
-            ms7 = (time.perf_counter() - t1) * 1e3 / 5
-            extras["frame_720p"] = {"value": round(w7 * h7 / 1e6 / (ms7 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms7, 4), "steps": 5,
-                                    "workload": "1280x720 frame of the same generator and flags (BASELINE configs[1]), inputs resident"}
+            each7 = []
+            for _ in range(7):
+                t2 = time.perf_counter()
+                ctx.denoise(*d7, S, prm, out7)   # (a blocking call)
+                each7.append(round((time.perf_counter() - t2) * 1e3, 3))
+            ms7 = sorted(each7)[len(each7) // 2]   # the median call: one slow call of seven (seen once: 23 ms) is reported in ms_each, not averaged in
+            extras["frame_720p"] = {"value": round(w7 * h7 / 1e6 / (ms7 * 1e-3), 3), "unit": "Mpix/s", "ms_per_step": round(ms7, 4), "steps": 7, "ms_each": each7,
+                                    "workload": "1280x720 frame of the same generator and flags (BASELINE configs[1]), inputs resident; median of seven blocking calls"}
             del d7, out7
         # BASELINE configs[3]'s frame on this one GPU: the N = 1 point of the 4K strong-scaling curve (north_star), untimed leg
         if not args.no_4k:
