@@ -2,8 +2,8 @@
 """GPU box: seeded random configurations of the hot path against the CPU oracle (test infrastructure: the oracle is the checker).
 Frame sizes (ragged, narrower than a tile, odd), scales, search radius, threshold, sample counts (1 .. 48, sometimes mixed per pixel), noise level, -m 0 / -m 1,
 -r 0 / -r 1.  Checks per case: similarity masks and |S| of the finest scale bit for bit, the denoised frame's finite pattern and relative L-inf < 1e-4.
-usage: python tools/fuzz_parity.py [n_cases] [seed] [--big] [--only=i,j,..] [--strict] [--dump=dir] [--bands] [--wide]   -> one line per case, a summary, exit code 1 on any mismatch
-(--big: frames up to 700 x 400; --wide: also host buffers / spike prefilter / fractional -m / other depths, patch radii and -e; --bands: also the row-band driver with 2 .. 4 virtual ranks against the single-GPU frame; --only: evaluate these cases of the sequence; --strict: bcd_hip_set_strict_eigensolver)"""
+usage: python tools/fuzz_parity.py [n_cases] [seed] [--big] [--only=i,j,..] [--strict] [--dump=dir] [--bands] [--wide] [--rccl]   -> one line per case, a summary, exit code 1 on any mismatch
+(--big: frames up to 700 x 400; --wide: also host buffers / spike prefilter / fractional -m / other depths, patch radii and -e; --rccl: also one rank of the band driver with RCCL in loopback against the single-GPU frame; --bands: also the row-band driver with 2 .. 4 virtual ranks against the single-GPU frame; --only: evaluate these cases of the sequence; --strict: bcd_hip_set_strict_eigensolver)"""
 import os
 import sys
 import time
@@ -54,7 +54,7 @@ def visiting_orders(c, w=1):
     return orders
 
 
-def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, bands=False, wide=False):
+def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, bands=False, wide=False, rccl=False):
     """n_cases seeded random configurations through `ctx`; returns (mismatches, refused, worst relative L-inf)"""
     import torch
     bad, refused, worst = 0, 0, 0.0
@@ -135,6 +135,25 @@ def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, ba
                 band_note = "  %d bands declined: %s" % (ranks, str(e)[:60])
             finally:
                 md.close()
+        if rccl and path != 2:  # rank 0 of 1 in loopback: every exchange / all-reduce of the band protocol on real RCCL communicators, the rank its own neighbour
+            try:
+                rd = bh.RankDenoiser(0, 1, 0, bh.multi_unique_ids(S + 1))
+                try:
+                    rd.set_loopback(True)
+                    rd.configure(W, H, hist.shape[2], S, prm)
+                    rd.upload(col, ns, hist, cov)
+                    rd.step()
+                    gr = rd.download()
+                    rd.step()                      # (steady state: the same communicators, a second frame)
+                    gr2 = rd.download()
+                    tr = rd.stats().transport
+                finally:
+                    rd.close()
+                er = max(float(np.max(np.abs(np.where(ok, g_, 0) - np.where(ok, got, 0))) / scale) if ok.any() else 0.0 for g_ in (gr, gr2))
+                good = good and tr == 1 and er < 1e-5
+                band_note += "  RCCL loopback vs one GPU %.1e" % er
+            except bh.BcdHipError as e:
+                band_note += "  RCCL loopback declined: %s" % str(e)[:60]
         bad += 0 if good else 1
         say(tag + "  masks %s  finite %s  rel Linf %.2e%s%s" % ("==" if masks_ok else "DIFFER", "==" if fin_ok else "DIFFER", err, band_note, "" if good else "   <-- MISMATCH"))
     return bad, refused, worst
@@ -155,7 +174,7 @@ def main():
     if "--strict" in sys.argv:
         bh.set_strict_eigensolver(True)    # the eigensolver's plain stopping rule (1e-12) instead of 2e-9 + first-order correction
     t0 = time.time()
-    bad, refused, worst = run_cases(ctx, n_cases, seed, say=lambda s: print(s, flush=True), only=only, big="--big" in sys.argv, dump=dump, bands="--bands" in sys.argv, wide="--wide" in sys.argv)
+    bad, refused, worst = run_cases(ctx, n_cases, seed, say=lambda s: print(s, flush=True), only=only, big="--big" in sys.argv, dump=dump, bands="--bands" in sys.argv, wide="--wide" in sys.argv, rccl="--rccl" in sys.argv)
     print("%d cases, %d refused, %d mismatches, worst rel Linf %.2e, %.0f s" % (n_cases, refused, bad, worst, time.time() - t0))
     ctx.close()
     sys.exit(1 if bad else 0)
