@@ -130,8 +130,8 @@ def run_cases(ctx, n_cases, seed, say=print, only=None, big=False, dump=None, ba
         ok = np.isfinite(want)
         fin_ok = np.array_equal(np.isfinite(got), ok)
         if nan and not fin_ok:
-            # Non-finite INPUT values (the reference's CLI zeroes them before the hot path: checkAndPutToZeroNegativeInfNaNValues, src/cli/main.cpp) are outside
-            # the parity contract; what is checked: the HIP path never yields a non-finite value where the oracle's is finite, and agrees wherever both are finite
+            # Non-finite INPUT values cannot be pinned to the reference (what it does with a NaN matrix is what Eigen's solver leaves in its eigenvectors; its CLI
+            # zeroes non-finite values of the OUTPUT, src/cli/main.cpp:389-470); what is checked: the HIP path never yields a non-finite value where the oracle's is finite, and agrees wherever both are finite
             hip_bad, ora_bad = ~np.isfinite(got), ~ok
             fin_ok = not bool((hip_bad & ~ora_bad).any())
             tag += "  [non-finite: oracle %d values, HIP %d, HIP only %d]" % (int(ora_bad.sum()), int(hip_bad.sum()), int((hip_bad & ~ora_bad).sum()))
